@@ -1,0 +1,139 @@
+"""Oracle (test infrastructure): the two networks' composition + CamCalib->SPEC hand-off.
+
+CPU restatement of the in-tree reference code (cannot travel to the GPU box):
+  * ``HMROracle``       <- ``spec/models/hmr.py:28-122``
+  * ``CamCalibOracle``  <- ``camcalib/model.py:24-81``
+  * ``decode_angles``   <- ``camcalib/cam_utils.py:110-118,121-145`` (soft-argmax branch)
+  * ``focal_from_vfov`` <- ``scripts/camcalib_demo.py:127-129``
+  * ``cam_params``      <- ``spec/utils/cam_params.py:24-50`` (R, K construction, K[2,2]=0)
+Pinned against the reference's own modules by tests/golden (see oracle/refshim.py).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .resnet import ResNet50Trunk, get_backbone_info
+from .heads import HMRHead, SMPLCamHead, SMPLHead, set_assets  # noqa: F401
+from .geometry import softargmax1d, batch_euler2matrix
+
+VFOV_RANGE = (0.2617, 2.1)     # np.min/np.max of vfov_bins, camcalib/cam_utils.py:60
+PITCH_RANGE = (-0.6, 0.6)      # pitch_bins, camcalib/cam_utils.py:39
+ROLL_RANGE = (-0.6, 0.6)       # literal, camcalib/cam_utils.py:133
+
+
+class CamCalibOracle(nn.Module):
+    """camcalib/model.py:25-57 (num_fc_layers == 1 branch) and forward :72-81."""
+
+    def __init__(self, backbone='resnet50', num_fc_layers=1, num_fc_channels=1024,
+                 num_out_channels=256):
+        super().__init__()
+        assert num_fc_layers == 1
+        self.backbone = ResNet50Trunk()
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        c = get_backbone_info(backbone)['n_output_channels']
+        self.fc_vfov = nn.Linear(c, num_out_channels)
+        self.fc_pitch = nn.Linear(c, num_out_channels)
+        self.fc_roll = nn.Linear(c, num_out_channels)
+
+    def forward(self, images):
+        x = torch.flatten(self.avgpool(self.backbone(images)), 1)
+        return [self.fc_vfov(x), self.fc_pitch(x), self.fc_roll(x)]
+
+
+def _soft_idx_to_angle(soft_idx, lo, hi):
+    return (hi - lo) * ((soft_idx + 1) / 2) + lo          # camcalib/cam_utils.py:110-111
+
+
+def _get_softargmax(pred):
+    out, _ = softargmax1d(pred.unsqueeze(1), normalize_keypoints=True)   # cam_utils.py:114-118
+    return out.reshape(-1)
+
+
+@torch.no_grad()
+def decode_angles(pred_vfov, pred_pitch, pred_roll):
+    """softargmax_l2 / softargmax_biased_l2, non-legacy branch (cam_utils.py:127-133).
+    The range ends are NumPy float64 scalars in the reference; tensor * python-float keeps fp32."""
+    vfov = _soft_idx_to_angle(_get_softargmax(pred_vfov), float(np.float64(VFOV_RANGE[0])), float(np.float64(VFOV_RANGE[1])))
+    pitch = _soft_idx_to_angle(_get_softargmax(pred_pitch), *PITCH_RANGE)
+    roll = _soft_idx_to_angle(_get_softargmax(pred_roll), *ROLL_RANGE)
+    return vfov, pitch, roll
+
+
+def focal_from_vfov(vfov, img_h):
+    """scripts/camcalib_demo.py:129 - NumPy on host, float64 result for a python-number height."""
+    return img_h / 2. / np.tan(np.asarray(vfov) / 2.)
+
+
+def cam_params(pitch, roll, f_pix, img_w, img_h):
+    """spec/utils/cam_params.py:37-48 batched: R = euler2matrix([pitch,0,roll]); K with K[2,2]=0."""
+    pitch = torch.as_tensor(pitch, dtype=torch.float32).reshape(-1)
+    roll = torch.as_tensor(roll, dtype=torch.float32).reshape(-1)
+    B = pitch.shape[0]
+    R = batch_euler2matrix(torch.stack([pitch, torch.zeros_like(pitch), roll], dim=1).float())
+    K = torch.zeros(B, 3, 3)
+    f = torch.as_tensor(np.asarray(f_pix), dtype=torch.float32).reshape(-1)
+    K[:, 0, 0] = f
+    K[:, 1, 1] = f
+    K[:, 0, 2] = torch.as_tensor(img_w, dtype=torch.float32) / 2
+    K[:, 1, 2] = torch.as_tensor(img_h, dtype=torch.float32) / 2
+    return R, K.float()
+
+
+class HMROracle(nn.Module):
+    """spec/models/hmr.py:29-122 (resnet50 branch)."""
+
+    def __init__(self, backbone='resnet50', focal_length=5000., img_res=224, pretrained=None,
+                 use_cam=False, p=0.0, estimate_var=False, use_separate_var_branch=False,
+                 uncertainty_activation='', use_cam_feats=False):
+        super().__init__()
+        self.backbone = ResNet50Trunk()
+        self.use_cam_feats = use_cam_feats
+        self.head = HMRHead(num_input_features=get_backbone_info(backbone)['n_output_channels'],
+                            backbone=backbone, use_cam_feats=use_cam_feats)
+        self.use_cam = use_cam
+        self.smpl = SMPLCamHead(img_res=img_res) if use_cam else SMPLHead(focal_length=focal_length, img_res=img_res)
+
+    def forward(self, images, cam_rotmat=None, cam_intrinsics=None, bbox_scale=None,
+                bbox_center=None, img_w=None, img_h=None):
+        features = self.backbone(images)                                             # :92
+        if self.use_cam_feats:
+            cam_vfov = 2 * torch.atan(img_h / (2 * cam_intrinsics[:, 0, 0]))         # :95
+            hmr_output = self.head(features, cam_rotmat=cam_rotmat, cam_vfov=cam_vfov)
+        else:
+            hmr_output = self.head(features)
+        if self.use_cam:
+            smpl_output = self.smpl(rotmat=hmr_output['pred_pose'], shape=hmr_output['pred_shape'],
+                                    cam=hmr_output['pred_cam'], cam_rotmat=cam_rotmat,
+                                    cam_intrinsics=cam_intrinsics, bbox_scale=bbox_scale,
+                                    bbox_center=bbox_center, img_w=img_w, img_h=img_h,
+                                    normalize_joints2d=False)                         # :101-112
+        else:
+            smpl_output = self.smpl(rotmat=hmr_output['pred_pose'], shape=hmr_output['pred_shape'],
+                                    cam=hmr_output['pred_cam'], normalize_joints2d=True)  # :115-120
+        smpl_output.update(hmr_output)
+        return smpl_output
+
+
+def load_numpy_state(module, state, prefix=''):
+    """Load a name->ndarray dict (spec_amd.synth) into an oracle module, non-strict on smpl.*"""
+    sd = {k[len(prefix):]: torch.from_numpy(np.ascontiguousarray(v)) for k, v in state.items()
+          if k.startswith(prefix)}
+    missing, unexpected = module.load_state_dict(sd, strict=False)
+    missing = [m for m in missing if not m.startswith('smpl.')]
+    assert not missing and not unexpected, (missing, unexpected)
+    return module
+
+
+@torch.no_grad()
+def full_pipeline(camcalib, hmr, images, bbox_scale, bbox_center, img_w, img_h):
+    """CamCalib -> decode -> (R, K) -> SPEC, fused in-process (the reference does this through
+    a subprocess + pickle, spec/tester.py:86-88,135-141).  All inputs are CPU tensors."""
+    logits = camcalib(images)
+    vfov, pitch, roll = decode_angles(*logits)
+    f_pix = (img_h / 2. / torch.tan(vfov / 2.)).float()
+    R, K = cam_params(pitch, roll, f_pix, img_w, img_h)
+    out = hmr(images, cam_rotmat=R, cam_intrinsics=K, bbox_scale=bbox_scale,
+              bbox_center=bbox_center, img_w=img_w, img_h=img_h)
+    out.update({'cam_vfov': vfov, 'cam_pitch': pitch, 'cam_roll': roll, 'cam_f_pix': f_pix,
+                'cam_rotmat': R, 'cam_intrinsics': K})
+    return out

@@ -1,0 +1,237 @@
+"""Deterministic synthetic parameters and inputs for the SPEC hot path.
+
+No checkpoints, SMPL model files or datasets can be shipped (licence-gated ~1 GB download,
+reference ``scripts/prepare_data.sh:4-11``), so every test and the benchmark run on
+*synthetic* tensors of the real shapes.  The generator is a counter-based SplitMix64 hash
+evaluated with NumPy integer arithmetic plus IEEE add/multiply only (no libm calls), so the
+same seed gives bit-identical float32 tensors on any host - the golden fixtures under
+``tests/golden`` store only seeds + expected outputs.
+
+State-dict key names follow the layouts in SURVEY.md App. C (torchvision ResNet-50 trunk,
+``fc_vfov/fc_pitch/fc_roll`` for CamCalib, ``head.*`` for the HMR regressor).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+
+from . import constants as C
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    """SplitMix64 finaliser on a uint64 array (wrapping arithmetic)."""
+    with np.errstate(over='ignore'):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        z = x
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def _stream_key(seed: int, name: str) -> np.uint64:
+    """Mix an integer seed with a tensor name into a 64-bit stream key (FNV-1a + SplitMix)."""
+    h = 0xCBF29CE484222325
+    for ch in name.encode():
+        h = ((h ^ ch) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    h ^= (seed * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    return _splitmix64(np.array([h], dtype=np.uint64))[0]
+
+
+def uniform01(seed: int, name: str, n: int, lane: int = 0) -> np.ndarray:
+    """n float64 values in [0,1) with 24 random mantissa bits (exactly representable in fp32)."""
+    key = _stream_key(seed, name)
+    with np.errstate(over='ignore'):
+        ctr = (np.arange(n, dtype=np.uint64) * np.uint64(8) + np.uint64(lane)) & _M64
+        bits = _splitmix64(ctr ^ key)
+    return (bits >> np.uint64(40)).astype(np.float64) * (1.0 / 16777216.0)
+
+
+def uniform(seed, name, shape, lo=0.0, hi=1.0) -> np.ndarray:
+    n = int(np.prod(shape)) if len(shape) else 1
+    u = uniform01(seed, name, n)
+    return (lo + (hi - lo) * u).astype(np.float32).reshape(shape)
+
+
+def normal(seed, name, shape, std=1.0, mean=0.0) -> np.ndarray:
+    """Approximately normal (Irwin-Hall of 4 uniforms, unit variance) - adds/multiplies only."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    s = uniform01(seed, name, n, 0) + uniform01(seed, name, n, 1) \
+        + uniform01(seed, name, n, 2) + uniform01(seed, name, n, 3)
+    z = (s - 2.0) * 1.7320508075688772
+    return (mean + std * z).astype(np.float32).reshape(shape)
+
+
+# --------------------------------------------------------------------------------------
+# ResNet-50 trunk (torchvision v1.5 layout, no avgpool / fc)
+# --------------------------------------------------------------------------------------
+
+RESNET50_BLOCKS = (3, 4, 6, 3)
+RESNET50_PLANES = (64, 128, 256, 512)
+
+
+def resnet50_conv_specs():
+    """List of (name, cin, cout, k, stride, pad, bn_name) in state-dict order."""
+    specs = [('conv1', 3, 64, 7, 2, 3, 'bn1')]
+    inplanes = 64
+    for li, (nb, planes) in enumerate(zip(RESNET50_BLOCKS, RESNET50_PLANES), start=1):
+        for b in range(nb):
+            stride = 2 if (b == 0 and li > 1) else 1
+            p = f'layer{li}.{b}'
+            specs.append((f'{p}.conv1', inplanes, planes, 1, 1, 0, f'{p}.bn1'))
+            specs.append((f'{p}.conv2', planes, planes, 3, stride, 1, f'{p}.bn2'))
+            specs.append((f'{p}.conv3', planes, planes * 4, 1, 1, 0, f'{p}.bn3'))
+            if b == 0:
+                specs.append((f'{p}.downsample.0', inplanes, planes * 4, 1, stride, 0,
+                              f'{p}.downsample.1'))
+            inplanes = planes * 4
+    return specs
+
+
+def resnet50_state(seed: int, prefix: str = '') -> 'OrderedDict[str, np.ndarray]':
+    """Random ResNet-50 trunk parameters with activations kept O(1) through 16 blocks."""
+    sd = OrderedDict()
+    for (name, cin, cout, k, _s, _p, bn) in resnet50_conv_specs():
+        fan_in = cin * k * k
+        sd[f'{prefix}{name}.weight'] = normal(seed, name + '.weight', (cout, cin, k, k),
+                                               std=math.sqrt(2.0 / fan_in))
+        if bn.endswith('bn3'):
+            g0 = 0.25          # damp the residual branch
+        elif bn.endswith('downsample.1'):
+            g0 = 0.7           # no ReLU follows: halve the variance gain
+        else:
+            g0 = 1.0
+        sd[f'{prefix}{bn}.weight'] = (g0 * (1.0 + 0.1 * normal(seed, bn + '.weight', (cout,)))).astype(np.float32)
+        sd[f'{prefix}{bn}.bias'] = normal(seed, bn + '.bias', (cout,), std=0.05)
+        sd[f'{prefix}{bn}.running_mean'] = normal(seed, bn + '.running_mean', (cout,), std=0.1)
+        sd[f'{prefix}{bn}.running_var'] = uniform(seed, bn + '.running_var', (cout,), 0.8, 1.2)
+        sd[f'{prefix}{bn}.num_batches_tracked'] = np.array(0, dtype=np.int64)
+    return sd
+
+
+def camcalib_state(seed: int = 1001, fc_std: float = 0.05, nbins: int = C.NUM_CAMCALIB_BINS):
+    """CameraRegressorNetwork(num_fc_layers=1) parameters (camcalib/model.py:40-52 layout)."""
+    sd = resnet50_state(seed, 'backbone.')
+    for head in ('fc_vfov', 'fc_pitch', 'fc_roll'):
+        sd[f'{head}.weight'] = normal(seed, head + '.weight', (nbins, 2048), std=fc_std)
+        sd[f'{head}.bias'] = normal(seed, head + '.bias', (nbins,), std=0.1)
+    return sd
+
+
+def _random_rot6d(seed, name, n):
+    """rot6d (first two columns, row-major 3x2) of n random rotations: returns (n*6,) fp32."""
+    a = normal(seed, name + '.a', (n, 3)).astype(np.float64)
+    b = normal(seed, name + '.b', (n, 3)).astype(np.float64)
+    a = 0.35 * a + np.array([1.0, 0.0, 0.0])
+    b = 0.35 * b + np.array([0.0, 1.0, 0.0])
+    # 6d layout is x.view(-1,3,2): element [i, c] = column c, row i
+    out = np.stack([a, b], axis=-1)  # (n,3,2)
+    return out.reshape(-1).astype(np.float32)
+
+
+def hmr_state(seed: int = 1002, use_cam_feats: bool = True, dec_gain: float = 1.0):
+    """HMR parameters: trunk + HMRHead (fc1, fc2, decpose, decshape, deccam, init_*)."""
+    sd = resnet50_state(seed, 'backbone.')
+    nin = 2048 + 144 + 13 + (7 if use_cam_feats else 0)
+
+    def linear(name, nout, nin_, bound=None, bias_bound=None):
+        bound = (1.0 / math.sqrt(nin_)) if bound is None else bound
+        bias_bound = (1.0 / math.sqrt(nin_)) if bias_bound is None else bias_bound
+        sd[f'head.{name}.weight'] = uniform(seed, f'head.{name}.weight', (nout, nin_), -bound, bound)
+        sd[f'head.{name}.bias'] = uniform(seed, f'head.{name}.bias', (nout,), -bias_bound, bias_bound)
+
+    linear('fc1', 1024, nin)
+    linear('fc2', 1024, 1024)
+    # upstream uses xavier_uniform(gain=0.01); a larger gain makes the synthetic poses vary
+    # between images so that parity tests exercise the full rot6d / LBS range.
+    for name, nout in (('decpose', 144), ('decshape', 10), ('deccam', 3)):
+        xav = dec_gain * 0.25 * math.sqrt(6.0 / (1024 + nout))
+        linear(name, nout, 1024, bound=xav, bias_bound=0.01)
+    sd['head.init_pose'] = _random_rot6d(seed, 'head.init_pose', 24).reshape(1, 144)
+    sd['head.init_shape'] = normal(seed, 'head.init_shape', (1, 10), std=0.5)
+    sd['head.init_cam'] = np.array([[0.9, 0.0, 0.0]], dtype=np.float32) \
+        + normal(seed, 'head.init_cam', (1, 3), std=0.02)
+    return sd
+
+
+# --------------------------------------------------------------------------------------
+# SMPL-shaped body model
+# --------------------------------------------------------------------------------------
+
+def smpl_model(seed: int = 1003, nv: int = C.NUM_SMPL_VERTS):
+    """A synthetic body model with the tensor shapes/dtypes of smplx.SMPL (+ SPIN extras).
+
+    Keys: v_template (nv,3), shapedirs (nv,3,10), posedirs (207, nv*3), J_regressor (24,nv),
+    lbs_weights (nv,24), J_regressor_extra (9,nv), parents (24,) int32,
+    extra_vertex_ids (21,) int32, joint_map (49,) int32.
+    """
+    m = OrderedDict()
+    box = np.array([0.6, 1.7, 0.3], dtype=np.float64)
+    vt = (uniform01(seed, 'v_template', nv * 3).reshape(nv, 3) - 0.5) * box
+    m['v_template'] = vt.astype(np.float32)
+    m['shapedirs'] = normal(seed, 'shapedirs', (nv, 3, 10), std=0.01)
+    m['posedirs'] = normal(seed, 'posedirs', (C.NUM_POSE_BASIS, nv * 3), std=0.002)
+
+    def sparse_rows(name, rows, nnz):
+        w = np.zeros((rows, nv), dtype=np.float64)
+        idx = (uniform01(seed, name + '.idx', rows * nnz) * nv).astype(np.int64).reshape(rows, nnz)
+        val = uniform01(seed, name + '.val', rows * nnz).reshape(rows, nnz) + 0.05
+        for r in range(rows):
+            np.add.at(w[r], idx[r], val[r])
+        w /= w.sum(axis=1, keepdims=True)
+        return w.astype(np.float32)
+
+    m['J_regressor'] = sparse_rows('J_regressor', 24, 48)
+    m['J_regressor_extra'] = sparse_rows('J_regressor_extra', C.NUM_EXTRA_REGRESSED, 32)
+
+    lw = np.zeros((nv, 24), dtype=np.float64)
+    jidx = (uniform01(seed, 'lbs.idx', nv * 4) * 24).astype(np.int64).reshape(nv, 4)
+    jval = uniform01(seed, 'lbs.val', nv * 4).reshape(nv, 4) + 0.05
+    np.add.at(lw, (np.repeat(np.arange(nv), 4), jidx.reshape(-1)), jval.reshape(-1))
+    lw /= lw.sum(axis=1, keepdims=True)
+    m['lbs_weights'] = lw.astype(np.float32)
+
+    m['parents'] = np.array(C.SMPL_PARENTS, dtype=np.int32)
+    ids = np.array(C.SMPL_EXTRA_VERTEX_IDS, dtype=np.int64)
+    if nv != C.NUM_SMPL_VERTS:
+        ids = ids % nv
+    m['extra_vertex_ids'] = ids.astype(np.int32)
+    m['joint_map'] = np.array(C.JOINT_MAP49, dtype=np.int32)
+    return m
+
+
+# --------------------------------------------------------------------------------------
+# inputs
+# --------------------------------------------------------------------------------------
+
+def images(seed: int, batch: int, h: int = 224, w: int = 224) -> np.ndarray:
+    """(B,3,H,W) fp32 crops: uniform[0,1) pixels, ImageNet-normalised (spec/constants.py:20-21)."""
+    x = uniform01(seed, 'images', batch * 3 * h * w).reshape(batch, 3, h, w)
+    # per-image contrast / per-channel brightness / a horizontal ramp, so that images (and the
+    # features, camera angles and poses regressed from them) differ from one another
+    gain = 0.25 + 0.75 * uniform01(seed, 'images.gain', batch).reshape(batch, 1, 1, 1)
+    offs = 0.5 * uniform01(seed, 'images.offset', batch * 3).reshape(batch, 3, 1, 1)
+    ramp = (uniform01(seed, 'images.ramp', batch).reshape(batch, 1, 1, 1) - 0.5) \
+        * np.linspace(-1.0, 1.0, w).reshape(1, 1, 1, w)
+    x = np.clip(x * gain + offs * (1.0 - gain) + 0.5 * ramp, 0.0, 1.0)
+    mean = np.array(C.IMG_NORM_MEAN).reshape(1, 3, 1, 1)
+    std = np.array(C.IMG_NORM_STD).reshape(1, 3, 1, 1)
+    return ((x - mean) / std).astype(np.float32)
+
+
+def bbox_inputs(seed: int, batch: int, img_w: float = 224.0, img_h: float = 224.0, jitter: bool = True):
+    """Per-image scalars in the tester's convention (spec/tester.py:127-134):
+    bbox_scale = bbox_h / 200, bbox_center = (cx, cy), img_w, img_h."""
+    if jitter:
+        scale = uniform(seed, 'bbox_scale', (batch,), 0.8, 1.4)
+        center = np.stack([uniform(seed, 'bbox_cx', (batch,), 0.35 * img_w, 0.65 * img_w),
+                           uniform(seed, 'bbox_cy', (batch,), 0.35 * img_h, 0.65 * img_h)], axis=1)
+    else:
+        scale = np.full((batch,), 224.0 / 200.0, dtype=np.float32)
+        center = np.tile(np.array([[img_w / 2, img_h / 2]], dtype=np.float32), (batch, 1))
+    return (scale.astype(np.float32), center.astype(np.float32),
+            np.full((batch,), img_w, dtype=np.float32), np.full((batch,), img_h, dtype=np.float32))
