@@ -1,0 +1,187 @@
+/*
+ * specmi.h - C ABI of the MI355X-native SPEC inference hot path (libspecmi.so).
+ *
+ * The reference (mkocabas/SPEC) has NO native/FFI seam for this path: its boundary is two
+ * Python nn.Module classes whose leaf ops are stock torch ops,
+ *
+ *   spec/models/hmr.py:28-122      class HMR            (trunk -> HMRHead -> SMPLCamHead)
+ *   camcalib/model.py:24-81        class CameraRegressorNetwork (trunk -> avgpool -> 3 FC)
+ *   camcalib/cam_utils.py:110-145  soft-argmax decode of the 256-bin logits
+ *   spec/utils/cam_params.py:24-50 (pitch, roll, f) -> cam_rotmat, cam_intrinsics
+ *
+ * so this header DEFINES the boundary a maintainer would bind (ctypes stub in
+ * INTEGRATION.md).  Each entry point names the reference interface it replaces.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only; no exceptions cross the ABI.
+ *   - return 0 (SPECMI_OK) or an error code; the message is kept per handle
+ *     (specmi_last_error).  Passing h == NULL to specmi_last_error returns the last error
+ *     of a failed specmi_create.
+ *   - parameters are handed over as HOST pointers in the canonical PyTorch layouts under
+ *     their state_dict key names; the library folds BatchNorm into a
+ *     per-channel scale/shift, re-lays the weights out for the MFMA kernels and uploads
+ *     them at specmi_commit.
+ *   - every forward I/O buffer is a caller-owned DEVICE pointer (torch.Tensor.data_ptr());
+ *     the library owns only the packed weights and its workspace.  All work is enqueued on
+ *     the caller's HIP stream (`stream` is a hipStream_t passed as void*; NULL = default
+ *     stream); no call synchronises the device except specmi_commit, specmi_destroy and
+ *     specmi_profile_read.
+ *   - one handle per model instance; a handle is not thread-safe (the reference is
+ *     single-threaded), distinct handles are independent.
+ *   - all arithmetic is IEEE fp32 (reference inference never enables AMP:
+ *     spec/config.py:138, spec/tester.py:109-110); index tables are int32.
+ */
+#ifndef SPECMI_H
+#define SPECMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct specmi_handle specmi_handle;
+
+enum {
+    SPECMI_OK = 0,
+    SPECMI_ERR_ARG = 1,     /* bad argument (null pointer, bad shape, unknown name)      */
+    SPECMI_ERR_HIP = 2,     /* a HIP runtime call failed                                  */
+    SPECMI_ERR_STATE = 3,   /* call order violated (forward before commit, ...)           */
+    SPECMI_ERR_MISSING = 4  /* commit: a required tensor was never set                    */
+};
+
+enum {
+    SPECMI_MODEL_CAMCALIB = 0, /* camcalib/model.py CameraRegressorNetwork(resnet50, 1 FC) */
+    SPECMI_MODEL_HMR = 1       /* spec/models/hmr.py HMR(resnet50)                         */
+};
+
+/* Output dict of HMR.forward (spec/models/hmr.py:113,122): device pointers, fp32. */
+typedef struct specmi_hmr_outputs {
+    float* smpl_vertices; /* (B, V, 3)      */
+    float* smpl_joints3d; /* (B, 49, 3)     */
+    float* smpl_joints2d; /* (B, 49, 2)     */
+    float* pred_cam_t;    /* (B, 3)         */
+    float* pred_pose;     /* (B, 24, 3, 3)  */
+    float* pred_cam;      /* (B, 3)         */
+    float* pred_shape;    /* (B, 10)        */
+    float* pred_pose_6d;  /* (B, 144)       */
+} specmi_hmr_outputs;
+
+/* One record of the built-in launch profiler (HIP events around every kernel). */
+typedef struct specmi_prof_entry {
+    char   kernel[48];  /* kernel family, e.g. "conv_igemm_f32<128x128>"                   */
+    char   label[48];   /* call site, e.g. "backbone.layer2.0.conv2"                       */
+    double ms;          /* accumulated device time                                         */
+    double flops;       /* algorithmic FLOPs of the accumulated launches (2*MACs)          */
+    double bytes;       /* algorithmic HBM bytes (activations in+out+residual, weights)    */
+    int    launches;
+} specmi_prof_entry;
+
+/* ---- lifetime ------------------------------------------------------------------------ */
+
+/* Replaces the module constructors HMR.__init__ (spec/models/hmr.py:29-80) and
+ * CameraRegressorNetwork.__init__ (camcalib/model.py:25-57). */
+int specmi_create(specmi_handle** out, int device_id, int model_kind);
+int specmi_destroy(specmi_handle* h);
+const char* specmi_last_error(const specmi_handle* h);
+const char* specmi_version(void);
+
+/* ---- parameters (replaces load_state_dict / load_pretrained_model,
+ *      spec/tester.py:63-71, scripts/camcalib_demo.py:80-81) ---------------------------- */
+
+/* Integer options before commit.  HMR: "use_cam" (SMPLCamHead vs SMPLHead, hmr.py:66-74),
+ * "use_cam_feats" (hmr.py:55,94-98), "img_res" (hmr.py:69).  Float option: "focal_length". */
+int specmi_set_option_i32(specmi_handle* h, const char* name, int value);
+int specmi_set_option_f32(specmi_handle* h, const char* name, float value);
+
+/* Host tensors under state_dict key names, e.g. "backbone.layer1.0.conv1.weight" (OIHW),
+ * "backbone.bn1.running_var", "fc_vfov.weight" (out,in), "head.fc1.weight",
+ * "head.init_pose"; SMPL body model under "smpl.v_template" (V,3), "smpl.shapedirs"
+ * (V,3,10), "smpl.posedirs" (207,3V), "smpl.J_regressor" (24,V), "smpl.lbs_weights" (V,24),
+ * "smpl.J_regressor_extra" (9,V); int32: "smpl.parents" (24), "smpl.extra_vertex_ids" (21),
+ * "smpl.joint_map" (49).  Data is copied; the caller may free it on return. */
+int specmi_set_tensor_f32(specmi_handle* h, const char* name, const float* host_data,
+                          const int64_t* shape, int ndim);
+int specmi_set_tensor_i32(specmi_handle* h, const char* name, const int32_t* host_data,
+                          const int64_t* shape, int ndim);
+/* Validate, fold BN, pack and upload to HBM.  May be called again after further set_* calls. */
+int specmi_commit(specmi_handle* h);
+
+/* ---- forward: CamCalib ----------------------------------------------------------------- */
+
+/* CameraRegressorNetwork.forward (camcalib/model.py:72-81): images (B,3,H,W) NCHW fp32 ->
+ * three (B,256) logit tensors [vfov, pitch, roll]. */
+int specmi_camcalib_forward(specmi_handle* h, const float* images_nchw, int B, int H, int W,
+                            float* logits_vfov, float* logits_pitch, float* logits_roll,
+                            void* stream);
+
+/* convert_preds_to_angles soft-argmax branch (camcalib/cam_utils.py:114-133), focal length
+ * (scripts/camcalib_demo.py:129) and the CamCalib->SPEC hand-off read_cam_params
+ * (spec/utils/cam_params.py:37-48), fused in one launch.  Any output pointer may be NULL.
+ * img_h/img_w: (B,) full-image size in pixels.  R (B,3,3) = Rx(pitch) Ry(0) Rz(roll);
+ * K (B,3,3) = [[f,0,w/2],[0,f,h/2],[0,0,0]] (K[2,2] stays 0 as in the reference). */
+int specmi_camcalib_decode(specmi_handle* h, const float* logits_vfov, const float* logits_pitch,
+                           const float* logits_roll, int B, int nbins, const float* img_h,
+                           const float* img_w, float* vfov, float* pitch, float* roll,
+                           float* f_pix, float* cam_rotmat, float* cam_intrinsics, void* stream);
+
+/* ---- forward: SPEC --------------------------------------------------------------------- */
+
+/* HMR.forward (spec/models/hmr.py:82-122).  cam_* / bbox_* / img_* may be NULL when the
+ * handle was built with use_cam = 0 (and use_cam_feats = 0). */
+int specmi_hmr_forward(specmi_handle* h, const float* images_nchw, int B, int H, int W,
+                       const float* cam_rotmat, const float* cam_intrinsics,
+                       const float* bbox_scale, const float* bbox_center, const float* img_w,
+                       const float* img_h, const specmi_hmr_outputs* out, void* stream);
+
+/* ---- stage-level entry points (parity tests, profiling, reuse) ------------------------- */
+
+/* The trunk alone: `self.backbone(images)` (hmr.py:92, camcalib/model.py:73).  Output is the
+ * layer4 map in NHWC: (B, H/32, W/32, 2048). */
+int specmi_trunk_forward(specmi_handle* h, const float* images_nchw, int B, int H, int W,
+                         float* feat_nhwc, void* stream);
+
+/* HMRHead.forward on an NHWC feature map (hmr.py:96/98): avg-pool + 3 IEF iterations +
+ * rot6d->rotmat.  Outputs any-NULL. */
+int specmi_hmr_head_forward(specmi_handle* h, const float* feat_nhwc, int B, int fh, int fw,
+                            const float* cam_rotmat, const float* cam_intrinsics,
+                            const float* img_h, float* pred_pose, float* pred_shape,
+                            float* pred_cam, float* pred_pose_6d, void* stream);
+
+/* SMPLCamHead / SMPLHead forward (hmr.py:101-120): SMPL LBS (pose2rot=False) + 49 joints +
+ * camera translation + perspective projection. */
+int specmi_smpl_forward(specmi_handle* h, const float* rotmat, const float* betas,
+                        const float* cam, int B, const float* cam_rotmat,
+                        const float* cam_intrinsics, const float* bbox_scale,
+                        const float* bbox_center, const float* img_w, const float* img_h,
+                        float* vertices, float* joints3d, float* joints2d, float* cam_t,
+                        void* stream);
+
+/* A single fused conv+BN(+residual)(+ReLU) layer, y = act(conv(x)*scale + shift [+ res]).
+ * x (B,H,W,Cin) NHWC device; w (Cout,Cin,KH,KW) OIHW HOST; scale/shift (Cout) HOST;
+ * residual/out (B,OH,OW,Cout) NHWC device.  Cin%32==0 unless (Cin==3,KH==7: stem path,
+ * x is then NCHW).  Used by the per-layer parity tests. */
+int specmi_conv2d(specmi_handle* h, const float* x, int B, int H, int W, int Cin,
+                  const float* w_oihw_host, const float* scale_host, const float* shift_host,
+                  int Cout, int KH, int KW, int stride, int pad, const float* residual,
+                  int relu, float* out, void* stream);
+
+/* MaxPool2d(3,2,1) and global average pool on NHWC device tensors (trunk building blocks). */
+int specmi_maxpool3x3s2(specmi_handle* h, const float* x, int B, int H, int W, int C,
+                        float* out, void* stream);
+int specmi_avgpool(specmi_handle* h, const float* x, int B, int HW, int C, float* out,
+                   void* stream);
+
+/* ---- profiling -------------------------------------------------------------------------- */
+
+/* When on, every kernel launch is bracketed by HIP events on the launch stream. */
+int specmi_profile_enable(specmi_handle* h, int on);
+/* Synchronises, folds the recorded launches into entries keyed by (kernel,label) and
+ * clears the log.  Returns the number of entries in *n (at most max_entries copied). */
+int specmi_profile_read(specmi_handle* h, specmi_prof_entry* entries, int max_entries, int* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPECMI_H */

@@ -1,0 +1,102 @@
+"""ctypes binding of libspecmi.so (the C ABI in include/specmi.h).
+
+There is NO CPU fallback: if the library is missing or cannot be loaded, importing the ops
+raises, and every forward requires device tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libspecmi.so')
+
+OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_MISSING = 0, 1, 2, 3, 4
+MODEL_CAMCALIB, MODEL_HMR = 0, 1
+
+c_float_p = C.POINTER(C.c_float)
+c_int32_p = C.POINTER(C.c_int32)
+c_int64_p = C.POINTER(C.c_int64)
+
+
+class HmrOutputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        'smpl_vertices', 'smpl_joints3d', 'smpl_joints2d', 'pred_cam_t', 'pred_pose', 'pred_cam',
+        'pred_shape', 'pred_pose_6d')]
+
+
+class ProfEntry(C.Structure):
+    _fields_ = [('kernel', C.c_char * 48), ('label', C.c_char * 48), ('ms', C.c_double),
+                ('flops', C.c_double), ('bytes', C.c_double), ('launches', C.c_int)]
+
+
+class SpecmiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f'libspecmi error {code}: {msg}')
+        self.code = code
+
+
+# every exported symbol of include/specmi.h with its prototype
+PROTOTYPES = {
+    'specmi_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
+    'specmi_destroy': (C.c_int, [C.c_void_p]),
+    'specmi_last_error': (C.c_char_p, [C.c_void_p]),
+    'specmi_version': (C.c_char_p, []),
+    'specmi_set_option_i32': (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    'specmi_set_option_f32': (C.c_int, [C.c_void_p, C.c_char_p, C.c_float]),
+    'specmi_set_tensor_f32': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_int64_p, C.c_int]),
+    'specmi_set_tensor_i32': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_int64_p, C.c_int]),
+    'specmi_commit': (C.c_int, [C.c_void_p]),
+    'specmi_camcalib_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'specmi_camcalib_decode': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'specmi_hmr_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.POINTER(HmrOutputs), C.c_void_p]),
+    'specmi_trunk_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_void_p]),
+    'specmi_hmr_head_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+    'specmi_smpl_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
+    'specmi_conv2d': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'specmi_maxpool3x3s2': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_void_p]),
+    'specmi_avgpool': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                 C.c_void_p]),
+    'specmi_profile_enable': (C.c_int, [C.c_void_p, C.c_int]),
+    'specmi_profile_read': (C.c_int, [C.c_void_p, C.POINTER(ProfEntry), C.c_int, C.POINTER(C.c_int)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libspecmi.so and attach prototypes; raises if it is missing (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f'{LIB_PATH} not found: build it with `python -m spec_amd.build` '
+            '(or __graft_entry__.build()).  spec_amd has no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)       # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(handle, rc):
+    if rc != OK:
+        msg = load().specmi_last_error(handle)
+        raise SpecmiError(rc, msg.decode() if msg else '?')

@@ -1,0 +1,806 @@
+// api.hip - host side of libspecmi.so: the C ABI of include/specmi.h, parameter staging,
+// BatchNorm folding + weight re-layout, workspace management and the launch sequences of the
+// two networks.  Device code lives in conv_igemm.hip / stem.hip / head.hip / smpl.hip.
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+
+#include "specmi_internal.h"
+
+namespace specmi {
+void conv_igemm_force_variant(int v);
+}
+using namespace specmi;
+
+// ------------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------------
+struct HostTensor {
+    std::vector<float> f;
+    std::vector<int32_t> i;
+    std::vector<int64_t> shape;
+    bool is_int = false;
+    size_t numel() const { return is_int ? i.size() : f.size(); }
+};
+
+struct ConvW {
+    std::string name;  // state-dict prefix of the conv ("layer1.0.conv1"), bn under bn_name
+    std::string bn_name;
+    int cin = 0, cout = 0, k = 1, stride = 1, pad = 0;
+    int Kp = 0, Npad = 0;
+    float *w = nullptr, *scale = nullptr, *shift = nullptr;  // device
+};
+
+struct Bneck {
+    ConvW c1, c2, c3, ds;
+    bool has_ds = false;
+};
+
+struct FcW {  // Linear layers as H=W=1 convolutions
+    int nin = 0, nout = 0, Kp = 0, Npad = 0;
+    float *w = nullptr, *scale = nullptr, *shift = nullptr;
+};
+
+struct specmi_handle {
+    int device = 0;
+    int kind = 0;
+    std::map<std::string, HostTensor> staged;
+    std::map<std::string, int> opt_i;
+    std::map<std::string, float> opt_f;
+    bool committed = false;
+    std::string err;
+
+    // packed parameters (device)
+    ConvW stem;
+    std::vector<Bneck> blocks;
+    FcW fc_cam[3];             // CamCalib: vfov, pitch, roll
+    FcW fc1, fc2, dec;         // HMR head (dec = decpose|decshape|deccam)
+    float *init_pose = nullptr, *init_shape = nullptr, *init_cam = nullptr;
+    SmplDev smpl;
+    std::vector<void*> param_allocs;
+
+    // workspace (device), grown on demand
+    std::vector<void*> ws_allocs;
+    float* act[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t act_elems = 0;
+    float *xc = nullptr, *h1 = nullptr, *h2 = nullptr, *xf = nullptr;
+    float *rot_ws = nullptr, *betas_ws = nullptr, *cam_ws = nullptr, *verts_ws = nullptr;
+    float *pf_ws = nullptr, *A_ws = nullptr, *pj_ws = nullptr;
+    int ws_B = 0;
+
+    Profiler prof;
+};
+
+static std::string g_create_err;
+
+static int fail(specmi_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_err = buf;
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess)                                                                  \
+            return fail(h, SPECMI_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                        __FILE__, __LINE__);                                                    \
+    } while (0)
+
+#define LAUNCHCHK(h, rc, what)                                                                   \
+    do {                                                                                        \
+        int rc__ = (rc);                                                                        \
+        if (rc__ != 0)                                                                          \
+            return fail(h, SPECMI_ERR_HIP, "launch %s failed: %s", what,                        \
+                        hipGetErrorString((hipError_t)rc__));                                   \
+    } while (0)
+
+static int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------------
+// device memory helpers
+// ------------------------------------------------------------------------------------------
+static int dev_upload(specmi_handle* h, const void* src, size_t bytes, void** out, std::vector<void*>& pool) {
+    void* p = nullptr;
+    HIPCHK(h, hipMalloc(&p, bytes ? bytes : 4));
+    pool.push_back(p);
+    if (bytes) HIPCHK(h, hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    *out = p;
+    return SPECMI_OK;
+}
+
+static int dev_alloc(specmi_handle* h, size_t bytes, void** out, std::vector<void*>& pool) {
+    void* p = nullptr;
+    HIPCHK(h, hipMalloc(&p, bytes ? bytes : 4));
+    pool.push_back(p);
+    *out = p;
+    return SPECMI_OK;
+}
+
+static void free_pool(std::vector<void*>& pool) {
+    for (void* p : pool) (void)hipFree(p);
+    pool.clear();
+}
+
+// ------------------------------------------------------------------------------------------
+// packing
+// ------------------------------------------------------------------------------------------
+// OIHW -> [Kp/4][Npad][4], k = (ky*KW + kx)*Cin + ci  (zero padded)
+static void pack_gemm_weights(const float* w, int cout, int cin, int kh, int kw, int Kp, int Npad,
+                              std::vector<float>& out) {
+    out.assign((size_t)Kp * Npad, 0.f);
+    for (int n = 0; n < cout; ++n)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int ky = 0; ky < kh; ++ky)
+                for (int kx = 0; kx < kw; ++kx) {
+                    const int k = (ky * kw + kx) * cin + ci;
+                    out[((size_t)(k / 4) * Npad + n) * 4 + (k % 4)] = w[(((size_t)n * cin + ci) * kh + ky) * kw + kx];
+                }
+}
+
+// stem: (64,3,7,7) -> [147][64], k = c*49 + ky*7 + kx
+static void pack_stem_weights(const float* w, std::vector<float>& out) {
+    out.assign(147 * 64, 0.f);
+    for (int n = 0; n < 64; ++n)
+        for (int k = 0; k < 147; ++k) out[k * 64 + n] = w[n * 147 + k];
+}
+
+// eval-mode BatchNorm as y = x*alpha + beta, computed like ATen's CPU kernel (fp32):
+// invstd = 1/sqrt(var+eps); alpha = invstd*gamma; beta = bias - mean*alpha
+static void fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, int n, float eps,
+                    int npad, std::vector<float>& scale, std::vector<float>& shift) {
+    scale.assign(npad, 0.f);
+    shift.assign(npad, 0.f);
+    for (int i = 0; i < n; ++i) {
+        const float invstd = 1.0f / std::sqrt(var[i] + eps);
+        const float a = invstd * gamma[i];
+        scale[i] = a;
+        shift[i] = beta[i] - mean[i] * a;
+    }
+}
+
+static const HostTensor* find(specmi_handle* h, const std::string& name) {
+    auto it = h->staged.find(name);
+    return it == h->staged.end() ? nullptr : &it->second;
+}
+
+static int need(specmi_handle* h, const std::string& name, std::initializer_list<int64_t> shape, bool is_int,
+                const HostTensor** out) {
+    const HostTensor* t = find(h, name);
+    if (!t) return fail(h, SPECMI_ERR_MISSING, "missing tensor '%s'", name.c_str());
+    if (t->is_int != is_int) return fail(h, SPECMI_ERR_ARG, "tensor '%s' has the wrong dtype", name.c_str());
+    size_t n = 1;
+    for (int64_t s : shape) n *= (size_t)s;
+    if (t->numel() != n) {
+        return fail(h, SPECMI_ERR_ARG, "tensor '%s' has %zu elements, expected %zu", name.c_str(), t->numel(), n);
+    }
+    *out = t;
+    return SPECMI_OK;
+}
+
+static int commit_conv(specmi_handle* h, const std::string& prefix, ConvW& c) {
+    const HostTensor *w, *g, *b, *m, *v;
+    int rc;
+    if ((rc = need(h, prefix + c.name + ".weight", {c.cout, c.cin, c.k, c.k}, false, &w))) return rc;
+    if ((rc = need(h, prefix + c.bn_name + ".weight", {c.cout}, false, &g))) return rc;
+    if ((rc = need(h, prefix + c.bn_name + ".bias", {c.cout}, false, &b))) return rc;
+    if ((rc = need(h, prefix + c.bn_name + ".running_mean", {c.cout}, false, &m))) return rc;
+    if ((rc = need(h, prefix + c.bn_name + ".running_var", {c.cout}, false, &v))) return rc;
+    std::vector<float> packed, scale, shift;
+    if (c.cin == 3) {
+        c.Kp = 147;
+        c.Npad = 64;
+        pack_stem_weights(w->f.data(), packed);
+    } else {
+        c.Kp = c.cin * c.k * c.k;
+        c.Npad = round_up(c.cout, 64);
+        pack_gemm_weights(w->f.data(), c.cout, c.cin, c.k, c.k, c.Kp, c.Npad, packed);
+    }
+    fold_bn(g->f.data(), b->f.data(), m->f.data(), v->f.data(), c.cout, 1e-5f, c.Npad, scale, shift);
+    if ((rc = dev_upload(h, packed.data(), packed.size() * 4, (void**)&c.w, h->param_allocs))) return rc;
+    if ((rc = dev_upload(h, scale.data(), scale.size() * 4, (void**)&c.scale, h->param_allocs))) return rc;
+    if ((rc = dev_upload(h, shift.data(), shift.size() * 4, (void**)&c.shift, h->param_allocs))) return rc;
+    return SPECMI_OK;
+}
+
+// One or several Linear layers stacked along the output dimension
+static int commit_fc(specmi_handle* h, const std::vector<std::string>& names, const std::vector<int>& nouts, int nin,
+                     FcW& fc) {
+    int ntot = 0;
+    for (int n : nouts) ntot += n;
+    fc.nin = nin;
+    fc.nout = ntot;
+    fc.Kp = round_up(nin, 32);
+    fc.Npad = round_up(ntot, 64);
+    std::vector<float> wcat((size_t)ntot * nin), bias(fc.Npad, 0.f), ones(fc.Npad, 1.f);
+    int row = 0, rc;
+    for (size_t i = 0; i < names.size(); ++i) {
+        const HostTensor *w, *b;
+        if ((rc = need(h, names[i] + ".weight", {nouts[i], nin}, false, &w))) return rc;
+        if ((rc = need(h, names[i] + ".bias", {nouts[i]}, false, &b))) return rc;
+        std::memcpy(wcat.data() + (size_t)row * nin, w->f.data(), (size_t)nouts[i] * nin * 4);
+        std::memcpy(bias.data() + row, b->f.data(), (size_t)nouts[i] * 4);
+        row += nouts[i];
+    }
+    std::vector<float> packed;
+    pack_gemm_weights(wcat.data(), ntot, nin, 1, 1, fc.Kp, fc.Npad, packed);
+    if ((rc = dev_upload(h, packed.data(), packed.size() * 4, (void**)&fc.w, h->param_allocs))) return rc;
+    if ((rc = dev_upload(h, ones.data(), ones.size() * 4, (void**)&fc.scale, h->param_allocs))) return rc;
+    if ((rc = dev_upload(h, bias.data(), bias.size() * 4, (void**)&fc.shift, h->param_allocs))) return rc;
+    return SPECMI_OK;
+}
+
+static void build_resnet50(specmi_handle* h) {
+    h->stem = ConvW();
+    h->stem.name = "conv1"; h->stem.bn_name = "bn1";
+    h->stem.cin = 3; h->stem.cout = 64; h->stem.k = 7; h->stem.stride = 2; h->stem.pad = 3;
+    h->blocks.clear();
+    const int nblocks[4] = {3, 4, 6, 3}, planes[4] = {64, 128, 256, 512};
+    int inplanes = 64;
+    for (int li = 0; li < 4; ++li) {
+        for (int b = 0; b < nblocks[li]; ++b) {
+            const int stride = (b == 0 && li > 0) ? 2 : 1;
+            const std::string p = "layer" + std::to_string(li + 1) + "." + std::to_string(b);
+            Bneck bn;
+            auto mk = [&](ConvW& c, const std::string& cn, const std::string& bnn, int cin, int cout, int k, int s,
+                          int pad) {
+                c.name = p + "." + cn; c.bn_name = p + "." + bnn;
+                c.cin = cin; c.cout = cout; c.k = k; c.stride = s; c.pad = pad;
+            };
+            mk(bn.c1, "conv1", "bn1", inplanes, planes[li], 1, 1, 0);
+            mk(bn.c2, "conv2", "bn2", planes[li], planes[li], 3, stride, 1);
+            mk(bn.c3, "conv3", "bn3", planes[li], planes[li] * 4, 1, 1, 0);
+            bn.has_ds = (b == 0);
+            if (bn.has_ds) mk(bn.ds, "downsample.0", "downsample.1", inplanes, planes[li] * 4, 1, stride, 0);
+            inplanes = planes[li] * 4;
+            h->blocks.push_back(bn);
+        }
+    }
+}
+
+static int opt_i(specmi_handle* h, const char* name, int dflt) {
+    auto it = h->opt_i.find(name);
+    return it == h->opt_i.end() ? dflt : it->second;
+}
+static float opt_f(specmi_handle* h, const char* name, float dflt) {
+    auto it = h->opt_f.find(name);
+    return it == h->opt_f.end() ? dflt : it->second;
+}
+
+static int commit_smpl(specmi_handle* h) {
+    const HostTensor* vt = find(h, "smpl.v_template");
+    if (!vt) return fail(h, SPECMI_ERR_MISSING, "missing tensor 'smpl.v_template'");
+    if (vt->is_int || vt->numel() % 3) return fail(h, SPECMI_ERR_ARG, "smpl.v_template must be (V,3) fp32");
+    const int V = (int)(vt->numel() / 3);
+    const HostTensor *sd, *pd, *jr, *lw, *jx, *par, *eid, *jm;
+    int rc;
+    if ((rc = need(h, "smpl.shapedirs", {V, 3, 10}, false, &sd))) return rc;
+    if ((rc = need(h, "smpl.posedirs", {207, (int64_t)V * 3}, false, &pd))) return rc;
+    if ((rc = need(h, "smpl.J_regressor", {24, V}, false, &jr))) return rc;
+    if ((rc = need(h, "smpl.lbs_weights", {V, 24}, false, &lw))) return rc;
+    if ((rc = need(h, "smpl.J_regressor_extra", {9, V}, false, &jx))) return rc;
+    if ((rc = need(h, "smpl.parents", {24}, true, &par))) return rc;
+    if ((rc = need(h, "smpl.extra_vertex_ids", {21}, true, &eid))) return rc;
+    if ((rc = need(h, "smpl.joint_map", {49}, true, &jm))) return rc;
+    for (int j = 1; j < 24; ++j)
+        if (par->i[j] < 0 || par->i[j] >= j)
+            return fail(h, SPECMI_ERR_ARG, "smpl.parents[%d]=%d: a parent must precede its child", j, par->i[j]);
+    for (int e = 0; e < 21; ++e)
+        if (eid->i[e] < 0 || eid->i[e] >= V) return fail(h, SPECMI_ERR_ARG, "smpl.extra_vertex_ids[%d] out of range", e);
+    for (int e = 0; e < 49; ++e)
+        if (jm->i[e] < 0 || jm->i[e] >= 54) return fail(h, SPECMI_ERR_ARG, "smpl.joint_map[%d] out of range", e);
+    // rest-pose joint regression is linear in beta: J = Jr@v_template + (Jr@shapedirs) beta,
+    // folded once in float64 (24 x V x 33 MACs)
+    std::vector<float> Jt(72), Jd(720);
+    for (int j = 0; j < 24; ++j) {
+        double acc[33] = {0};
+        for (int v = 0; v < V; ++v) {
+            const double wv = jr->f[(size_t)j * V + v];
+            if (wv == 0.0) continue;
+            for (int c = 0; c < 3; ++c) {
+                acc[c] += wv * vt->f[(size_t)v * 3 + c];
+                for (int l = 0; l < 10; ++l) acc[3 + c * 10 + l] += wv * sd->f[((size_t)v * 3 + c) * 10 + l];
+            }
+        }
+        for (int c = 0; c < 3; ++c) {
+            Jt[j * 3 + c] = (float)acc[c];
+            for (int l = 0; l < 10; ++l) Jd[(j * 3 + c) * 10 + l] = (float)acc[3 + c * 10 + l];
+        }
+    }
+    SmplDev& m = h->smpl;
+    m.V = V;
+    std::vector<int32_t> parents = par->i;
+    parents[0] = -1;
+    if ((rc = dev_upload(h, vt->f.data(), vt->f.size() * 4, (void**)&m.v_template, h->param_allocs))) return rc;
+    if ((rc = dev_upload(h, sd->f.data(), sd->f.size() * 4, (void**)&m.shapedirs, h->param_allocs))) return rc;
+    if ((rc = dev_upload(h, pd->f.data(), pd->f.size() * 4, (void**)&m.posedirs, h->param_allocs))) return rc;
+    if ((rc = dev_upload(h, lw->f.data(), lw->f.size() * 4, (void**)&m.lbs_weights, h->param_allocs))) return rc;
+    if ((rc = dev_upload(h, jx->f.data(), jx->f.size() * 4, (void**)&m.J_extra, h->param_allocs))) return rc;
+    if ((rc = dev_upload(h, Jt.data(), Jt.size() * 4, (void**)&m.J_template, h->param_allocs))) return rc;
+    if ((rc = dev_upload(h, Jd.data(), Jd.size() * 4, (void**)&m.J_shapedirs, h->param_allocs))) return rc;
+    if ((rc = dev_upload(h, parents.data(), 24 * 4, (void**)&m.parents, h->param_allocs))) return rc;
+    if ((rc = dev_upload(h, eid->i.data(), 21 * 4, (void**)&m.extra_ids, h->param_allocs))) return rc;
+    if ((rc = dev_upload(h, jm->i.data(), 49 * 4, (void**)&m.joint_map, h->param_allocs))) return rc;
+    return SPECMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// workspace
+// ------------------------------------------------------------------------------------------
+static int conv_out(int x, int k, int s, int p) { return (x + 2 * p - k) / s + 1; }
+
+static int ensure_ws(specmi_handle* h, int B, int H, int W) {
+    const int oh1 = conv_out(H, 7, 2, 3), ow1 = conv_out(W, 7, 2, 3);
+    // largest activation: stem output (B,oh1,ow1,64) == layer1 output (B,oh1/2,ow1/2,256) rounded up
+    const int oh2 = conv_out(oh1, 3, 2, 1), ow2 = conv_out(ow1, 3, 2, 1);
+    size_t elems = (size_t)B * oh1 * ow1 * 64;
+    const size_t l1 = (size_t)B * oh2 * ow2 * 256;
+    if (l1 > elems) elems = l1;
+    const bool grow_act = elems > h->act_elems;
+    const bool grow_b = B > h->ws_B;
+    if (!grow_act && !grow_b) return SPECMI_OK;
+    HIPCHK(h, hipDeviceSynchronize());
+    free_pool(h->ws_allocs);
+    if (elems < h->act_elems) elems = h->act_elems;
+    const int Bw = B > h->ws_B ? B : h->ws_B;
+    int rc;
+    for (int i = 0; i < 4; ++i)
+        if ((rc = dev_alloc(h, elems * 4, (void**)&h->act[i], h->ws_allocs))) return rc;
+    h->act_elems = elems;
+    const int Bp = round_up(Bw, 8);
+    const int V = h->smpl.V > 0 ? h->smpl.V : 1;
+    if ((rc = dev_alloc(h, (size_t)Bp * XC_LD * 4, (void**)&h->xc, h->ws_allocs))) return rc;
+    if ((rc = dev_alloc(h, (size_t)Bp * 1024 * 4, (void**)&h->h1, h->ws_allocs))) return rc;
+    if ((rc = dev_alloc(h, (size_t)Bp * 1024 * 4, (void**)&h->h2, h->ws_allocs))) return rc;
+    if ((rc = dev_alloc(h, (size_t)Bp * 2048 * 4, (void**)&h->xf, h->ws_allocs))) return rc;
+    if ((rc = dev_alloc(h, (size_t)Bp * 216 * 4, (void**)&h->rot_ws, h->ws_allocs))) return rc;
+    if ((rc = dev_alloc(h, (size_t)Bp * 10 * 4, (void**)&h->betas_ws, h->ws_allocs))) return rc;
+    if ((rc = dev_alloc(h, (size_t)Bp * 3 * 4, (void**)&h->cam_ws, h->ws_allocs))) return rc;
+    if ((rc = dev_alloc(h, (size_t)Bp * V * 3 * 4, (void**)&h->verts_ws, h->ws_allocs))) return rc;
+    if ((rc = dev_alloc(h, (size_t)Bp * (208 + 10) * 4, (void**)&h->pf_ws, h->ws_allocs))) return rc;
+    if ((rc = dev_alloc(h, (size_t)Bp * 288 * 4, (void**)&h->A_ws, h->ws_allocs))) return rc;
+    if ((rc = dev_alloc(h, (size_t)Bp * 72 * 4, (void**)&h->pj_ws, h->ws_allocs))) return rc;
+    HIPCHK(h, hipMemset(h->pf_ws, 0, (size_t)Bp * (208 + 10) * 4));
+    HIPCHK(h, hipMemset(h->A_ws, 0, (size_t)Bp * 288 * 4));
+    h->ws_B = Bw;
+    return SPECMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// launch sequences
+// ------------------------------------------------------------------------------------------
+static int run_conv(specmi_handle* h, const ConvW& c, const float* x, int B, int H, int W, const float* res, int relu,
+                    float* out, int* OHo, int* OWo, hipStream_t s, const std::string& label) {
+    ConvArgs a;
+    a.x = x; a.w = c.w; a.scale = c.scale; a.shift = c.shift; a.res = res; a.out = out;
+    a.B = B; a.H = H; a.W = W; a.Cin = c.cin; a.ldx = c.cin;
+    a.OH = conv_out(H, c.k, c.stride, c.pad); a.OW = conv_out(W, c.k, c.stride, c.pad);
+    a.Cout = c.cout; a.Npad = c.Npad; a.ldo = c.cout;
+    a.KH = c.k; a.KW = c.k; a.stride = c.stride; a.pad = c.pad; a.relu = relu;
+    LaunchCtx ctx{s, &h->prof, label.c_str()};
+    LAUNCHCHK(h, launch_conv_igemm(a, ctx), label.c_str());
+    if (OHo) *OHo = a.OH;
+    if (OWo) *OWo = a.OW;
+    return SPECMI_OK;
+}
+
+static int run_fc(specmi_handle* h, const FcW& fc, const float* x, int ldx, int B, const float* res, float* out,
+                  int ldo, hipStream_t s, const char* label) {
+    ConvArgs a;
+    a.x = x; a.w = fc.w; a.scale = fc.scale; a.shift = fc.shift; a.res = res; a.out = out;
+    a.B = B; a.H = 1; a.W = 1; a.Cin = fc.Kp; a.ldx = ldx;
+    a.OH = 1; a.OW = 1; a.Cout = fc.nout; a.Npad = fc.Npad; a.ldo = ldo;
+    a.KH = 1; a.KW = 1; a.stride = 1; a.pad = 0; a.relu = 0;
+    LaunchCtx ctx{s, &h->prof, label};
+    LAUNCHCHK(h, launch_conv_igemm(a, ctx), label);
+    return SPECMI_OK;
+}
+
+// images NCHW -> layer4 map NHWC in *feat (a workspace buffer unless feat_out given)
+static int run_trunk(specmi_handle* h, const float* images, int B, int H, int W, float* feat_out, const float** feat,
+                     int* fh, int* fw, hipStream_t s) {
+    int rc;
+    if (H < 32 || W < 32) return fail(h, SPECMI_ERR_ARG, "image size %dx%d too small", H, W);
+    if ((rc = ensure_ws(h, B, H, W))) return rc;
+    const int oh1 = conv_out(H, 7, 2, 3), ow1 = conv_out(W, 7, 2, 3);
+    {
+        LaunchCtx ctx{s, &h->prof, "backbone.conv1"};
+        LAUNCHCHK(h, launch_stem(images, h->stem.w, h->stem.scale, h->stem.shift, h->act[0], B, H, W, oh1, ow1, 1, ctx),
+                  "stem");
+    }
+    int ch = conv_out(oh1, 3, 2, 1), cw = conv_out(ow1, 3, 2, 1);
+    {
+        LaunchCtx ctx{s, &h->prof, "backbone.maxpool"};
+        LAUNCHCHK(h, launch_maxpool3x3s2(h->act[0], h->act[1], B, oh1, ow1, 64, ch, cw, ctx), "maxpool");
+    }
+    int xi = 1;  // index of the buffer holding the block input
+    for (size_t bi = 0; bi < h->blocks.size(); ++bi) {
+        const Bneck& bk = h->blocks[bi];
+        const bool last = (bi + 1 == h->blocks.size());
+        int free_idx[3], nf = 0;
+        for (int i = 0; i < 4; ++i)
+            if (i != xi) free_idx[nf++] = i;
+        float* x = h->act[xi];
+        float* t1 = h->act[free_idx[0]];
+        float* t2 = h->act[free_idx[1]];
+        float* idb = h->act[free_idx[2]];
+        int oh, ow;
+        const std::string p = "backbone." + bk.c1.name.substr(0, bk.c1.name.rfind('.'));
+        if ((rc = run_conv(h, bk.c1, x, B, ch, cw, nullptr, 1, t1, nullptr, nullptr, s, p + ".conv1"))) return rc;
+        if ((rc = run_conv(h, bk.c2, t1, B, ch, cw, nullptr, 1, t2, &oh, &ow, s, p + ".conv2"))) return rc;
+        const float* identity = x;
+        if (bk.has_ds) {
+            if ((rc = run_conv(h, bk.ds, x, B, ch, cw, nullptr, 0, idb, nullptr, nullptr, s, p + ".downsample"))) return rc;
+            identity = idb;
+        }
+        float* out = (last && feat_out) ? feat_out : t1;  // t1 is dead after conv2
+        if ((rc = run_conv(h, bk.c3, t2, B, oh, ow, identity, 1, out, nullptr, nullptr, s, p + ".conv3"))) return rc;
+        ch = oh; cw = ow;
+        xi = free_idx[0];
+        if (last) *feat = out;
+    }
+    *fh = ch; *fw = cw;
+    return SPECMI_OK;
+}
+
+static int run_head(specmi_handle* h, const float* feat, int B, int fh, int fw, const float* R, const float* K,
+                    const float* img_h, float* pred_pose, float* pred_shape, float* pred_cam, float* pred_pose_6d,
+                    hipStream_t s) {
+    int rc;
+    const int ucf = opt_i(h, "use_cam_feats", 0);
+    if (ucf && (!R || !K || !img_h))
+        return fail(h, SPECMI_ERR_ARG, "use_cam_feats needs cam_rotmat, cam_intrinsics and img_h");
+    {
+        LaunchCtx ctx{s, &h->prof, "head.avgpool"};
+        LAUNCHCHK(h, launch_avgpool(feat, h->xc, B, fh * fw, 2048, XC_LD, ctx), "avgpool");
+    }
+    {
+        LaunchCtx ctx{s, &h->prof, "head.init"};
+        LAUNCHCHK(h, launch_head_init(h->xc, h->init_pose, h->init_shape, h->init_cam, R, K, img_h, ucf, B, ctx),
+                  "head_init");
+    }
+    for (int it = 0; it < 3; ++it) {
+        if ((rc = run_fc(h, h->fc1, h->xc, XC_LD, B, nullptr, h->h1, 1024, s, "head.fc1"))) return rc;
+        if ((rc = run_fc(h, h->fc2, h->h1, 1024, B, nullptr, h->h2, 1024, s, "head.fc2"))) return rc;
+        float* state = h->xc + XC_STATE_OFF;  // dec* + running estimate, in place
+        if ((rc = run_fc(h, h->dec, h->h2, 1024, B, state, state, XC_LD, s, "head.dec"))) return rc;
+    }
+    {
+        LaunchCtx ctx{s, &h->prof, "head.final"};
+        LAUNCHCHK(h, launch_head_final(h->xc, pred_pose, pred_shape, pred_cam, pred_pose_6d, h->rot_ws, h->betas_ws,
+                                       h->cam_ws, B, ctx),
+                  "head_final");
+    }
+    return SPECMI_OK;
+}
+
+static int run_smpl(specmi_handle* h, const float* rotmat, const float* betas, const float* cam, int B, const float* R,
+                    const float* K, const float* bbox_scale, const float* bbox_center, const float* img_w,
+                    const float* img_h, float* vertices, float* joints3d, float* joints2d, float* cam_t,
+                    hipStream_t s) {
+    const int use_cam = opt_i(h, "use_cam", 0);
+    if (use_cam && (!R || !K || !bbox_scale || !bbox_center || !img_w || !img_h))
+        return fail(h, SPECMI_ERR_ARG, "use_cam needs cam_rotmat, cam_intrinsics, bbox_scale, bbox_center, img_w, img_h");
+    SmplArgs a;
+    a.rotmat = rotmat; a.betas = betas; a.cam = cam; a.cam_rotmat = R; a.cam_intrinsics = K;
+    a.bbox_scale = bbox_scale; a.bbox_center = bbox_center; a.img_w = img_w; a.img_h = img_h;
+    a.vertices = vertices ? vertices : h->verts_ws;
+    a.joints3d = joints3d; a.joints2d = joints2d; a.cam_t = cam_t;
+    a.pose_feat = h->pf_ws; a.A = h->A_ws; a.posed_j = h->pj_ws;
+    a.B = B;
+    a.mode = use_cam ? 0 : 1;
+    a.focal_length = opt_f(h, "focal_length", 5000.f);
+    a.img_res = (float)opt_i(h, "img_res", 224);
+    a.normalize_joints2d = use_cam ? 0 : 1;  // spec/models/hmr.py:111 vs :119
+    LaunchCtx ctx{s, &h->prof, "smpl"};
+    LAUNCHCHK(h, launch_smpl(h->smpl, a, ctx), "smpl");
+    return SPECMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* specmi_version(void) { return "specmi 0.1 (gfx950, fp32 MFMA)"; }
+
+int specmi_create(specmi_handle** out, int device_id, int model_kind) {
+    if (!out) return fail(nullptr, SPECMI_ERR_ARG, "out is NULL");
+    if (model_kind != SPECMI_MODEL_CAMCALIB && model_kind != SPECMI_MODEL_HMR)
+        return fail(nullptr, SPECMI_ERR_ARG, "unknown model kind %d", model_kind);
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, SPECMI_ERR_HIP, "no HIP device available (%s)", hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return fail(nullptr, SPECMI_ERR_ARG, "device %d out of range [0,%d)", device_id, n);
+    specmi_handle* h = new specmi_handle();
+    h->device = device_id;
+    h->kind = model_kind;
+    build_resnet50(h);
+    *out = h;
+    return SPECMI_OK;
+}
+
+int specmi_destroy(specmi_handle* h) {
+    if (!h) return SPECMI_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    for (auto& r : h->prof.log) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    free_pool(h->ws_allocs);
+    free_pool(h->param_allocs);
+    delete h;
+    return SPECMI_OK;
+}
+
+const char* specmi_last_error(const specmi_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int specmi_set_option_i32(specmi_handle* h, const char* name, int value) {
+    if (!h || !name) return fail(h, SPECMI_ERR_ARG, "null argument");
+    if (!std::strcmp(name, "force_conv_variant")) { conv_igemm_force_variant(value); return SPECMI_OK; }
+    h->opt_i[name] = value;
+    return SPECMI_OK;
+}
+
+int specmi_set_option_f32(specmi_handle* h, const char* name, float value) {
+    if (!h || !name) return fail(h, SPECMI_ERR_ARG, "null argument");
+    h->opt_f[name] = value;
+    return SPECMI_OK;
+}
+
+static int stage(specmi_handle* h, const char* name, const void* data, const int64_t* shape, int ndim, bool is_int) {
+    if (!h || !name || !data || (ndim > 0 && !shape) || ndim < 0 || ndim > 8) return fail(h, SPECMI_ERR_ARG, "bad argument to set_tensor");
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] < 0) return fail(h, SPECMI_ERR_ARG, "negative dimension in '%s'", name);
+        n *= (size_t)shape[i];
+    }
+    HostTensor t;
+    t.is_int = is_int;
+    t.shape.assign(shape, shape + ndim);
+    if (is_int) t.i.assign((const int32_t*)data, (const int32_t*)data + n);
+    else t.f.assign((const float*)data, (const float*)data + n);
+    h->staged[name] = std::move(t);
+    return SPECMI_OK;
+}
+
+int specmi_set_tensor_f32(specmi_handle* h, const char* name, const float* d, const int64_t* shape, int ndim) {
+    return stage(h, name, d, shape, ndim, false);
+}
+int specmi_set_tensor_i32(specmi_handle* h, const char* name, const int32_t* d, const int64_t* shape, int ndim) {
+    return stage(h, name, d, shape, ndim, true);
+}
+
+int specmi_commit(specmi_handle* h) {
+    if (!h) return SPECMI_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    free_pool(h->param_allocs);
+    h->committed = false;
+    int rc;
+    const std::string bp = "backbone.";
+    if ((rc = commit_conv(h, bp, h->stem))) return rc;
+    for (Bneck& b : h->blocks) {
+        if ((rc = commit_conv(h, bp, b.c1))) return rc;
+        if ((rc = commit_conv(h, bp, b.c2))) return rc;
+        if ((rc = commit_conv(h, bp, b.c3))) return rc;
+        if (b.has_ds && (rc = commit_conv(h, bp, b.ds))) return rc;
+    }
+    if (h->kind == SPECMI_MODEL_CAMCALIB) {
+        const char* names[3] = {"fc_vfov", "fc_pitch", "fc_roll"};
+        const HostTensor* w0 = find(h, "fc_vfov.weight");
+        if (!w0) return fail(h, SPECMI_ERR_MISSING, "missing tensor 'fc_vfov.weight'");
+        const int nb = (int)(w0->numel() / 2048);
+        h->opt_i["nbins"] = nb;
+        for (int i = 0; i < 3; ++i)
+            if ((rc = commit_fc(h, {names[i]}, {nb}, 2048, h->fc_cam[i]))) return rc;
+    } else {
+        const int ucf = opt_i(h, "use_cam_feats", 0);
+        const int nin = 2048 + 144 + 13 + (ucf ? 7 : 0);
+        if ((rc = commit_fc(h, {"head.fc1"}, {1024}, nin, h->fc1))) return rc;
+        if ((rc = commit_fc(h, {"head.fc2"}, {1024}, 1024, h->fc2))) return rc;
+        if ((rc = commit_fc(h, {"head.decpose", "head.decshape", "head.deccam"}, {144, 10, 3}, 1024, h->dec))) return rc;
+        const HostTensor *ip, *is, *ic;
+        if ((rc = need(h, "head.init_pose", {144}, false, &ip))) return rc;
+        if ((rc = need(h, "head.init_shape", {10}, false, &is))) return rc;
+        if ((rc = need(h, "head.init_cam", {3}, false, &ic))) return rc;
+        if ((rc = dev_upload(h, ip->f.data(), 144 * 4, (void**)&h->init_pose, h->param_allocs))) return rc;
+        if ((rc = dev_upload(h, is->f.data(), 10 * 4, (void**)&h->init_shape, h->param_allocs))) return rc;
+        if ((rc = dev_upload(h, ic->f.data(), 3 * 4, (void**)&h->init_cam, h->param_allocs))) return rc;
+        if ((rc = commit_smpl(h))) return rc;
+        // the SMPL vertex count sizes the workspace
+        free_pool(h->ws_allocs);
+        h->act_elems = 0; h->ws_B = 0;
+    }
+    h->committed = true;
+    return SPECMI_OK;
+}
+
+#define ENTER(h)                                                                   \
+    if (!(h)) return SPECMI_ERR_ARG;                                               \
+    HIPCHK(h, hipSetDevice((h)->device));
+
+#define NEED_COMMIT(h) \
+    if (!(h)->committed) return fail(h, SPECMI_ERR_STATE, "specmi_commit has not succeeded on this handle");
+
+int specmi_trunk_forward(specmi_handle* h, const float* images, int B, int H, int W, float* feat, void* stream) {
+    ENTER(h); NEED_COMMIT(h);
+    if (!images || !feat || B <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
+    const float* f; int fh, fw;
+    return run_trunk(h, images, B, H, W, feat, &f, &fh, &fw, (hipStream_t)stream);
+}
+
+int specmi_camcalib_forward(specmi_handle* h, const float* images, int B, int H, int W, float* lv, float* lp, float* lr,
+                            void* stream) {
+    ENTER(h); NEED_COMMIT(h);
+    if (h->kind != SPECMI_MODEL_CAMCALIB) return fail(h, SPECMI_ERR_STATE, "handle is not a CamCalib model");
+    if (!images || !lv || !lp || !lr || B <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const float* f; int fh, fw, rc;
+    if ((rc = run_trunk(h, images, B, H, W, nullptr, &f, &fh, &fw, s))) return rc;
+    {
+        LaunchCtx ctx{s, &h->prof, "avgpool"};
+        LAUNCHCHK(h, launch_avgpool(f, h->xf, B, fh * fw, 2048, 2048, ctx), "avgpool");
+    }
+    float* outs[3] = {lv, lp, lr};
+    const char* labels[3] = {"fc_vfov", "fc_pitch", "fc_roll"};
+    for (int i = 0; i < 3; ++i)
+        if ((rc = run_fc(h, h->fc_cam[i], h->xf, 2048, B, nullptr, outs[i], h->fc_cam[i].nout, s, labels[i]))) return rc;
+    return SPECMI_OK;
+}
+
+int specmi_camcalib_decode(specmi_handle* h, const float* lv, const float* lp, const float* lr, int B, int nbins,
+                           const float* img_h, const float* img_w, float* vfov, float* pitch, float* roll, float* f_pix,
+                           float* R, float* K, void* stream) {
+    ENTER(h);
+    if (!lv || !lp || !lr || B <= 0 || nbins < 2) return fail(h, SPECMI_ERR_ARG, "bad argument");
+    if ((f_pix || K) && !img_h) return fail(h, SPECMI_ERR_ARG, "f_pix / K need img_h");
+    if (K && !img_w) return fail(h, SPECMI_ERR_ARG, "K needs img_w");
+    LaunchCtx ctx{(hipStream_t)stream, &h->prof, "camcalib.decode"};
+    LAUNCHCHK(h, launch_camcalib_decode(lv, lp, lr, B, nbins, img_h, img_w, vfov, pitch, roll, f_pix, R, K, ctx), "decode");
+    return SPECMI_OK;
+}
+
+int specmi_hmr_head_forward(specmi_handle* h, const float* feat, int B, int fh, int fw, const float* R, const float* K,
+                            const float* img_h, float* pred_pose, float* pred_shape, float* pred_cam,
+                            float* pred_pose_6d, void* stream) {
+    ENTER(h); NEED_COMMIT(h);
+    if (h->kind != SPECMI_MODEL_HMR) return fail(h, SPECMI_ERR_STATE, "handle is not an HMR model");
+    if (!feat || B <= 0 || fh <= 0 || fw <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
+    int rc;
+    if ((rc = ensure_ws(h, B, 32, 32))) return rc;
+    return run_head(h, feat, B, fh, fw, R, K, img_h, pred_pose, pred_shape, pred_cam, pred_pose_6d, (hipStream_t)stream);
+}
+
+int specmi_smpl_forward(specmi_handle* h, const float* rotmat, const float* betas, const float* cam, int B,
+                        const float* R, const float* K, const float* bbox_scale, const float* bbox_center,
+                        const float* img_w, const float* img_h, float* vertices, float* joints3d, float* joints2d,
+                        float* cam_t, void* stream) {
+    ENTER(h); NEED_COMMIT(h);
+    if (h->kind != SPECMI_MODEL_HMR) return fail(h, SPECMI_ERR_STATE, "handle is not an HMR model");
+    if (!rotmat || !betas || !cam || B <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
+    int rc;
+    if ((rc = ensure_ws(h, B, 32, 32))) return rc;
+    return run_smpl(h, rotmat, betas, cam, B, R, K, bbox_scale, bbox_center, img_w, img_h, vertices, joints3d, joints2d,
+                    cam_t, (hipStream_t)stream);
+}
+
+int specmi_hmr_forward(specmi_handle* h, const float* images, int B, int H, int W, const float* R, const float* K,
+                       const float* bbox_scale, const float* bbox_center, const float* img_w, const float* img_h,
+                       const specmi_hmr_outputs* out, void* stream) {
+    ENTER(h); NEED_COMMIT(h);
+    if (h->kind != SPECMI_MODEL_HMR) return fail(h, SPECMI_ERR_STATE, "handle is not an HMR model");
+    if (!images || !out || B <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const float* f; int fh, fw, rc;
+    if ((rc = run_trunk(h, images, B, H, W, nullptr, &f, &fh, &fw, s))) return rc;
+    if ((rc = run_head(h, f, B, fh, fw, R, K, img_h, out->pred_pose, out->pred_shape, out->pred_cam, out->pred_pose_6d, s)))
+        return rc;
+    return run_smpl(h, h->rot_ws, h->betas_ws, h->cam_ws, B, R, K, bbox_scale, bbox_center, img_w, img_h,
+                    out->smpl_vertices, out->smpl_joints3d, out->smpl_joints2d, out->pred_cam_t, s);
+}
+
+int specmi_conv2d(specmi_handle* h, const float* x, int B, int H, int W, int Cin, const float* w_host,
+                  const float* scale_host, const float* shift_host, int Cout, int KH, int KW, int stride, int pad,
+                  const float* residual, int relu, float* out, void* stream) {
+    ENTER(h);
+    if (!x || !w_host || !scale_host || !shift_host || !out || B <= 0 || KH != KW)
+        return fail(h, SPECMI_ERR_ARG, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<void*> tmp;
+    std::vector<float> packed, sc, sh;
+    const bool stem = (Cin == 3 && KH == 7 && Cout == 64 && stride == 2 && pad == 3);
+    int rc = SPECMI_OK;
+    float *dw = nullptr, *dsc = nullptr, *dsh = nullptr;
+    const int Npad = round_up(Cout, 64);
+    sc.assign(Npad, 0.f); sh.assign(Npad, 0.f);
+    std::memcpy(sc.data(), scale_host, (size_t)Cout * 4);
+    std::memcpy(sh.data(), shift_host, (size_t)Cout * 4);
+    if (stem) pack_stem_weights(w_host, packed);
+    else {
+        if (Cin % 32) return fail(h, SPECMI_ERR_ARG, "Cin must be a multiple of 32 (got %d)", Cin);
+        pack_gemm_weights(w_host, Cout, Cin, KH, KW, Cin * KH * KW, Npad, packed);
+    }
+    if ((rc = dev_upload(h, packed.data(), packed.size() * 4, (void**)&dw, tmp)) ||
+        (rc = dev_upload(h, sc.data(), sc.size() * 4, (void**)&dsc, tmp)) ||
+        (rc = dev_upload(h, sh.data(), sh.size() * 4, (void**)&dsh, tmp))) {
+        free_pool(tmp);
+        return rc;
+    }
+    const int OH = conv_out(H, KH, stride, pad), OW = conv_out(W, KW, stride, pad);
+    LaunchCtx ctx{s, &h->prof, "conv2d"};
+    int lrc;
+    if (stem) {
+        lrc = launch_stem(x, dw, dsc, dsh, out, B, H, W, OH, OW, relu, ctx);
+    } else {
+        ConvArgs a;
+        a.x = x; a.w = dw; a.scale = dsc; a.shift = dsh; a.res = residual; a.out = out;
+        a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.ldx = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout; a.Npad = Npad;
+        a.ldo = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.relu = relu;
+        lrc = launch_conv_igemm(a, ctx);
+    }
+    hipError_t se = hipStreamSynchronize(s);
+    free_pool(tmp);
+    if (lrc) return fail(h, SPECMI_ERR_HIP, "conv2d launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    if (se != hipSuccess) return fail(h, SPECMI_ERR_HIP, "conv2d failed: %s", hipGetErrorString(se));
+    return SPECMI_OK;
+}
+
+int specmi_maxpool3x3s2(specmi_handle* h, const float* x, int B, int H, int W, int C, float* out, void* stream) {
+    ENTER(h);
+    if (!x || !out || B <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
+    LaunchCtx ctx{(hipStream_t)stream, &h->prof, "maxpool"};
+    LAUNCHCHK(h, launch_maxpool3x3s2(x, out, B, H, W, C, conv_out(H, 3, 2, 1), conv_out(W, 3, 2, 1), ctx), "maxpool");
+    return SPECMI_OK;
+}
+
+int specmi_avgpool(specmi_handle* h, const float* x, int B, int HW, int C, float* out, void* stream) {
+    ENTER(h);
+    if (!x || !out || B <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
+    LaunchCtx ctx{(hipStream_t)stream, &h->prof, "avgpool"};
+    LAUNCHCHK(h, launch_avgpool(x, out, B, HW, C, C, ctx), "avgpool");
+    return SPECMI_OK;
+}
+
+int specmi_profile_enable(specmi_handle* h, int on) {
+    if (!h) return SPECMI_ERR_ARG;
+    h->prof.on = on != 0;
+    return SPECMI_OK;
+}
+
+int specmi_profile_read(specmi_handle* h, specmi_prof_entry* entries, int max_entries, int* n) {
+    ENTER(h);
+    if (!n) return fail(h, SPECMI_ERR_ARG, "n is NULL");
+    std::vector<specmi_prof_entry> acc;
+    for (auto& r : h->prof.log) {
+        (void)hipEventSynchronize(r.e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+        specmi_prof_entry* e = nullptr;
+        for (auto& a : acc)
+            if (!std::strncmp(a.kernel, r.kernel, sizeof(a.kernel) - 1) && !std::strncmp(a.label, r.label.c_str(), sizeof(a.label) - 1)) {
+                e = &a;
+                break;
+            }
+        if (!e) {
+            specmi_prof_entry ne;
+            std::memset(&ne, 0, sizeof(ne));
+            std::strncpy(ne.kernel, r.kernel, sizeof(ne.kernel) - 1);
+            std::strncpy(ne.label, r.label.c_str(), sizeof(ne.label) - 1);
+            acc.push_back(ne);
+            e = &acc.back();
+        }
+        e->ms += ms; e->flops += r.flops; e->bytes += r.bytes; e->launches += 1;
+    }
+    h->prof.log.clear();
+    *n = (int)acc.size();
+    for (int i = 0; i < (int)acc.size() && i < max_entries && entries; ++i) entries[i] = acc[i];
+    return SPECMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,249 @@
+// conv_igemm.hip - implicit-GEMM convolution / linear layer on the gfx950 fp32 matrix cores.
+//
+// One kernel family serves every contraction of the SPEC hot path except the 7x7 stem:
+//   * the 36 1x1 and 16 3x3 convolutions of each ResNet-50 trunk (reference call sites
+//     spec/models/hmr.py:92, camcalib/model.py:73) with BatchNorm (eval) folded into a
+//     per-channel scale/shift epilogue, optional residual add and ReLU fused,
+//   * the FC layers of the CamCalib heads (camcalib/model.py:77-79) and of the HMR iterative
+//     regressor (spec/models/hmr.py:96), as H=W=1 "convolutions".
+//
+// GEMM view: out[M = B*OH*OW][N = Cout] = A[M][K = KH*KW*Cin] * Wp[K][N], activations NHWC so
+// that for a fixed filter tap the Cin slice of a pixel is contiguous.
+//
+// MI355X mapping (CDNA4, wave64):
+//   * v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain), 64 cycles, 16 acc VGPRs.
+//     A workgroup = 4 waves in a 2x2 grid; a wave owns (BM/2)x(BN/2) = TMxTN tiles of 32x32.
+//   * K is consumed in chunks of 32 (one filter tap x 32 channels).  Inside a chunk the k
+//     order is permuted so that each lane's 4 consecutive k values are one 16-byte LDS read:
+//     sub-chunk q (8 k's), lane half h, step s  ->  k = 8q + 4h + s.  A and B use the same
+//     permutation, so the sum over k is unchanged.
+//   * LDS: A tile [BM][32+4] fp32 (row pad 4 floats => ds_read_b128 of 16 rows hits 64
+//     distinct banks, ds_write_b128 of one row's 8 quads hits 32 distinct banks);
+//     B tile [8][BN][4] fp32 - exactly the HBM layout of the packed weights [K/4][Npad][4],
+//     so the copy is linear and the fragment read (consecutive n per lane) is conflict-free.
+//   * double-buffered LDS, register-staged prefetch of chunk c+1 issued before the MFMAs of
+//     chunk c (one barrier per chunk); 2 workgroups / CU (<= 69.6 KB LDS, <= 256 VGPR).
+//   * blockIdx -> tile map is XCD-aware: the 8 XCDs get contiguous runs of tiles ordered
+//     n-fastest, so tiles sharing an A row-panel hit the same 4 MiB L2.
+#include "specmi_internal.h"
+
+namespace specmi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct KArgs {
+    const float* x;
+    const float* w;
+    const float* scale;
+    const float* shift;
+    const float* res;
+    float* out;
+    int H, W, ldx;
+    int OW, OHW, Cout, Npad, ldo;
+    int KW, stride, pad;
+    int M, nbn, nchunks, cpc;  // cpc = chunks per filter tap = Cin / 32
+    int relu;
+};
+
+template <int BM, int BN>
+__global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(const KArgs p) {
+    constexpr int BK = 32;
+    constexpr int LDA = BK + 4;
+    constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave
+    constexpr int AI = BM / 32, BI = BN / 32;  // float4 loads per thread per chunk
+    constexpr int A_STAGE = BM * LDA, B_STAGE = 8 * BN * 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + 2 * A_STAGE;
+
+    const int tid = threadIdx.x;
+
+    // ---- XCD-aware tile order (bijective for any grid size) ------------------------------
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q8 = nblk >> 3, r8 = nblk & 7;
+    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int tile_m = L / p.nbn, tile_n = L - tile_m * p.nbn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- per-thread im2col rows ------------------------------------------------------------
+    const int a_kq = tid & 7, a_r = tid >> 3;
+    int a_pix[AI], a_iy[AI], a_ix[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int m = m0 + a_r + 32 * i;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int b = mm / p.OHW;
+        const int rem = mm - b * p.OHW;
+        const int oy = rem / p.OW;
+        const int ox = rem - oy * p.OW;
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+        a_iy[i] = ok ? iy0 : -(1 << 20);  // rows past M read as zeros
+        a_ix[i] = ix0;
+        a_pix[i] = (b * p.H + iy0) * p.W + ix0;
+    }
+
+    f32x4 ra[AI], rb[BI];
+    auto load_chunk = [&](int c) {
+        const int tap = c / p.cpc;
+        const int c0 = (c - tap * p.cpc) * BK;
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const float* src = p.x + (size_t)(long long)(a_pix[i] + ky * p.W + kx) * p.ldx + c0 + a_kq * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4*>(src);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const int e = tid + 256 * i;
+            const int kq = e / BN, n = e % BN;
+            rb[i] = *reinterpret_cast<const f32x4*>(p.w + ((size_t)(c * 8 + kq) * p.Npad + n0 + n) * 4);
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+            *reinterpret_cast<f32x4*>(&As[buf * A_STAGE + (a_r + 32 * i) * LDA + a_kq * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BI; ++i)
+            *reinterpret_cast<f32x4*>(&Bs[buf * B_STAGE + (tid + 256 * i) * 4]) = rb[i];
+    };
+
+    // ---- wave / lane coordinates -------------------------------------------------------------
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hh = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+
+    for (int c = 0; c < p.nchunks; ++c) {
+        const int buf = c & 1;
+        const bool more = (c + 1) < p.nchunks;
+        if (more) load_chunk(c + 1);  // global loads in flight under the MFMAs below
+
+        const float* Ab = As + buf * A_STAGE + (wm * (BM / 2) + l31) * LDA + hh * 4;
+        const float* Bb = Bs + buf * B_STAGE + (hh * BN + wn * (BN / 2) + l31) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDA + q * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j] = *reinterpret_cast<const f32x4*>(Bb + (q * 2 * BN + j * 32) * 4);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+        }
+
+        if (more) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: y = acc*scale + shift (+res) (ReLU); C/D layout of the 32x32 MFMA:
+    //      col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + l31;
+        const float sc = p.scale[n], sh = p.shift[n];
+        const bool nok = n < p.Cout;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const int m = m0 + wm * (BM / 2) + i * 32 + row;
+                if (nok && m < p.M) {
+                    const size_t o = (size_t)m * p.ldo + n;
+                    float v = fmaf(acc[i][j][r], sc, sh);
+                    if (p.res) v += p.res[o];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    p.out[o] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN>
+static int launch_variant(const KArgs& k, int M, const LaunchCtx& ctx, const char* name, double flops,
+                          double bytes) {
+    constexpr size_t smem = (size_t)(2 * BM * 36 + 2 * 8 * BN * 4) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32_kernel<BM, BN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    KArgs kk = k;
+    kk.nbn = k.Npad / BN;
+    const int nbm = (M + BM - 1) / BM;
+    const int grid = nbm * kk.nbn;
+    ProfScope ps(ctx, name, flops, bytes);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN>), dim3(grid), dim3(256), smem, ctx.stream, kk);
+    return (int)hipGetLastError();
+}
+
+static int g_force_variant = 0;  // 0 auto, 1: 128x128, 2: 128x64, 3: 64x64
+void conv_igemm_force_variant(int v) { g_force_variant = v; }
+
+static int pick_variant(int M, int Npad) {
+    if (g_force_variant == 1 && Npad % 128 == 0) return 1;
+    if (g_force_variant == 2 || g_force_variant == 3) return g_force_variant;
+    const long nbm128 = (M + 127) / 128;
+    if (Npad % 128 == 0 && nbm128 * (Npad / 128) >= 512) return 1;
+    if (nbm128 * (Npad / 64) >= 512) return 2;
+    return 3;
+}
+
+const char* conv_igemm_variant(const ConvArgs& a) {
+    static const char* names[] = {"", "conv_igemm_f32<128x128>", "conv_igemm_f32<128x64>", "conv_igemm_f32<64x64>"};
+    return names[pick_variant(a.B * a.OH * a.OW, a.Npad)];
+}
+
+int launch_conv_igemm(const ConvArgs& a, const LaunchCtx& ctx) {
+    if (a.Cin % 32 != 0 || a.Npad % 64 != 0 || a.ldx % 4 != 0) return (int)hipErrorInvalidValue;
+    KArgs k;
+    k.x = a.x; k.w = a.w; k.scale = a.scale; k.shift = a.shift; k.res = a.res; k.out = a.out;
+    k.H = a.H; k.W = a.W; k.ldx = a.ldx;
+    k.OW = a.OW; k.OHW = a.OH * a.OW; k.Cout = a.Cout; k.Npad = a.Npad; k.ldo = a.ldo;
+    k.KW = a.KW; k.stride = a.stride; k.pad = a.pad;
+    const int M = a.B * a.OH * a.OW;
+    k.M = M;
+    k.cpc = a.Cin / 32;
+    k.nchunks = a.KH * a.KW * k.cpc;
+    k.nbn = 0;
+    k.relu = a.relu;
+    const double Kd = (double)a.KH * a.KW * a.Cin;
+    const double flops = 2.0 * (double)M * a.Cout * Kd;
+    const double bytes = 4.0 * ((double)a.B * a.H * a.W * a.Cin + (double)M * a.Cout * (a.res ? 2.0 : 1.0) +
+                                Kd * a.Cout);
+    switch (pick_variant(M, a.Npad)) {
+        case 1: return launch_variant<128, 128>(k, M, ctx, "conv_igemm_f32<128x128>", flops, bytes);
+        case 2: return launch_variant<128, 64>(k, M, ctx, "conv_igemm_f32<128x64>", flops, bytes);
+        default: return launch_variant<64, 64>(k, M, ctx, "conv_igemm_f32<64x64>", flops, bytes);
+    }
+}
+
+}  // namespace specmi

@@ -1,0 +1,187 @@
+// head.hip - small per-image kernels around the regressor GEMMs (gfx950).
+//
+//   * head_init_kernel   : builds the IEF state row of HMRHead (pare, call site
+//     spec/models/hmr.py:94-98): xc = [xf(2048) | pose6d(144) | shape(10) | cam(3) |
+//     rot6d(cam_rotmat)(6) | vfov(1) | zero pad] with vfov = 2*atan(img_h / (2*K[0,0]))
+//     (spec/models/hmr.py:95).  xf is written by the avg-pool kernel; the three dec* GEMMs
+//     update the state columns in place (residual epilogue), so torch.cat is never executed.
+//   * head_final_kernel  : rot6d_to_rotmat (Gram-Schmidt, F.normalize eps 1e-12) and the
+//     output gather pred_pose / pred_shape / pred_cam / pred_pose_6d.
+//   * camcalib_decode_kernel : soft-argmax decode of the three 256-bin logit rows
+//     (camcalib/cam_utils.py:110-133: softmax expectation -> [-1,1] -> affine to radians),
+//     f = h/2/tan(vfov/2) (scripts/camcalib_demo.py:129), R = euler2matrix([pitch,0,roll])
+//     via the quaternion route and K with K[2,2] = 0 (spec/utils/cam_params.py:37-46).
+//     One wave per (image, head): 64-lane shuffle reductions, no LDS traffic for the softmax.
+#include "specmi_internal.h"
+
+namespace specmi {
+
+__global__ void __launch_bounds__(256) head_init_kernel(float* __restrict__ xc, const float* __restrict__ init_pose,
+                                                         const float* __restrict__ init_shape,
+                                                         const float* __restrict__ init_cam,
+                                                         const float* __restrict__ R, const float* __restrict__ K,
+                                                         const float* __restrict__ img_h, int use_cam_feats, int B) {
+    const int b = blockIdx.x;
+    float* row = xc + (size_t)b * XC_LD + XC_STATE_OFF;
+    for (int i = threadIdx.x; i < XC_LD - XC_STATE_OFF; i += blockDim.x) {
+        float v = 0.f;
+        if (i < 144) v = init_pose[i];
+        else if (i < 154) v = init_shape[i - 144];
+        else if (i < 157) v = init_cam[i - 154];
+        else if (use_cam_feats && i < 163) {
+            const int e = i - 157;                   // rotmat[:, :, :2] row-major: (row, col) = (e/2, e%2)
+            v = R[(size_t)b * 9 + (e >> 1) * 3 + (e & 1)];
+        } else if (use_cam_feats && i == 163) {
+            v = 2.0f * atanf(img_h[b] / (2.0f * K[(size_t)b * 9]));
+        }
+        row[i] = v;
+    }
+}
+
+int launch_head_init(float* xc, const float* init_pose, const float* init_shape, const float* init_cam,
+                     const float* cam_rotmat, const float* cam_intrinsics, const float* img_h, int use_cam_feats,
+                     int B, const LaunchCtx& ctx) {
+    ProfScope ps(ctx, "head_init", 0.0, 4.0 * B * (XC_LD - XC_STATE_OFF));
+    hipLaunchKernelGGL(head_init_kernel, dim3(B), dim3(256), 0, ctx.stream, xc, init_pose, init_shape, init_cam,
+                       cam_rotmat, cam_intrinsics, img_h, use_cam_feats, B);
+    return (int)hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) head_final_kernel(const float* __restrict__ xc, float* __restrict__ pred_pose,
+                                                          float* __restrict__ pred_shape, float* __restrict__ pred_cam,
+                                                          float* __restrict__ pred_pose_6d, float* __restrict__ rot_ws,
+                                                          float* __restrict__ betas_ws, float* __restrict__ cam_ws,
+                                                          int B) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float* s = xc + (size_t)b * XC_LD + XC_STATE_OFF;
+    if (t < 144 && pred_pose_6d) pred_pose_6d[(size_t)b * 144 + t] = s[t];
+    if (t >= 144 && t < 154) {
+        const float v = s[t];
+        if (pred_shape) pred_shape[(size_t)b * 10 + t - 144] = v;
+        if (betas_ws) betas_ws[(size_t)b * 10 + t - 144] = v;
+    }
+    if (t >= 154 && t < 157) {
+        const float v = s[t];
+        if (pred_cam) pred_cam[(size_t)b * 3 + t - 154] = v;
+        if (cam_ws) cam_ws[(size_t)b * 3 + t - 154] = v;
+    }
+    if (t >= 192 && t < 216) {
+        const int j = t - 192;
+        const float* p = s + 6 * j;  // view(-1,3,2): a1 = p[0],p[2],p[4]; a2 = p[1],p[3],p[5]
+        const float a1x = p[0], a1y = p[2], a1z = p[4];
+        const float a2x = p[1], a2y = p[3], a2z = p[5];
+        const float n1 = fmaxf(sqrtf(a1x * a1x + a1y * a1y + a1z * a1z), 1e-12f);
+        const float b1x = a1x / n1, b1y = a1y / n1, b1z = a1z / n1;
+        const float d = b1x * a2x + b1y * a2y + b1z * a2z;
+        const float ux = a2x - d * b1x, uy = a2y - d * b1y, uz = a2z - d * b1z;
+        const float n2 = fmaxf(sqrtf(ux * ux + uy * uy + uz * uz), 1e-12f);
+        const float b2x = ux / n2, b2y = uy / n2, b2z = uz / n2;
+        const float b3x = b1y * b2z - b1z * b2y;
+        const float b3y = b1z * b2x - b1x * b2z;
+        const float b3z = b1x * b2y - b1y * b2x;
+        const float Rm[9] = {b1x, b2x, b3x, b1y, b2y, b3y, b1z, b2z, b3z};  // columns b1 b2 b3
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (pred_pose) pred_pose[((size_t)b * 24 + j) * 9 + k] = Rm[k];
+            if (rot_ws) rot_ws[((size_t)b * 24 + j) * 9 + k] = Rm[k];
+        }
+    }
+}
+
+int launch_head_final(const float* xc, float* pred_pose, float* pred_shape, float* pred_cam, float* pred_pose_6d,
+                      float* rotmat_ws, float* betas_ws, float* cam_ws, int B, const LaunchCtx& ctx) {
+    ProfScope ps(ctx, "head_final_rot6d", 0.0, 4.0 * B * (157 + 157 + 216));
+    hipLaunchKernelGGL(head_final_kernel, dim3(B), dim3(256), 0, ctx.stream, xc, pred_pose, pred_shape, pred_cam,
+                       pred_pose_6d, rotmat_ws, betas_ws, cam_ws, B);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(192) camcalib_decode_kernel(const float* __restrict__ lv, const float* __restrict__ lp,
+                                                               const float* __restrict__ lr, int nbins,
+                                                               const float* __restrict__ img_h,
+                                                               const float* __restrict__ img_w, float* __restrict__ vfov,
+                                                               float* __restrict__ pitch, float* __restrict__ roll,
+                                                               float* __restrict__ f_pix, float* __restrict__ R,
+                                                               float* __restrict__ K) {
+    __shared__ float ang[3];
+    const int b = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float* row = (wave == 0 ? lv : wave == 1 ? lp : lr) + (size_t)b * nbins;
+    float mx = -INFINITY;
+    for (int i = lane; i < nbins; i += 64) mx = fmaxf(mx, row[i]);
+    mx = wave_max(mx);
+    float se = 0.f, sp = 0.f;
+    for (int i = lane; i < nbins; i += 64) {
+        const float e = expf(row[i] - mx);
+        se += e;
+    }
+    se = wave_sum(se);
+    for (int i = lane; i < nbins; i += 64) {
+        const float pr = expf(row[i] - mx) / se;  // softmax, then expectation of the index
+        sp += pr * (float)i;
+    }
+    sp = wave_sum(sp);
+    if (lane == 0) {
+        const float s = sp / (float)(nbins - 1) * 2.0f - 1.0f;                  // softargmax1d normalisation
+        // soft_idx_to_angle: (max - min) is a python double rounded to fp32 when it meets the tensor
+        const float span = wave == 0 ? (float)(2.1 - 0.2617) : (float)(0.6 - (-0.6));
+        const float lo = wave == 0 ? (float)0.2617 : (float)-0.6;
+        ang[wave] = span * ((s + 1.0f) / 2.0f) + lo;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float vf = ang[0], pt = ang[1], rl = ang[2];
+        if (vfov) vfov[b] = vf;
+        if (pitch) pitch[b] = pt;
+        if (roll) roll[b] = rl;
+        const float h = img_h ? img_h[b] : 0.f, w = img_w ? img_w[b] : 0.f;
+        const float f = h / 2.0f / tanf(vf / 2.0f);
+        if (f_pix) f_pix[b] = f;
+        if (R) {
+            // batch_euler2matrix([pitch, 0, roll]) = quat2mat(euler2quat): half angles
+            const float hx = pt / 2.0f, hy = 0.0f / 2.0f, hz = rl / 2.0f;
+            const float cz = cosf(hz), sz = sinf(hz), cy = cosf(hy), sy = sinf(hy), cx = cosf(hx), sx = sinf(hx);
+            float qw = cx * cy * cz - sx * sy * sz;
+            float qx = cx * sy * sz + cy * cz * sx;
+            float qy = cx * cz * sy - sx * cy * sz;
+            float qz = cx * cy * sz + sx * cz * sy;
+            const float nq = sqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
+            qw /= nq; qx /= nq; qy /= nq; qz /= nq;
+            const float w2 = qw * qw, x2 = qx * qx, y2 = qy * qy, z2 = qz * qz;
+            const float wx = qw * qx, wy = qw * qy, wz = qw * qz, xy = qx * qy, xz = qx * qz, yz = qy * qz;
+            float* o = R + (size_t)b * 9;
+            o[0] = w2 + x2 - y2 - z2; o[1] = 2 * xy - 2 * wz;     o[2] = 2 * wy + 2 * xz;
+            o[3] = 2 * wz + 2 * xy;     o[4] = w2 - x2 + y2 - z2; o[5] = 2 * yz - 2 * wx;
+            o[6] = 2 * xz - 2 * wy;     o[7] = 2 * wx + 2 * yz;     o[8] = w2 - x2 - y2 + z2;
+        }
+        if (K) {
+            float* o = K + (size_t)b * 9;
+            o[0] = f;   o[1] = 0.f; o[2] = w / 2.0f;
+            o[3] = 0.f; o[4] = f;   o[5] = h / 2.0f;
+            o[6] = 0.f; o[7] = 0.f; o[8] = 0.f;   // K[2,2] stays 0 (spec/utils/cam_params.py:39-46)
+        }
+    }
+}
+
+int launch_camcalib_decode(const float* lv, const float* lp, const float* lr, int B, int nbins, const float* img_h,
+                           const float* img_w, float* vfov, float* pitch, float* roll, float* f_pix, float* R,
+                           float* K, const LaunchCtx& ctx) {
+    ProfScope ps(ctx, "camcalib_decode", 0.0, 4.0 * B * (3.0 * nbins + 24));
+    hipLaunchKernelGGL(camcalib_decode_kernel, dim3(B), dim3(192), 0, ctx.stream, lv, lp, lr, nbins, img_h, img_w, vfov,
+                       pitch, roll, f_pix, R, K);
+    return (int)hipGetLastError();
+}
+
+}  // namespace specmi

@@ -1,0 +1,311 @@
+// smpl.hip - SMPL linear blend skinning + 49 joints + camera + projection (gfx950).
+//
+// Replaces SMPLCamHead / SMPLHead of the reference path (call sites spec/models/hmr.py:101-120;
+// arithmetic = smplx 0.1.28 lbs(pose2rot=False) + the SPIN/PARE 49-joint wrapper +
+// convert_pare_to_full_img_cam + perspective_projection).  ~25 framework launches and a
+// 23-step Python loop upstream become three kernels:
+//
+//   1. smpl_pose_kernel   (one wave per image): rest joints J = J_template + J_shapedirs*beta,
+//      pose features (R_j - I), and the 24-joint kinematic chain.  Lane j owns joint j; the
+//      tree is walked level by level and a child reads its parent's 3x4 world transform with
+//      wave shuffles (ds_bpermute), so the chain never touches memory.
+//   2. smpl_skin_kernel   (256 vertices x 8 images per workgroup): shape blend, pose blend
+//      (207-term), blended 3x4 transform (24 joints) and the skinned vertex, all in registers.
+//      Everything that is constant across the lanes of a wave (betas, pose features, the
+//      24x12 joint transforms of the 8 images) is laid out so the compiler fetches it with
+//      scalar loads (s_load_dwordx4/x8 through the scalar cache) and feeds it to v_fma as an
+//      SGPR operand - no LDS traffic, no broadcast reads.  posedirs rows are read coalesced
+//      (a wave covers 192 contiguous floats) and reused for the 8 images of the tile.
+//   3. smpl_joints_kernel (one workgroup per image): J_regressor_extra @ vertices (9 dot
+//      products of length V, wave-shuffle + LDS reduction), the 21 vertex-picked joints, the
+//      49-entry joint_map gather, the full-image camera translation and the projection
+//      p = K ((R X + t) / z).
+#include "specmi_internal.h"
+
+namespace specmi {
+
+constexpr int IT = 8;        // images per skinning workgroup
+constexpr int PF_LD = 208;   // 207 pose features padded
+
+__global__ void __launch_bounds__(64) smpl_pose_kernel(const float* __restrict__ rotmat, const float* __restrict__ betas,
+                                                        const float* __restrict__ Jt, const float* __restrict__ Jd,
+                                                        const int* __restrict__ parents, float* __restrict__ pf_t,
+                                                        float* __restrict__ betas_t, float* __restrict__ A,
+                                                        float* __restrict__ posed_j) {
+    const int b = blockIdx.x;
+    const int j = threadIdx.x;
+    const bool act = j < 24;
+    const int jj = act ? j : 0;
+    int par = (act && j > 0) ? parents[jj] : -1;
+    int depth = 0;
+    for (int pp = par; pp >= 0; pp = (pp > 0 ? parents[pp] : -1)) ++depth;
+    int maxd = act ? depth : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxd = max(maxd, __shfl_xor(maxd, o, 64));
+
+    float R[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = rotmat[((size_t)b * 24 + jj) * 9 + k];
+
+    float beta[10];
+#pragma unroll
+    for (int l = 0; l < 10; ++l) beta[l] = betas[(size_t)b * 10 + l];
+    if (j < 10) betas_t[((size_t)(b / IT) * 10 + j) * IT + (b % IT)] = beta[j];
+
+    float J[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int l = 0; l < 10; ++l) s = fmaf(beta[l], Jd[(jj * 3 + c) * 10 + l], s);
+        J[c] = Jt[jj * 3 + c] + s;
+    }
+
+    // pose feature (R_j - I) for j >= 1, tiled [tile][k][IT] so the skin kernel reads it with scalar loads
+    if (act && j > 0) {
+        float* dst = pf_t + ((size_t)(b / IT) * PF_LD + (j - 1) * 9) * IT + (b % IT);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dst[k * IT] = R[k] - ((k % 4 == 0) ? 1.0f : 0.0f);
+    }
+    if (j == 24) pf_t[((size_t)(b / IT) * PF_LD + 207) * IT + (b % IT)] = 0.f;
+
+    const int src = par >= 0 ? par : 0;
+    float rel[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float pj = __shfl(J[c], src, 64);
+        rel[c] = (par >= 0) ? J[c] - pj : J[c];
+    }
+    // local transform L = [R | rel]; world transform G starts as L (root) and is finalised level by level
+    float G[12];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        G[r * 4 + 0] = R[r * 3 + 0]; G[r * 4 + 1] = R[r * 3 + 1]; G[r * 4 + 2] = R[r * 3 + 2]; G[r * 4 + 3] = rel[r];
+    }
+    for (int d = 1; d <= maxd; ++d) {
+        float P[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) P[e] = __shfl(G[e], src, 64);
+        if (act && depth == d) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    G[r * 4 + c] = P[r * 4 + 0] * R[0 * 3 + c] + P[r * 4 + 1] * R[1 * 3 + c] + P[r * 4 + 2] * R[2 * 3 + c];
+                G[r * 4 + 3] = P[r * 4 + 0] * rel[0] + P[r * 4 + 1] * rel[1] + P[r * 4 + 2] * rel[2] + P[r * 4 + 3];
+            }
+        }
+    }
+    if (act) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            posed_j[((size_t)b * 24 + j) * 3 + r] = G[r * 4 + 3];
+            float* a = A + ((size_t)b * 24 + j) * 12 + r * 4;
+            a[0] = G[r * 4 + 0]; a[1] = G[r * 4 + 1]; a[2] = G[r * 4 + 2];
+            a[3] = G[r * 4 + 3] - (G[r * 4 + 0] * J[0] + G[r * 4 + 1] * J[1] + G[r * 4 + 2] * J[2]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) smpl_skin_kernel(const float* __restrict__ v_template,
+                                                         const float* __restrict__ shapedirs,
+                                                         const float* __restrict__ posedirs,
+                                                         const float* __restrict__ lbs_w,
+                                                         const float* __restrict__ betas_t,
+                                                         const float* __restrict__ pf_t, const float* __restrict__ A,
+                                                         float* __restrict__ verts, int V, int B) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    const bool vok = v < V;
+    const int vv = vok ? v : V - 1;
+    const int tile = blockIdx.y, b0 = tile * IT;
+    const float* __restrict__ bt = betas_t + (size_t)tile * 10 * IT;    // [10][IT]   wave-uniform
+    const float* __restrict__ pf = pf_t + (size_t)tile * PF_LD * IT;    // [208][IT]  wave-uniform
+    const float* __restrict__ At = A + (size_t)b0 * 288;                // [IT][24][12] wave-uniform
+
+    float vp[IT][3];
+    {   // v_shaped = v_template + shapedirs . beta
+        float vt[3], sd[30];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) vt[c] = v_template[vv * 3 + c];
+#pragma unroll
+        for (int e = 0; e < 30; ++e) sd[e] = shapedirs[(size_t)vv * 30 + e];
+#pragma unroll
+        for (int i = 0; i < IT; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float s = 0.f;
+#pragma unroll
+                for (int l = 0; l < 10; ++l) s = fmaf(bt[l * IT + i], sd[c * 10 + l], s);
+                vp[i][c] = vt[c] + s;
+            }
+    }
+    {   // v_posed = pose_offsets + v_shaped, pose_offsets = pose_feature @ posedirs
+        float off[IT][3];
+#pragma unroll
+        for (int i = 0; i < IT; ++i) off[i][0] = off[i][1] = off[i][2] = 0.f;
+        const float* pd = posedirs + (size_t)vv * 3;
+        const size_t ldp = (size_t)V * 3;
+#pragma unroll 3
+        for (int k = 0; k < 207; ++k) {
+            const float p0 = pd[k * ldp + 0], p1 = pd[k * ldp + 1], p2 = pd[k * ldp + 2];
+#pragma unroll
+            for (int i = 0; i < IT; ++i) {
+                const float f = pf[k * IT + i];
+                off[i][0] = fmaf(f, p0, off[i][0]);
+                off[i][1] = fmaf(f, p1, off[i][1]);
+                off[i][2] = fmaf(f, p2, off[i][2]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < IT; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vp[i][c] = off[i][c] + vp[i][c];
+    }
+    float w[24];
+#pragma unroll
+    for (int j = 0; j < 24; ++j) w[j] = lbs_w[(size_t)vv * 24 + j];
+
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        if (b0 + i >= B) break;   // wave-uniform
+        float T[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 24; ++j)
+#pragma unroll
+            for (int e = 0; e < 12; ++e) T[e] = fmaf(w[j], At[(i * 24 + j) * 12 + e], T[e]);
+        if (vok) {
+            float* o = verts + ((size_t)(b0 + i) * V + v) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                o[c] = T[c * 4 + 0] * vp[i][0] + T[c * 4 + 1] * vp[i][1] + T[c * 4 + 2] * vp[i][2] + T[c * 4 + 3];
+        }
+    }
+}
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+struct JointArgs {
+    const float* verts; const float* posed_j; const float* J_extra; const int* extra_ids; const int* joint_map;
+    const float* cam; const float* R; const float* K; const float* bbox_scale; const float* bbox_center;
+    const float* img_w; const float* img_h;
+    float* joints3d; float* joints2d; float* cam_t;
+    int V, mode, normalize; float focal, img_res;
+};
+
+__global__ void __launch_bounds__(256) smpl_joints_kernel(const JointArgs a) {
+    __shared__ float red[4][27];
+    __shared__ float J54[54][3];
+    __shared__ float ct[3];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float* vb = a.verts + (size_t)b * a.V * 3;
+    float acc[9][3];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) acc[e][0] = acc[e][1] = acc[e][2] = 0.f;
+    for (int v = t; v < a.V; v += 256) {
+        const float x = vb[v * 3 + 0], y = vb[v * 3 + 1], z = vb[v * 3 + 2];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+            const float wgt = a.J_extra[(size_t)e * a.V + v];
+            acc[e][0] = fmaf(wgt, x, acc[e][0]);
+            acc[e][1] = fmaf(wgt, y, acc[e][1]);
+            acc[e][2] = fmaf(wgt, z, acc[e][2]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 9; ++e)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float s = wsum(acc[e][c]);
+            if ((t & 63) == 0) red[t >> 6][e * 3 + c] = s;
+        }
+    if (t < 72) J54[t / 3][t % 3] = a.posed_j[(size_t)b * 72 + t];
+    if (t >= 72 && t < 72 + 63) {
+        const int i = t - 72, e = i / 3, c = i % 3;
+        J54[24 + e][c] = vb[(size_t)a.extra_ids[e] * 3 + c];
+    }
+    if (t == 255) {
+        const float s = a.cam[b * 3 + 0], tx = a.cam[b * 3 + 1], ty = a.cam[b * 3 + 2];
+        if (a.mode == 0) {  // convert_pare_to_full_img_cam, res = 224 literal
+            const float f = a.K[(size_t)b * 9];
+            const float bh = a.bbox_scale[b] * 200.0f;
+            const float r = bh / 224.0f;
+            const float tz = 2.0f * f / (r * 224.0f * s);
+            const float cx = 2.0f * (a.bbox_center[b * 2 + 0] - (a.img_w[b] / 2.0f)) / (s * bh);
+            const float cy = 2.0f * (a.bbox_center[b * 2 + 1] - (a.img_h[b] / 2.0f)) / (s * bh);
+            ct[0] = tx + cx; ct[1] = ty + cy; ct[2] = tz;
+        } else {            // convert_weak_perspective_to_perspective
+            ct[0] = tx; ct[1] = ty; ct[2] = 2.0f * a.focal / (a.img_res * s + 1e-9f);
+        }
+    }
+    __syncthreads();
+    if (t < 27) J54[45 + t / 3][t % 3] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    __syncthreads();
+    if (t < 3 && a.cam_t) a.cam_t[b * 3 + t] = ct[t];
+    if (t < 49) {
+        const int jm = a.joint_map[t];
+        const float X0 = J54[jm][0], X1 = J54[jm][1], X2 = J54[jm][2];
+        if (a.joints3d) {
+            float* o = a.joints3d + ((size_t)b * 49 + t) * 3;
+            o[0] = X0; o[1] = X1; o[2] = X2;
+        }
+        if (a.joints2d) {
+            float Rm[9], Km[9];
+            if (a.mode == 0) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { Rm[k] = a.R[(size_t)b * 9 + k]; Km[k] = a.K[(size_t)b * 9 + k]; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { Rm[k] = (k % 4 == 0) ? 1.f : 0.f; Km[k] = 0.f; }
+                Km[0] = a.focal; Km[4] = a.focal; Km[8] = 1.f;
+            }
+            float P[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) P[i] = Rm[i * 3 + 0] * X0 + Rm[i * 3 + 1] * X1 + Rm[i * 3 + 2] * X2 + ct[i];
+            const float x0 = P[0] / P[2], x1 = P[1] / P[2], x2 = P[2] / P[2];
+            float u = Km[0] * x0 + Km[1] * x1 + Km[2] * x2;
+            float vv = Km[3] * x0 + Km[4] * x1 + Km[5] * x2;
+            if (a.normalize) { u = u / (a.img_res / 2.0f); vv = vv / (a.img_res / 2.0f); }
+            a.joints2d[((size_t)b * 49 + t) * 2 + 0] = u;
+            a.joints2d[((size_t)b * 49 + t) * 2 + 1] = vv;
+        }
+    }
+}
+
+int launch_smpl(const SmplDev& m, const SmplArgs& a, const LaunchCtx& ctx) {
+    const int B = a.B, V = m.V;
+    // workspace layout inside pose_feat: [tiles][208][IT] pose features, then [tiles][10][IT] betas
+    const int tiles = (B + IT - 1) / IT;
+    float* pf_t = a.pose_feat;
+    float* betas_t = a.pose_feat + (size_t)tiles * PF_LD * IT;
+    {
+        ProfScope ps(ctx, "smpl_pose_chain", 0.0, 4.0 * B * (216 + 10 + 207 + 288 + 72));
+        hipLaunchKernelGGL(smpl_pose_kernel, dim3(B), dim3(64), 0, ctx.stream, a.rotmat, a.betas, m.J_template,
+                           m.J_shapedirs, m.parents, pf_t, betas_t, a.A, a.posed_j);
+    }
+    {
+        const double flops = 2.0 * (double)B * V * (3.0 * 207 + 30 + 288 + 9);
+        const double bytes = 4.0 * ((double)B * V * 3 + (double)tiles * V * (3.0 * 207 + 3 + 30 + 24));
+        ProfScope ps(ctx, "smpl_skin_lbs", flops, bytes);
+        hipLaunchKernelGGL(smpl_skin_kernel, dim3((V + 255) / 256, tiles), dim3(256), 0, ctx.stream, m.v_template,
+                           m.shapedirs, m.posedirs, m.lbs_weights, betas_t, pf_t, a.A, a.vertices, V, B);
+    }
+    {
+        JointArgs j;
+        j.verts = a.vertices; j.posed_j = a.posed_j; j.J_extra = m.J_extra; j.extra_ids = m.extra_ids;
+        j.joint_map = m.joint_map; j.cam = a.cam; j.R = a.cam_rotmat; j.K = a.cam_intrinsics;
+        j.bbox_scale = a.bbox_scale; j.bbox_center = a.bbox_center; j.img_w = a.img_w; j.img_h = a.img_h;
+        j.joints3d = a.joints3d; j.joints2d = a.joints2d; j.cam_t = a.cam_t;
+        j.V = V; j.mode = a.mode; j.normalize = a.normalize_joints2d; j.focal = a.focal_length; j.img_res = a.img_res;
+        ProfScope ps(ctx, "smpl_joints_project", 2.0 * B * V * 27.0, 4.0 * B * ((double)V * 3 + 9.0 * V + 49 * 5));
+        hipLaunchKernelGGL(smpl_joints_kernel, dim3(B), dim3(256), 0, ctx.stream, j);
+    }
+    return (int)hipGetLastError();
+}
+
+}  // namespace specmi

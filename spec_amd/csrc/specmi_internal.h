@@ -1,0 +1,147 @@
+// Internal declarations shared by the HIP translation units of libspecmi.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/specmi.h"
+
+namespace specmi {
+
+// ----------------------------------------------------------------------------------------
+// launch profiler: HIP events on the launch stream around every kernel
+// ----------------------------------------------------------------------------------------
+struct ProfRecord {
+    const char* kernel;
+    std::string label;
+    double flops, bytes;
+    hipEvent_t e0, e1;
+};
+
+struct Profiler {
+    bool on = false;
+    std::vector<ProfRecord> log;
+    std::string scope;  // label prefix set by the caller ("backbone.layer1.0.conv1")
+};
+
+struct LaunchCtx {
+    hipStream_t stream;
+    Profiler* prof;
+    const char* label;
+};
+
+struct ProfScope {  // RAII: records e0 at construction, e1 at destruction
+    Profiler* p;
+    hipStream_t s;
+    ProfRecord r;
+    bool active;
+    ProfScope(const LaunchCtx& c, const char* kernel, double flops, double bytes)
+        : p(c.prof), s(c.stream), active(c.prof && c.prof->on) {
+        if (!active) return;
+        r.kernel = kernel;
+        r.label = c.label ? c.label : "";
+        r.flops = flops;
+        r.bytes = bytes;
+        (void)hipEventCreate(&r.e0);
+        (void)hipEventCreate(&r.e1);
+        (void)hipEventRecord(r.e0, s);
+    }
+    ~ProfScope() {
+        if (!active) return;
+        (void)hipEventRecord(r.e1, s);
+        p->log.push_back(r);
+    }
+};
+
+// ----------------------------------------------------------------------------------------
+// implicit-GEMM convolution / linear layer on fp32 MFMA  (conv_igemm.hip)
+// ----------------------------------------------------------------------------------------
+struct ConvArgs {
+    const float* x;      // NHWC activations; pixel stride ldx floats
+    const float* w;      // packed weights [Kp/4][Npad][4], k = (ky*KW+kx)*Cin + ci
+    const float* scale;  // [Npad]
+    const float* shift;  // [Npad]
+    const float* res;    // optional residual, indexed like out (may alias out)
+    float* out;          // [M][ldo]
+    int B, H, W, Cin, ldx;
+    int OH, OW, Cout, Npad, ldo;
+    int KH, KW, stride, pad;
+    int relu;
+};
+// Cin % 32 == 0, Npad % 64 == 0.  Returns hipError as int.
+int launch_conv_igemm(const ConvArgs& a, const LaunchCtx& ctx);
+// pick the tile the launcher would use (for tests / labels)
+const char* conv_igemm_variant(const ConvArgs& a);
+
+// ----------------------------------------------------------------------------------------
+// stem + pooling  (stem.hip)
+// ----------------------------------------------------------------------------------------
+// x NCHW (B,3,H,W); w packed [147][64] (k = c*49+ky*7+kx); out NHWC (B,OH,OW,64), BN+ReLU.
+int launch_stem(const float* x, const float* w, const float* scale, const float* shift,
+                float* out, int B, int H, int W, int OH, int OW, int relu, const LaunchCtx& ctx);
+int launch_maxpool3x3s2(const float* x, float* out, int B, int H, int W, int C, int OH, int OW,
+                        const LaunchCtx& ctx);
+// x (B,HW,C) -> out[b*ldo + c] = mean_hw
+int launch_avgpool(const float* x, float* out, int B, int HW, int C, int ldo, const LaunchCtx& ctx);
+
+// ----------------------------------------------------------------------------------------
+// heads  (head.hip)
+// ----------------------------------------------------------------------------------------
+constexpr int XC_LD = 2240;       // row stride of the IEF state [xf | pose6d | shape | cam | rot6d(R) | vfov | 0-pad]
+constexpr int XC_STATE_OFF = 2048;
+int launch_head_init(float* xc, const float* init_pose, const float* init_shape,
+                     const float* init_cam, const float* cam_rotmat, const float* cam_intrinsics,
+                     const float* img_h, int use_cam_feats, int B, const LaunchCtx& ctx);
+int launch_head_final(const float* xc, float* pred_pose, float* pred_shape, float* pred_cam,
+                      float* pred_pose_6d, float* rotmat_ws, float* betas_ws, float* cam_ws,
+                      int B, const LaunchCtx& ctx);
+int launch_camcalib_decode(const float* lv, const float* lp, const float* lr, int B, int nbins,
+                           const float* img_h, const float* img_w, float* vfov, float* pitch,
+                           float* roll, float* f_pix, float* R, float* K, const LaunchCtx& ctx);
+
+// ----------------------------------------------------------------------------------------
+// SMPL  (smpl.hip)
+// ----------------------------------------------------------------------------------------
+struct SmplDev {
+    int V = 0;
+    float* v_template = nullptr;   // (V,3)
+    float* shapedirs = nullptr;    // (V,3,10)
+    float* posedirs = nullptr;     // (207, 3V)
+    float* lbs_weights = nullptr;  // (V,24)
+    float* J_template = nullptr;   // (24,3)   = J_regressor @ v_template      (fp64 on host)
+    float* J_shapedirs = nullptr;  // (24,3,10) = J_regressor @ shapedirs      (fp64 on host)
+    float* J_extra = nullptr;      // (9,V)
+    int* parents = nullptr;        // (24)
+    int* extra_ids = nullptr;      // (21)
+    int* joint_map = nullptr;      // (49)
+};
+struct SmplArgs {
+    const float* rotmat;  // (B,24,3,3)
+    const float* betas;   // (B,10)
+    const float* cam;     // (B,3)
+    const float* cam_rotmat;      // (B,3,3) or null (mode 1)
+    const float* cam_intrinsics;  // (B,3,3) or null (mode 1)
+    const float* bbox_scale;
+    const float* bbox_center;
+    const float* img_w;
+    const float* img_h;
+    float* vertices;   // (B,V,3)
+    float* joints3d;   // (B,49,3)
+    float* joints2d;   // (B,49,2)
+    float* cam_t;      // (B,3)
+    // workspace
+    float* pose_feat;  // (B,208)
+    float* A;          // (B,24,12)
+    float* posed_j;    // (B,24,3)
+    int B;
+    int mode;          // 0: SMPLCamHead (full-image camera), 1: SMPLHead (weak perspective)
+    float focal_length;
+    float img_res;
+    int normalize_joints2d;
+};
+int launch_smpl(const SmplDev& m, const SmplArgs& a, const LaunchCtx& ctx);
+
+}  // namespace specmi

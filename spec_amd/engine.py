@@ -1,0 +1,243 @@
+"""Thin object wrapper over a libspecmi handle: parameter upload and forward calls with torch
+device tensors (torch is plumbing here: HBM allocations + the current HIP stream)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Mapping, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+KIND = {'camcalib': _lib.MODEL_CAMCALIB, 'hmr': _lib.MODEL_HMR}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _dev_f32(t, device, shape=None):
+    """-> contiguous fp32 tensor on `device` (accepts tensors / arrays / scalars), or None."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(np.asarray(t, dtype=np.float32))
+    t = t.to(device=device, dtype=torch.float32).contiguous()
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f'expected shape {tuple(shape)}, got {tuple(t.shape)}')
+    return t
+
+
+class Engine:
+    def __init__(self, kind: str, device: torch.device):
+        if device.type != 'cuda':
+            raise RuntimeError('spec_amd runs on an AMD GPU (torch device "cuda"); there is no CPU path')
+        self.lib = _lib.load()
+        self.kind = kind
+        self.device = torch.device('cuda', device.index if device.index is not None else torch.cuda.current_device())
+        h = C.c_void_p()
+        rc = self.lib.specmi_create(C.byref(h), self.device.index, KIND[kind])
+        if rc != _lib.OK:
+            raise _lib.SpecmiError(rc, (self.lib.specmi_last_error(None) or b'?').decode())
+        self.h = h
+        self.nbins = 256
+        self.num_verts = 0
+
+    def close(self):
+        if getattr(self, 'h', None) is not None and self.h:
+            self.lib.specmi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- parameters ----------------------------------------------------------------------
+    def set_option(self, name: str, value):
+        if isinstance(value, float):
+            _lib.check(self.h, self.lib.specmi_set_option_f32(self.h, name.encode(), value))
+        else:
+            _lib.check(self.h, self.lib.specmi_set_option_i32(self.h, name.encode(), int(value)))
+
+    def set_tensor(self, name: str, value):
+        if isinstance(value, torch.Tensor):
+            value = value.detach().cpu().numpy()
+        a = np.asarray(value)
+        if a.dtype.kind in 'iu' or a.dtype == np.bool_:
+            a = np.ascontiguousarray(a, dtype=np.int32)
+            fn = self.lib.specmi_set_tensor_i32
+        else:
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            fn = self.lib.specmi_set_tensor_f32
+        shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+        _lib.check(self.h, fn(self.h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
+
+    def load(self, tensors: Mapping[str, object], smpl: Optional[Mapping[str, object]] = None, **options):
+        """Stage a state_dict-like mapping (+ the SMPL body model under 'smpl.*'), then commit."""
+        for k, v in options.items():
+            self.set_option(k, v)
+        for k, v in tensors.items():
+            if k.endswith('num_batches_tracked'):
+                continue
+            self.set_tensor(k, v)
+        if smpl is not None:
+            for k, v in smpl.items():
+                self.set_tensor('smpl.' + k, v)
+            self.num_verts = int(np.asarray(smpl['v_template']).shape[0]) if not isinstance(
+                smpl['v_template'], torch.Tensor) else int(smpl['v_template'].shape[0])
+        if 'fc_vfov.weight' in tensors:
+            self.nbins = int(tensors['fc_vfov.weight'].shape[0])
+        _lib.check(self.h, self.lib.specmi_commit(self.h))
+
+    # ---- forward ---------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _images(self, images):
+        if not isinstance(images, torch.Tensor) or images.device.type != 'cuda':
+            raise RuntimeError('images must be a device tensor (no CPU path in spec_amd)')
+        if images.dim() != 4 or images.shape[1] != 3:
+            raise ValueError(f'images must be (B,3,H,W), got {tuple(images.shape)}')
+        return images.to(device=self.device, dtype=torch.float32).contiguous()
+
+    def trunk(self, images):
+        x = self._images(images)
+        B, _, H, W = x.shape
+
+        def o(n, k, s, p):
+            return (n + 2 * p - k) // s + 1
+        fh, fw = H, W
+        fh, fw = o(fh, 7, 2, 3), o(fw, 7, 2, 3)
+        fh, fw = o(fh, 3, 2, 1), o(fw, 3, 2, 1)
+        for _ in range(3):
+            fh, fw = o(fh, 3, 2, 1), o(fw, 3, 2, 1)
+        feat = torch.empty(B, fh, fw, 2048, device=self.device, dtype=torch.float32)
+        _lib.check(self.h, self.lib.specmi_trunk_forward(self.h, _ptr(x), B, H, W, _ptr(feat), self._stream()))
+        return feat
+
+    def camcalib_forward(self, images):
+        x = self._images(images)
+        B, _, H, W = x.shape
+        out = torch.empty(3, B, self.nbins, device=self.device, dtype=torch.float32)
+        _lib.check(self.h, self.lib.specmi_camcalib_forward(
+            self.h, _ptr(x), B, H, W, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), self._stream()))
+        return [out[0], out[1], out[2]]
+
+    def camcalib_decode(self, lv, lp, lr, img_h=None, img_w=None):
+        lv, lp, lr = (_dev_f32(t, self.device) for t in (lv, lp, lr))
+        B, nb = lv.shape
+        img_h = _dev_f32(img_h, self.device, (B,))
+        img_w = _dev_f32(img_w, self.device, (B,))
+        mk = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)
+        vf, pt, rl = mk(B), mk(B), mk(B)
+        f = mk(B) if img_h is not None else None
+        R = mk(B, 3, 3)
+        K = mk(B, 3, 3) if (img_h is not None and img_w is not None) else None
+        _lib.check(self.h, self.lib.specmi_camcalib_decode(
+            self.h, _ptr(lv), _ptr(lp), _ptr(lr), B, nb, _ptr(img_h), _ptr(img_w), _ptr(vf), _ptr(pt),
+            _ptr(rl), _ptr(f), _ptr(R), _ptr(K), self._stream()))
+        return {'vfov': vf, 'pitch': pt, 'roll': rl, 'f_pix': f, 'cam_rotmat': R, 'cam_intrinsics': K}
+
+    def _cam_args(self, B, cam_rotmat, cam_intrinsics, bbox_scale, bbox_center, img_w, img_h):
+        d = self.device
+        return (_dev_f32(cam_rotmat, d, (B, 3, 3)), _dev_f32(cam_intrinsics, d, (B, 3, 3)),
+                _dev_f32(bbox_scale, d, (B,)), _dev_f32(bbox_center, d, (B, 2)),
+                _dev_f32(img_w, d, (B,)), _dev_f32(img_h, d, (B,)))
+
+    def _hmr_outputs(self, B) -> Dict[str, torch.Tensor]:
+        mk = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)
+        return {'smpl_vertices': mk(B, self.num_verts, 3), 'smpl_joints3d': mk(B, 49, 3),
+                'smpl_joints2d': mk(B, 49, 2), 'pred_cam_t': mk(B, 3), 'pred_pose': mk(B, 24, 3, 3),
+                'pred_cam': mk(B, 3), 'pred_shape': mk(B, 10), 'pred_pose_6d': mk(B, 144)}
+
+    def hmr_forward(self, images, cam_rotmat=None, cam_intrinsics=None, bbox_scale=None,
+                    bbox_center=None, img_w=None, img_h=None, out: Optional[Dict[str, torch.Tensor]] = None):
+        x = self._images(images)
+        B, _, H, W = x.shape
+        R, K, sc, ce, iw, ih = self._cam_args(B, cam_rotmat, cam_intrinsics, bbox_scale, bbox_center, img_w, img_h)
+        out = out if out is not None else self._hmr_outputs(B)
+        o = _lib.HmrOutputs(**{k: out[k].data_ptr() for k, _ in _lib.HmrOutputs._fields_})
+        _lib.check(self.h, self.lib.specmi_hmr_forward(
+            self.h, _ptr(x), B, H, W, _ptr(R), _ptr(K), _ptr(sc), _ptr(ce), _ptr(iw), _ptr(ih),
+            C.byref(o), self._stream()))
+        return out
+
+    def hmr_head(self, feat_nhwc, cam_rotmat=None, cam_intrinsics=None, img_h=None):
+        f = _dev_f32(feat_nhwc, self.device)
+        B, fh, fw, _ = f.shape
+        R = _dev_f32(cam_rotmat, self.device, (B, 3, 3))
+        K = _dev_f32(cam_intrinsics, self.device, (B, 3, 3))
+        ih = _dev_f32(img_h, self.device, (B,))
+        mk = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)
+        out = {'pred_pose': mk(B, 24, 3, 3), 'pred_shape': mk(B, 10), 'pred_cam': mk(B, 3),
+               'pred_pose_6d': mk(B, 144)}
+        _lib.check(self.h, self.lib.specmi_hmr_head_forward(
+            self.h, _ptr(f), B, fh, fw, _ptr(R), _ptr(K), _ptr(ih), _ptr(out['pred_pose']),
+            _ptr(out['pred_shape']), _ptr(out['pred_cam']), _ptr(out['pred_pose_6d']), self._stream()))
+        return out
+
+    def smpl(self, rotmat, betas, cam, cam_rotmat=None, cam_intrinsics=None, bbox_scale=None,
+             bbox_center=None, img_w=None, img_h=None):
+        rot = _dev_f32(rotmat, self.device)
+        B = rot.shape[0]
+        rot = rot.reshape(B, 24, 3, 3).contiguous()
+        be = _dev_f32(betas, self.device, (B, 10))
+        cm = _dev_f32(cam, self.device, (B, 3))
+        R, K, sc, ce, iw, ih = self._cam_args(B, cam_rotmat, cam_intrinsics, bbox_scale, bbox_center, img_w, img_h)
+        mk = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)
+        out = {'smpl_vertices': mk(B, self.num_verts, 3), 'smpl_joints3d': mk(B, 49, 3),
+               'smpl_joints2d': mk(B, 49, 2), 'pred_cam_t': mk(B, 3)}
+        _lib.check(self.h, self.lib.specmi_smpl_forward(
+            self.h, _ptr(rot), _ptr(be), _ptr(cm), B, _ptr(R), _ptr(K), _ptr(sc), _ptr(ce), _ptr(iw),
+            _ptr(ih), _ptr(out['smpl_vertices']), _ptr(out['smpl_joints3d']), _ptr(out['smpl_joints2d']),
+            _ptr(out['pred_cam_t']), self._stream()))
+        return out
+
+    def conv2d(self, x, w_oihw, scale, shift, stride, pad, residual=None, relu=True, nchw_input=False):
+        """Single fused layer (tests).  x NHWC device tensor (NCHW for the 7x7 stem)."""
+        x = _dev_f32(x, self.device)
+        w = np.ascontiguousarray(np.asarray(w_oihw, dtype=np.float32))
+        sc = np.ascontiguousarray(np.asarray(scale, dtype=np.float32))
+        sh = np.ascontiguousarray(np.asarray(shift, dtype=np.float32))
+        cout, cin, kh, kw = w.shape
+        if nchw_input:
+            B, _, H, W = x.shape
+        else:
+            B, H, W, _ = x.shape
+        oh, ow = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+        out = torch.empty(B, oh, ow, cout, device=self.device, dtype=torch.float32)
+        res = _dev_f32(residual, self.device, (B, oh, ow, cout))
+        _lib.check(self.h, self.lib.specmi_conv2d(
+            self.h, _ptr(x), B, H, W, cin, w.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p),
+            sh.ctypes.data_as(C.c_void_p), cout, kh, kw, stride, pad, _ptr(res), int(relu), _ptr(out),
+            self._stream()))
+        return out
+
+    def maxpool(self, x):
+        x = _dev_f32(x, self.device)
+        B, H, W, Cc = x.shape
+        out = torch.empty(B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc, device=self.device, dtype=torch.float32)
+        _lib.check(self.h, self.lib.specmi_maxpool3x3s2(self.h, _ptr(x), B, H, W, Cc, _ptr(out), self._stream()))
+        return out
+
+    def avgpool(self, x):
+        x = _dev_f32(x, self.device)
+        B, H, W, Cc = x.shape
+        out = torch.empty(B, Cc, device=self.device, dtype=torch.float32)
+        _lib.check(self.h, self.lib.specmi_avgpool(self.h, _ptr(x), B, H * W, Cc, _ptr(out), self._stream()))
+        return out
+
+    # ---- profiling -------------------------------------------------------------------------
+    def profile(self, on: bool):
+        _lib.check(self.h, self.lib.specmi_profile_enable(self.h, int(on)))
+
+    def profile_read(self, max_entries: int = 512):
+        arr = (_lib.ProfEntry * max_entries)()
+        n = C.c_int(0)
+        _lib.check(self.h, self.lib.specmi_profile_read(self.h, arr, max_entries, C.byref(n)))
+        return [{'kernel': arr[i].kernel.decode(), 'label': arr[i].label.decode(), 'ms': arr[i].ms,
+                 'flops': arr[i].flops, 'bytes': arr[i].bytes, 'launches': arr[i].launches}
+                for i in range(min(n.value, max_entries))]

@@ -1,0 +1,72 @@
+"""The fused per-image path: CamCalib -> soft-argmax decode -> (R, K) -> SPEC -> SMPL -> projection.
+
+The reference runs these as separate processes joined by pickle files
+(``spec/tester.py:86-88`` spawns ``scripts/camcalib_demo.py``; ``spec/utils/cam_params.py:28-35``
+reads the result back).  Here every hand-off stays in HBM on one stream.
+
+Multi-GPU (``BASELINE.json`` config 4): images shard embarrassingly across ranks (no
+cross-image op in eval mode); each rank packs its outputs into one (B, 21294)-float record
+and a single RCCL all-gather over xGMI collects them.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from . import cam_utils
+
+# (key, per-image shape) in packing order: 85,164 B of SPEC outputs + 12 B of camera angles
+PACKED_KEYS = (
+    ('smpl_vertices', None), ('smpl_joints3d', (49, 3)), ('smpl_joints2d', (49, 2)),
+    ('pred_cam_t', (3,)), ('pred_pose', (24, 3, 3)), ('pred_cam', (3,)), ('pred_shape', (10,)),
+    ('pred_pose_6d', (144,)), ('cam_vfov', ()), ('cam_pitch', ()), ('cam_roll', ()),
+)
+
+
+class SpecPipeline:
+    def __init__(self, camcalib, hmr):
+        self.camcalib = camcalib
+        self.hmr = hmr
+
+    @torch.no_grad()
+    def __call__(self, images, bbox_scale, bbox_center, img_w, img_h, camcalib_images=None) -> Dict[str, torch.Tensor]:
+        """``images``: (B,3,224,224) crops for SPEC.  ``camcalib_images``: what CamCalib sees
+        (the full frame in the reference demo; defaults to the same crops, as in the benchmark)."""
+        logits = self.camcalib(images if camcalib_images is None else camcalib_images)
+        cam = cam_utils.decode_camera(logits[0], logits[1], logits[2], img_h=img_h, img_w=img_w)
+        out = self.hmr(images, cam_rotmat=cam['cam_rotmat'], cam_intrinsics=cam['cam_intrinsics'],
+                       bbox_scale=bbox_scale, bbox_center=bbox_center, img_w=img_w, img_h=img_h)
+        out.update({'cam_vfov': cam['vfov'], 'cam_pitch': cam['pitch'], 'cam_roll': cam['roll'],
+                    'cam_f_pix': cam['f_pix'], 'cam_rotmat': cam['cam_rotmat'],
+                    'cam_intrinsics': cam['cam_intrinsics']})
+        return out
+
+
+def pack_outputs(out: Dict[str, torch.Tensor]) -> torch.Tensor:
+    B = out['pred_cam'].shape[0]
+    return torch.cat([out[k].reshape(B, -1) for k, _ in PACKED_KEYS], dim=1).contiguous()
+
+
+def unpack_outputs(packed: torch.Tensor, num_verts: int) -> Dict[str, torch.Tensor]:
+    B = packed.shape[0]
+    res, off = {}, 0
+    for k, shp in PACKED_KEYS:
+        shp = (num_verts, 3) if shp is None else shp
+        n = 1
+        for s in shp:
+            n *= s
+        res[k] = packed[:, off:off + n].reshape(B, *shp)
+        off += n
+    return res
+
+
+def gather_outputs(out: Dict[str, torch.Tensor], group=None) -> torch.Tensor:
+    """One all-gather (RCCL over xGMI with backend 'nccl'; gloo on CPU tests) of the packed
+    per-image records: returns (world*B, record) on every rank, rank-major."""
+    import torch.distributed as dist
+    packed = pack_outputs(out)
+    world = dist.get_world_size(group)
+    full = torch.empty(world * packed.shape[0], packed.shape[1], device=packed.device, dtype=packed.dtype)
+    dist.all_gather_into_tensor(full, packed, group=group)
+    return full

@@ -1,0 +1,169 @@
+"""End-to-end parity on the GPU through the drop-in nn.Modules: against the golden vectors the
+reference's own modules produced (tests/golden), against the CPU oracle on fresh seeded
+inputs, and - at BASELINE.json's full batch 256 - through size-independent properties."""
+import numpy as np
+import pytest
+import torch
+
+from spec_amd import synth
+from tests.util import golden, gpu_models, oracle_models, rel_err, t
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+DEV = 'cuda:0'
+TOL = 1e-4   # BASELINE.json: SMPL vertices and projected keypoints within 1e-4 relative fp32
+
+
+@pytest.fixture(scope='module')
+def models():
+    return gpu_models(True, True, DEV)
+
+
+def test_native_library_is_loaded(models):
+    """The GPU path must be the HIP library, not a silent fallback."""
+    import os
+    from spec_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH)
+    maps = open('/proc/self/maps').read()
+    assert 'libspecmi.so' in maps
+
+
+def test_trunk_vs_oracle(models):
+    _, hm = models
+    _, ohm = oracle_models(True, True)
+    x = t(synth.images(11, 2))
+    feat = hm.engine(torch.device(DEV)).trunk(x.to(DEV)).cpu()
+    ref = ohm.backbone(x).permute(0, 2, 3, 1)
+    err = rel_err(feat.numpy(), ref.numpy())
+    assert err < 2e-5, err
+
+
+def test_camcalib_vs_reference_fixture(models):
+    cc, _ = models
+    g = golden('camcalib_e2e.npz')
+    x = t(synth.images(int(g['seed_images']), int(g['batch']))).to(DEV)
+    lg = cc(x)
+    assert isinstance(lg, list) and len(lg) == 3 and all(l.shape == (int(g['batch']), 256) for l in lg)
+    for l, k in zip(lg, ('logits_vfov', 'logits_pitch', 'logits_roll')):
+        err = rel_err(l.cpu().numpy(), g[k])
+        assert err < 5e-5, (k, err)
+    from spec_amd.cam_utils import convert_preds_to_angles
+    ang = convert_preds_to_angles(*lg, loss_type='softargmax_biased_l2')
+    for a, k in zip(ang, ('vfov', 'pitch', 'roll')):
+        assert np.abs(a.cpu().numpy() - g[k]).max() < 2e-5, k
+
+
+@pytest.mark.parametrize('tag,use_cam,ucf', [('camfeats', True, True), ('cam', True, False), ('nocam', False, False)])
+def test_hmr_vs_reference_fixture(tag, use_cam, ucf):
+    g = golden(f'hmr_e2e_{tag}.npz')
+    _, hm = gpu_models(use_cam, ucf, DEV)
+    B = int(g['batch'])
+    x = t(synth.images(int(g['seed_images']), B)).to(DEV)
+    if use_cam:   # positional call as in spec/trainer.py:139
+        out = hm(x, t(g['cam_rotmat']).to(DEV), t(g['cam_intrinsics']).to(DEV), t(g['bbox_scale']).to(DEV),
+                 t(g['bbox_center']).to(DEV), t(g['img_w']).to(DEV), t(g['img_h']).to(DEV))
+    else:
+        out = hm(x)
+    assert sorted(out.keys()) == sorted(g['out_keys'])
+    for k in out:
+        assert tuple(out[k].shape) == g[f'out_{k}'].shape, k
+        err = rel_err(out[k].cpu().numpy(), g[f'out_{k}'])
+        assert err < TOL, (k, err)
+        assert hasattr(out[k], 'cpu')      # spec/tester.py:153-154 contract
+
+
+def _wmpjpe_mm(verts_a, verts_b, J):
+    """spec/utils/compute_error.py:33-49,184: J_regressor @ vertices, pelvis aligned, mean L2 (mm)."""
+    ja = np.einsum('jv,bvc->bjc', J, verts_a)
+    jb = np.einsum('jv,bvc->bjc', J, verts_b)
+    ja = ja - ja[:, :1]
+    jb = jb - jb[:, :1]
+    return float(np.sqrt(((ja - jb) ** 2).sum(-1)).mean() * 1000.0)
+
+
+def test_full_pipeline_vs_oracle(models):
+    from oracle.models import full_pipeline
+    from spec_amd.pipeline import SpecPipeline
+    from tests.util import smpl_model
+    cc, hm = models
+    occ, ohm = oracle_models(True, True)
+    B = 4
+    x = t(synth.images(31, B))
+    sc, ce, iw, ih = [t(a) for a in synth.bbox_inputs(31, B, 640., 480.)]
+    ref = full_pipeline(occ, ohm, x, sc, ce, iw, ih)
+    out = SpecPipeline(cc, hm)(x.to(DEV), sc.to(DEV), ce.to(DEV), iw.to(DEV), ih.to(DEV))
+    for k in ('cam_vfov', 'cam_pitch', 'cam_roll'):
+        assert np.abs(out[k].cpu().numpy() - ref[k].numpy()).max() < 2e-5, k
+    for k in ('smpl_vertices', 'smpl_joints3d', 'smpl_joints2d', 'pred_cam_t', 'pred_pose', 'pred_shape', 'pred_cam'):
+        err = rel_err(out[k].cpu().numpy(), ref[k].numpy())
+        assert err < TOL, (k, err)
+    d = _wmpjpe_mm(out['smpl_vertices'].cpu().numpy().astype(np.float64), ref['smpl_vertices'].numpy().astype(np.float64),
+                   smpl_model()['J_regressor'].astype(np.float64))
+    assert d < 0.1, f'delta W-MPJPE {d} mm'      # BASELINE.json: within 0.1 mm
+
+
+@pytest.mark.parametrize('B', [1, 3])
+def test_small_and_ragged_batches(models, B):
+    _, hm = models
+    _, ohm = oracle_models(True, True)
+    x = t(synth.images(100 + B, B))
+    sc, ce, iw, ih = [t(a) for a in synth.bbox_inputs(100 + B, B, 640., 480.)]
+    g = torch.Generator().manual_seed(B)
+    from oracle.models import cam_params
+    R, K = cam_params(0.3 * torch.randn(B, generator=g), 0.2 * torch.randn(B, generator=g),
+                      (400 + 200 * torch.rand(B, generator=g)).numpy(), iw, ih)
+    ref = ohm(x, R, K, sc, ce, iw, ih)
+    out = hm(x.to(DEV), cam_rotmat=R.to(DEV), cam_intrinsics=K.to(DEV), bbox_scale=sc.to(DEV),
+             bbox_center=ce.to(DEV), img_w=iw.to(DEV), img_h=ih.to(DEV))
+    for k in ref:
+        assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < TOL, k
+
+
+def test_camcalib_variable_resolution(models):
+    """CamCalib runs on the full frame at arbitrary resolution (camcalib/pano_dataset.py:157)."""
+    cc, _ = models
+    occ, _ = oracle_models(True, True)
+    x = t(synth.images(55, 1, 300, 420))
+    lg = cc(x.to(DEV))
+    ref = occ(x)
+    for a, b in zip(lg, ref):
+        assert rel_err(a.cpu().numpy(), b.numpy()) < 5e-5
+
+
+def test_full_batch_256_properties(models):
+    """BASELINE.json config 3 size (B=256): results for an image do not depend on its batch
+    (bit-exact: the k-order of every dot product is fixed), and all outputs are finite."""
+    from spec_amd.pipeline import SpecPipeline
+    cc, hm = models
+    pipe = SpecPipeline(cc, hm)
+    B = 256
+    x = t(synth.images(77, B)).to(DEV)
+    sc, ce, iw, ih = [t(a).to(DEV) for a in synth.bbox_inputs(77, B)]
+    big = pipe(x, sc, ce, iw, ih)
+    idx = torch.tensor([0, 5, 63, 64, 127, 200, 254, 255], device=DEV)
+    small = pipe(x[idx], sc[idx], ce[idx], iw[idx], ih[idx])
+    for k in ('smpl_vertices', 'smpl_joints3d', 'smpl_joints2d', 'pred_cam_t', 'pred_pose_6d', 'cam_vfov'):
+        assert torch.isfinite(big[k]).all(), k
+        assert torch.equal(big[k][idx], small[k]), k
+    # rotations are orthonormal, joints2d consistent with joints3d through the returned camera
+    Rm = big['pred_pose'].reshape(-1, 3, 3).double()
+    eye = torch.eye(3, dtype=torch.float64, device=DEV)
+    assert (Rm @ Rm.transpose(1, 2) - eye).abs().max() < 1e-5
+    X = big['smpl_joints3d'].double()
+    P = torch.einsum('bij,bkj->bki', big['cam_rotmat'].double(), X) + big['pred_cam_t'].double()[:, None]
+    P = P / P[..., 2:3]
+    p2 = torch.einsum('bij,bkj->bki', big['cam_intrinsics'].double(), P)[..., :2]
+    assert ((p2 - big['smpl_joints2d'].double()).abs().max() / big['smpl_joints2d'].abs().max()) < 1e-5
+
+
+def test_reload_after_parameter_change(models):
+    """In-place parameter edits are picked up (version counters) - checkpoint loading after construction."""
+    cc, _ = models
+    x = t(synth.images(5, 1)).to(DEV)
+    a = cc(x)[0].clone()
+    with torch.no_grad():
+        cc.fc_vfov.bias.add_(1.0)
+    b = cc(x)[0]
+    assert torch.allclose(b, a + 1.0, atol=1e-5)
+    with torch.no_grad():
+        cc.fc_vfov.bias.sub_(1.0)

@@ -1,0 +1,65 @@
+"""Shared builders for the tests (oracle side and GPU side use the same seeded tensors)."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+SEED_CAMCALIB, SEED_HMR, SEED_SMPL, SEED_IMG = 1001, 1002, 1003, 20210001
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def rel_err(a, b):
+    """max |a-b| / max |b|  (the '1e-4 relative fp32' criterion of BASELINE.json, tensor-wise)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+_cache = {}
+
+
+def synth_states(use_cam_feats=True):
+    from spec_amd import synth
+    key = ('states', use_cam_feats)
+    if key not in _cache:
+        _cache[key] = (synth.camcalib_state(SEED_CAMCALIB), synth.hmr_state(SEED_HMR, use_cam_feats))
+    return _cache[key]
+
+
+def smpl_model():
+    from spec_amd import synth
+    if 'smpl' not in _cache:
+        _cache['smpl'] = synth.smpl_model(SEED_SMPL)
+    return _cache['smpl']
+
+
+def oracle_models(use_cam=True, use_cam_feats=True):
+    from oracle import heads
+    from oracle.models import CamCalibOracle, HMROracle, load_numpy_state
+    torch.set_grad_enabled(False)
+    heads.set_assets(smpl_model=smpl_model())
+    cs, hs = synth_states(use_cam_feats)
+    cc = load_numpy_state(CamCalibOracle().eval(), cs)
+    hm = load_numpy_state(HMROracle(use_cam=use_cam, use_cam_feats=use_cam_feats).eval(), hs)
+    return cc, hm
+
+
+def gpu_models(use_cam=True, use_cam_feats=True, device='cuda:0'):
+    from spec_amd import assets
+    from spec_amd.modules import HMR, CameraRegressorNetwork
+    assets.use_synthetic_assets(SEED_SMPL)
+    cs, hs = synth_states(use_cam_feats)
+    cc = CameraRegressorNetwork()
+    cc.load_state_dict({k: t(v) for k, v in cs.items()}, strict=True)
+    hm = HMR(use_cam=use_cam, use_cam_feats=use_cam_feats)
+    missing, unexpected = hm.load_state_dict({k: t(v) for k, v in hs.items()}, strict=False)
+    assert not unexpected and all(m.startswith('smpl.') for m in missing), (missing, unexpected)
+    return cc.to(device).eval(), hm.to(device).eval()
