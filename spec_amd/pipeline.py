@@ -43,6 +43,14 @@ class SpecPipeline:
         return out
 
 
+def shard_range(total: int, rank: int, world: int):
+    """Contiguous rank-major image slice [lo, hi) of a global batch (config 4: 2048 -> 256 per GPU).
+    Remainders go to the lowest ranks, so any total / world is covered exactly once."""
+    q, r = divmod(total, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
 def pack_outputs(out: Dict[str, torch.Tensor]) -> torch.Tensor:
     B = out['pred_cam'].shape[0]
     return torch.cat([out[k].reshape(B, -1) for k, _ in PACKED_KEYS], dim=1).contiguous()

@@ -1,0 +1,76 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the shard -> forward -> single all-gather
+protocol (the GPU forward is replaced by a deterministic per-image stand-in; the collective
+and the rank-major packing are the real code from spec_amd.pipeline)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from spec_amd.pipeline import PACKED_KEYS, gather_outputs, pack_outputs, shard_range, unpack_outputs
+
+V = 37  # small synthetic vertex count
+
+
+def _fake_forward(image_ids):
+    """Per-image outputs that depend only on the global image id."""
+    out = {}
+    for k, shp in PACKED_KEYS:
+        shp = (V, 3) if shp is None else shp
+        n = int(np.prod(shp)) if len(shp) else 1
+        base = torch.arange(n, dtype=torch.float32).reshape(1, *shp) * 1e-3
+        out[k] = base + image_ids.to(torch.float32).reshape(-1, *([1] * len(shp)))
+    return out
+
+
+def _worker(rank, world, port, total, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        lo, hi = shard_range(total, rank, world)
+        out = _fake_forward(torch.arange(lo, hi))
+        full = gather_outputs(out)
+        q.put((rank, full.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def test_shard_range_covers_everything():
+    for total, world in [(2048, 8), (10, 4), (7, 2), (3, 8)]:
+        seen = []
+        for r in range(world):
+            lo, hi = shard_range(total, r, world)
+            seen += list(range(lo, hi))
+        assert seen == list(range(total))
+    assert shard_range(2048, 3, 8) == (768, 1024)
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_all_gather_matches_unsharded():
+    world, total = 2, 8
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = pack_outputs(_fake_forward(torch.arange(total))).numpy()
+    for r in range(world):
+        assert np.array_equal(results[r], ref)        # every rank holds the rank-major global result
+    back = unpack_outputs(torch.from_numpy(results[0]), V)
+    assert back['smpl_vertices'].shape == (total, V, 3)
+    assert torch.equal(back['cam_vfov'], torch.arange(total, dtype=torch.float32))

@@ -24,6 +24,8 @@ def test_native_library_is_loaded(models):
     import os
     from spec_amd import _lib
     assert os.path.exists(_lib.LIB_PATH)
+    cc, _ = models
+    cc(t(synth.images(1, 1)).to(DEV))          # the library is dlopen'ed by the first forward
     maps = open('/proc/self/maps').read()
     assert 'libspecmi.so' in maps
 
