@@ -116,6 +116,8 @@ def main():
     ap.add_argument('--batch', type=int, default=256, help='images per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--no-overlap', action='store_true', help='run CamCalib and SPEC back to back on one stream')
+    ap.add_argument('--force-variant', type=int, default=0, help='debug: force a conv tile (1:128x128 2:128x64 3:64x64)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -135,7 +137,10 @@ def main():
     from spec_amd.pipeline import SpecPipeline, gather_outputs
     torch.set_grad_enabled(False)
     cc, hm, cs, hs = build_models(device)
-    pipe = SpecPipeline(cc, hm)
+    pipe = SpecPipeline(cc, hm, overlap=not args.no_overlap)
+    seq_pipe = SpecPipeline(cc, hm, overlap=False)    # per-kernel profiling pass runs serially
+    if args.force_variant:
+        cc._engine.set_option('force_conv_variant', args.force_variant)
     B = args.batch
     x, scale, center, img_w, img_h = make_inputs(B, device, 20210001 + rank)
 
@@ -179,7 +184,7 @@ def main():
             pass
         nprof = 2
         for _ in range(nprof):
-            pipe(x, scale, center, img_w, img_h)
+            seq_pipe(x, scale, center, img_w, img_h)
         torch.cuda.synchronize()
         entries = []
         for tag, e in (('camcalib', cc._engine), ('spec', hm._engine), ('decode', cam_eng)):
@@ -225,6 +230,7 @@ def main():
                                    'regressor + SMPL LBS 6890 verts + projection), random weights, '
                                    'synthetic 224x224 crops resident in HBM',
                        'batch_per_gpu': B, 'global_batch': B * n_gpus,
+                       'streams': 1 if args.no_overlap else 2,
                        'parallelism': f'images sharded over {n_gpus} GPU(s), 1 all-gather' if n_gpus > 1 else 'single GPU'},
             'roofline': roof, 'cpu_baseline': cpu,
         }

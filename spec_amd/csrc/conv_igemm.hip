@@ -44,6 +44,7 @@ struct KArgs {
     int KW, stride, pad;
     int M, nbn, nchunks, cpc;  // cpc = chunks per filter tap = Cin / 32
     int relu;
+    int vec_ok;  // out/res rows are 16-byte aligned: float4 epilogue traffic allowed
 };
 
 template <int BM, int BN>
@@ -160,25 +161,62 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(const KArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue: y = acc*scale + shift (+res) (ReLU); C/D layout of the 32x32 MFMA:
-    //      col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
+    // ---- epilogue -------------------------------------------------------------------------
+    // The accumulators go through LDS once so that the HBM side is whole-row traffic: the
+    // MFMA C/D layout (col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)) would give
+    // 4-byte stores at a row stride; after the transpose every lane moves 16 contiguous bytes
+    // and a wave covers 2 (BN=128) or 4 (BN=64) full output rows per instruction, for the
+    // store, the residual read and the scale/shift fetch alike.
+    // All waves have passed the loop's last barrier, so the A/B stages are free to reuse.
+    constexpr int LDC = BN + 4;
+    float* Cs = smem;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 32 + l31;
-        const float sc = p.scale[n], sh = p.shift[n];
-        const bool nok = n < p.Cout;
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const int m = m0 + wm * (BM / 2) + i * 32 + row;
-                if (nok && m < p.M) {
-                    const size_t o = (size_t)m * p.ldo + n;
-                    float v = fmaf(acc[i][j][r], sc, sh);
-                    if (p.res) v += p.res[o];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    p.out[o] = v;
+                const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                Cs[row * LDC + wn * (BN / 2) + j * 32 + l31] = acc[i][j][r];
+            }
+    __syncthreads();
+
+    constexpr int QPR = BN / 4;         // float4 quads per tile row
+    constexpr int RPP = 256 / QPR;      // rows per pass
+    const int cq = tid % QPR, r0 = tid / QPR;
+    const int n = n0 + cq * 4;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+    const bool full = (n + 3 < p.Cout) && p.vec_ok;
+#pragma unroll 4
+    for (int ps = 0; ps < BM / RPP; ++ps) {
+        const int row = r0 + ps * RPP;
+        const int m = m0 + row;
+        if (m >= p.M) break;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(Cs + row * LDC + cq * 4);
+        const size_t o = (size_t)m * p.ldo + n;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(a[e], sc[e], sh[e]);
+        if (full) {
+            if (p.res) {
+                const f32x4 rr = *reinterpret_cast<const f32x4*>(p.res + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += rr[e];
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            *reinterpret_cast<f32x4*>(p.out + o) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (n + e < p.Cout) {
+                    float t = v[e];
+                    if (p.res) t += p.res[o + e];
+                    if (p.relu) t = fmaxf(t, 0.f);
+                    p.out[o + e] = t;
                 }
             }
         }
@@ -235,6 +273,8 @@ int launch_conv_igemm(const ConvArgs& a, const LaunchCtx& ctx) {
     k.nchunks = a.KH * a.KW * k.cpc;
     k.nbn = 0;
     k.relu = a.relu;
+    k.vec_ok = (a.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0) &&
+               (!a.res || (reinterpret_cast<uintptr_t>(a.res) & 15) == 0);
     const double Kd = (double)a.KH * a.KW * a.Cin;
     const double flops = 2.0 * (double)M * a.Cout * Kd;
     const double bytes = 4.0 * ((double)a.B * a.H * a.W * a.Cin + (double)M * a.Cout * (a.res ? 2.0 : 1.0) +

@@ -25,18 +25,50 @@ PACKED_KEYS = (
 
 
 class SpecPipeline:
-    def __init__(self, camcalib, hmr):
+    """``overlap=True`` runs the CamCalib network on a second HIP stream concurrently with the
+    SPEC trunk (the two ResNet-50 trunks are independent; only the regressor head needs the
+    camera).  On MI355X this fills the partially occupied last wave of workgroups of one
+    trunk's kernels with the other trunk's work and lets bandwidth-bound layers of one run
+    beside MFMA-bound layers of the other."""
+
+    def __init__(self, camcalib, hmr, overlap: bool = True):
         self.camcalib = camcalib
         self.hmr = hmr
+        self.overlap = overlap
+        self._side = {}
+
+    def _side_stream(self, device):
+        if device not in self._side:
+            self._side[device] = torch.cuda.Stream(device=device)
+        return self._side[device]
 
     @torch.no_grad()
     def __call__(self, images, bbox_scale, bbox_center, img_w, img_h, camcalib_images=None) -> Dict[str, torch.Tensor]:
         """``images``: (B,3,224,224) crops for SPEC.  ``camcalib_images``: what CamCalib sees
         (the full frame in the reference demo; defaults to the same crops, as in the benchmark)."""
-        logits = self.camcalib(images if camcalib_images is None else camcalib_images)
-        cam = cam_utils.decode_camera(logits[0], logits[1], logits[2], img_h=img_h, img_w=img_w)
-        out = self.hmr(images, cam_rotmat=cam['cam_rotmat'], cam_intrinsics=cam['cam_intrinsics'],
-                       bbox_scale=bbox_scale, bbox_center=bbox_center, img_w=img_w, img_h=img_h)
+        cam_in = images if camcalib_images is None else camcalib_images
+        if not (self.overlap and self.hmr.use_cam):
+            logits = self.camcalib(cam_in)
+            cam = cam_utils.decode_camera(logits[0], logits[1], logits[2], img_h=img_h, img_w=img_w)
+            out = self.hmr(images, cam_rotmat=cam['cam_rotmat'], cam_intrinsics=cam['cam_intrinsics'],
+                           bbox_scale=bbox_scale, bbox_center=bbox_center, img_w=img_w, img_h=img_h)
+        else:
+            device = images.device
+            main = torch.cuda.current_stream(device)
+            side = self._side_stream(device)
+            side.wait_stream(main)                      # inputs were produced on the main stream
+            with torch.cuda.stream(side):
+                logits = self.camcalib(cam_in)
+                cam = cam_utils.decode_camera(logits[0], logits[1], logits[2], img_h=img_h, img_w=img_w)
+            eng = self.hmr.engine(device)
+            feat = eng.trunk(images)                    # SPEC trunk on the main stream, concurrently
+            main.wait_stream(side)                      # the head needs (R, K)
+            for v in cam.values():
+                if v is not None:
+                    v.record_stream(main)
+            out = eng.hmr_head(feat, cam['cam_rotmat'], cam['cam_intrinsics'], img_h)
+            out.update(eng.smpl(out['pred_pose'], out['pred_shape'], out['pred_cam'], cam['cam_rotmat'],
+                                cam['cam_intrinsics'], bbox_scale, bbox_center, img_w, img_h))
         out.update({'cam_vfov': cam['vfov'], 'cam_pitch': cam['pitch'], 'cam_roll': cam['roll'],
                     'cam_f_pix': cam['f_pix'], 'cam_rotmat': cam['cam_rotmat'],
                     'cam_intrinsics': cam['cam_intrinsics']})
