@@ -21,7 +21,8 @@ export TMPDIR=/tmp
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile --no-overlap > $OUT/rocprof_$TAG.log 2>&1
 cd $R
-find $OUT/prof_$TAG -name "*kernel_stats*" | head -3
+for db in $(find $OUT/prof_$TAG -name "*.db"); do python scripts/rocprof_summary.py stats $db > $OUT/rocprof_${TAG}_kernel_stats.txt; done
+rm -rf $OUT/prof_$TAG; head -8 $OUT/rocprof_${TAG}_kernel_stats.txt
 for f in $OUT/bench_${TAG}_serial.json $OUT/bench_${TAG}.json $OUT/bench_${TAG}_v2.json $OUT/bench_${TAG}_v3.json; do python - "$f" <<'PY'
 import json,sys
 try:

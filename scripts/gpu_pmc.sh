@@ -20,5 +20,13 @@ pass sq2 GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_LDS SQ_LDS_BANK_CONFLIC
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum
-ls $OUT | grep pmc_$TAG
-tail -3 $OUT/pmc_$TAG.log
+cd $R
+: > $OUT/pmc_${TAG}_summary.txt
+for d in $OUT/pmc_${TAG}_*/; do
+  for db in $(find $d -name "*.db"); do python scripts/rocprof_summary.py pmc $db >> $OUT/pmc_${TAG}_summary.txt 2>&1; done
+  rm -rf $d
+done
+grep -E "GUI_ACTIVE|MFMA|FETCH|WRITE|TCC|WAIT|conv_igemm|stem" $OUT/pmc_${TAG}_summary.txt | head -60
+tail -2 $OUT/pmc_$TAG.log | cut -c1-200
+rm -f $OUT/pmc_$TAG.log
+head -c 200000 $OUT/counters_avail.txt > $OUT/counters_avail_head.txt; rm -f $OUT/counters_avail.txt

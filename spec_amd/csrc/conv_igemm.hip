@@ -86,18 +86,22 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(const KArgs p) {
     }
 
     f32x4 ra[AI], rb[BI];
+    unsigned a_okmask = 0;
+    // Loads are unconditional (an out-of-image tap or a row past M reads pixel 0 and is zeroed
+    // when it is written to LDS): no exec-masked branches, so the 2*AI/BI loads of a chunk are
+    // issued back to back and stay in flight under the MFMAs.
     auto load_chunk = [&](int c) {
         const int tap = c / p.cpc;
         const int c0 = (c - tap * p.cpc) * BK;
         const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        a_okmask = 0;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
             const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const float* src = p.x + (size_t)(long long)(a_pix[i] + ky * p.W + kx) * p.ldx + c0 + a_kq * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(src);
-            ra[i] = v;
+            const long long pix = ok ? (long long)(a_pix[i] + ky * p.W + kx) : 0ll;
+            ra[i] = *reinterpret_cast<const f32x4*>(p.x + (size_t)pix * p.ldx + c0 + a_kq * 4);
+            a_okmask |= (ok ? 1u : 0u) << i;
         }
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
@@ -108,8 +112,11 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(const KArgs p) {
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < AI; ++i)
-            *reinterpret_cast<f32x4*>(&As[buf * A_STAGE + (a_r + 32 * i) * LDA + a_kq * 4]) = ra[i];
+        for (int i = 0; i < AI; ++i) {
+            f32x4 v = ra[i];
+            if (!((a_okmask >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(&As[buf * A_STAGE + (a_r + 32 * i) * LDA + a_kq * 4]) = v;
+        }
 #pragma unroll
         for (int i = 0; i < BI; ++i)
             *reinterpret_cast<f32x4*>(&Bs[buf * B_STAGE + (tid + 256 * i) * 4]) = rb[i];
@@ -128,15 +135,21 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(const KArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // ---- epilogue coordinates (known up front so the residual can be prefetched) ------------
+    constexpr int LDC = BN + 4;
+    constexpr int QPR = BN / 4;         // float4 quads per tile row
+    constexpr int RPP = 256 / QPR;      // rows per pass
+    constexpr int NP = BM / RPP;        // passes over the tile rows
+    const int cq = tid % QPR, r0 = tid / QPR;
+    const int n = n0 + cq * 4;
+    const bool full = (n + 3 < p.Cout) && p.vec_ok;
+    f32x4 rr[NP];
+
     load_chunk(0);
     store_chunk(0);
     __syncthreads();
 
-    for (int c = 0; c < p.nchunks; ++c) {
-        const int buf = c & 1;
-        const bool more = (c + 1) < p.nchunks;
-        if (more) load_chunk(c + 1);  // global loads in flight under the MFMAs below
-
+    auto compute = [&](int buf) {
         const float* Ab = As + buf * A_STAGE + (wm * (BM / 2) + l31) * LDA + hh * 4;
         const float* Bb = Bs + buf * B_STAGE + (hh * BN + wn * (BN / 2) + l31) * 4;
 #pragma unroll
@@ -156,10 +169,29 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(const KArgs p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
         }
+    };
 
-        if (more) store_chunk(buf ^ 1);
+    const int last = p.nchunks - 1;
+    for (int c = 0; c < last; ++c) {
+        load_chunk(c + 1);          // global loads in flight under the MFMAs below
+        __builtin_amdgcn_sched_barrier(0);   // keep hipcc from sinking the loads next to their use
+        compute(c & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        store_chunk((c + 1) & 1);
         __syncthreads();
     }
+    // last chunk: nothing left to stage - fetch the residual rows of the epilogue under its MFMAs
+    if (p.res && full) {
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            const int m = m0 + r0 + ps * RPP;
+            const size_t o = (m < p.M) ? (size_t)m * p.ldo + n : (size_t)n;
+            rr[ps] = *reinterpret_cast<const f32x4*>(p.res + o);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    compute(last & 1);
+    __syncthreads();
 
     // ---- epilogue -------------------------------------------------------------------------
     // The accumulators go through LDS once so that the HBM side is whole-row traffic: the
@@ -168,7 +200,6 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(const KArgs p) {
     // and a wave covers 2 (BN=128) or 4 (BN=64) full output rows per instruction, for the
     // store, the residual read and the scale/shift fetch alike.
     // All waves have passed the loop's last barrier, so the A/B stages are free to reuse.
-    constexpr int LDC = BN + 4;
     float* Cs = smem;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -181,26 +212,10 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(const KArgs p) {
             }
     __syncthreads();
 
-    constexpr int QPR = BN / 4;         // float4 quads per tile row
-    constexpr int RPP = 256 / QPR;      // rows per pass
-    const int cq = tid % QPR, r0 = tid / QPR;
-    const int n = n0 + cq * 4;
     const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);
     const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
-    const bool full = (n + 3 < p.Cout) && p.vec_ok;
-    constexpr int NP = BM / RPP;        // passes over the tile rows
     if (full) {
-        // all residual reads of the tile are issued before the first use (one latency, not NP)
-        f32x4 rr[NP];
-        if (p.res) {
-#pragma unroll
-            for (int ps = 0; ps < NP; ++ps) {
-                const int m = m0 + r0 + ps * RPP;
-                f32x4 t = {0.f, 0.f, 0.f, 0.f};
-                if (m < p.M) t = *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldo + n);
-                rr[ps] = t;
-            }
-        }
+        // the residual rows were fetched under the last chunk's MFMAs (rr)
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps) {
             const int row = r0 + ps * RPP;
