@@ -12,7 +12,7 @@
 //
 // MI355X mapping (CDNA4, wave64):
 //   * v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain), 64 cycles, 16 acc VGPRs.
-//     A workgroup = 4 waves in a 2x2 grid; a wave owns (BM/2)x(BN/2) = TMxTN tiles of 32x32.
+//     A workgroup = WGM x WGN waves; a wave owns TM x TN tiles of 32x32.
 //   * K is consumed in chunks of 32 (one filter tap x 32 channels).  Inside a chunk the k
 //     order is permuted so that each lane's 4 consecutive k values are one 16-byte LDS read:
 //     sub-chunk q (8 k's), lane half h, step s  ->  k = 8q + 4h + s.  A and B use the same
@@ -21,16 +21,25 @@
 //     distinct banks, ds_write_b128 of one row's 8 quads hits 32 distinct banks);
 //     B tile [8][BN][4] fp32 - exactly the HBM layout of the packed weights [K/4][Npad][4],
 //     so the copy is linear and the fragment read (consecutive n per lane) is conflict-free.
+//   * The fp32 MFMA holds a SIMD's matrix pipe for 64 cycles but the SIMD has only ~16 issue
+//     slots in that time, shared by all its waves - so everything that is not an MFMA is kept
+//     off the VALU: tile rows are addressed with buffer loads (32-bit per-row offset computed
+//     once + a scalar per-chunk offset in SGPRs), im2col padding and the M tail are handled by
+//     the buffer's hardware range check (an out-of-image tap gets an out-of-range offset and
+//     reads as 0.0), 1x1 convolutions need no per-chunk VALU work at all.
 //   * double-buffered LDS, register-staged prefetch of chunk c+1 issued before the MFMAs of
-//     chunk c (one barrier per chunk); 2 workgroups / CU (<= 69.6 KB LDS, <= 256 VGPR).
+//     chunk c (one barrier per chunk); the last chunk prefetches the residual rows instead.
 //   * blockIdx -> tile map is XCD-aware: the 8 XCDs get contiguous runs of tiles ordered
 //     n-fastest, so tiles sharing an A row-panel hit the same 4 MiB L2.
+//   * epilogue: accumulators are transposed through LDS so that HBM sees 16-byte,
+//     row-contiguous stores / residual reads with scale/shift/ReLU fused.
 #include "specmi_internal.h"
 
 namespace specmi {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct KArgs {
     const float* x;
@@ -39,26 +48,48 @@ struct KArgs {
     const float* shift;
     const float* res;
     float* out;
+    unsigned x_bytes, w_bytes;  // buffer extents (< 2^31)
     int H, W, ldx;
     int OW, OHW, Cout, Npad, ldo;
-    int KW, stride, pad;
+    int KH, KW, stride, pad;
     int M, nbn, nchunks, cpc;  // cpc = chunks per filter tap = Cin / 32
     int relu;
     int vec_ok;  // out/res rows are 16-byte aligned: float4 epilogue traffic allowed
+#ifdef SPECMI_TUNE
+    int ablate;  // perf ablation bits (wrong results!): 1 no global loads in loop, 2 no LDS restage, 4 no epilogue stores
+    unsigned long long* tprof;  // per-phase cycle counters (s_memtime)
+#endif
 };
 
-template <int BM, int BN>
-__global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(const KArgs p) {
+#ifdef SPECMI_TUNE
+#define TUNE_ABLATE(bit) (p.ablate & (bit))
+#define TUNE_T(var) const long long var = __builtin_amdgcn_s_memtime()
+#else
+#define TUNE_ABLATE(bit) 0
+#define TUNE_T(var)
+#endif
+
+constexpr unsigned kOutOfRange = 0x80000000u;  // >= any buffer extent: the load returns zeros
+
+template <int BM, int BN, int WGM, int WGN, bool IS1X1>
+__global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KArgs p) {
     constexpr int BK = 32;
     constexpr int LDA = BK + 4;
-    constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave
-    constexpr int AI = BM / 32, BI = BN / 32;  // float4 loads per thread per chunk
+    constexpr int NT = 64 * WGM * WGN;                         // threads: WGM x WGN waves
+    constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);  // 32x32 MFMA tiles per wave
+    constexpr int AI = BM * 8 / NT, BI = BN * 8 / NT;          // float4 loads per thread per chunk
+    constexpr int ARS = NT / 8;                                // A rows covered per load pass
     constexpr int A_STAGE = BM * LDA, B_STAGE = 8 * BN * 4;
+    static_assert(TM >= 1 && TN >= 1 && AI >= 1 && BI >= 1, "tile too small for the wave grid");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Bs = smem + 2 * A_STAGE;
 
     const int tid = threadIdx.x;
+#ifdef SPECMI_TUNE
+    const long long t_start = __builtin_amdgcn_s_memtime();
+    long long tp[4] = {0, 0, 0, 0};
+#endif
 
     // ---- XCD-aware tile order (bijective for any grid size) ------------------------------
     const int nblk = gridDim.x, bid = blockIdx.x;
@@ -67,12 +98,15 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(const KArgs p) {
     const int tile_m = L / p.nbn, tile_n = L - tile_m * p.nbn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    // ---- per-thread im2col rows ------------------------------------------------------------
+    // ---- buffer descriptors (wave-uniform) and per-thread row offsets -----------------------
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
     const int a_kq = tid & 7, a_r = tid >> 3;
-    int a_pix[AI], a_iy[AI], a_ix[AI];
+    unsigned a_voff[AI];   // byte offset of (row's tap-(0,0) pixel, quad a_kq); out-of-range when the row is past M (1x1)
+    unsigned a_mask[AI];   // 3x3: bit t = filter tap t lies inside the image for this row
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-        const int m = m0 + a_r + 32 * i;
+        const int m = m0 + a_r + ARS * i;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
         const int b = mm / p.OHW;
@@ -80,51 +114,68 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(const KArgs p) {
         const int oy = rem / p.OW;
         const int ox = rem - oy * p.OW;
         const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-        a_iy[i] = ok ? iy0 : -(1 << 20);  // rows past M read as zeros
-        a_ix[i] = ix0;
-        a_pix[i] = (b * p.H + iy0) * p.W + ix0;
+        const int pix0 = (b * p.H + iy0) * p.W + ix0;
+        const unsigned off = (unsigned)(pix0 * p.ldx * 4 + a_kq * 16);   // wraps for padded rows; only used on valid taps
+        if (IS1X1) {
+            a_voff[i] = ok ? off : kOutOfRange;
+            a_mask[i] = 0;
+        } else {
+            a_voff[i] = off;
+            unsigned mk = 0;
+            for (int ky = 0; ky < p.KH; ++ky)
+                for (int kx = 0; kx < p.KW; ++kx) {
+                    const bool in = ok && (unsigned)(iy0 + ky) < (unsigned)p.H && (unsigned)(ix0 + kx) < (unsigned)p.W;
+                    mk |= (in ? 1u : 0u) << (ky * p.KW + kx);
+                }
+            a_mask[i] = mk;
+        }
+    }
+    unsigned b_voff[BI];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int e = tid + NT * i;
+        const int kq = e / BN, n = e % BN;
+        b_voff[i] = (unsigned)(((kq * p.Npad) + n0 + n) * 16);
     }
 
     f32x4 ra[AI], rb[BI];
-    unsigned a_okmask = 0;
-    // Loads are unconditional (an out-of-image tap or a row past M reads pixel 0 and is zeroed
-    // when it is written to LDS): no exec-masked branches, so the 2*AI/BI loads of a chunk are
-    // issued back to back and stay in flight under the MFMAs.
+    // chunk c = (tap, 32-channel slice); the per-chunk part of every address is scalar
     auto load_chunk = [&](int c) {
-        const int tap = c / p.cpc;
-        const int c0 = (c - tap * p.cpc) * BK;
-        const int ky = tap / p.KW, kx = tap - ky * p.KW;
-        a_okmask = 0;
-#pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
-            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const long long pix = ok ? (long long)(a_pix[i] + ky * p.W + kx) : 0ll;
-            ra[i] = *reinterpret_cast<const f32x4*>(p.x + (size_t)pix * p.ldx + c0 + a_kq * 4);
-            a_okmask |= (ok ? 1u : 0u) << i;
+        const int tap = IS1X1 ? 0 : c / p.cpc;
+        const int c0 = IS1X1 ? c : c - tap * p.cpc;
+        unsigned tap_bytes = 0;
+        if (!IS1X1) {
+            const int ky = tap / p.KW, kx = tap - ky * p.KW;
+            tap_bytes = (unsigned)((ky * p.W + kx) * p.ldx * 4);
         }
+        const unsigned s_a = (unsigned)(c0 * BK * 4);
+        const unsigned s_b = (unsigned)(c * 8 * p.Npad * 16);
+        if (!TUNE_ABLATE(16)) {
 #pragma unroll
-        for (int i = 0; i < BI; ++i) {
-            const int e = tid + 256 * i;
-            const int kq = e / BN, n = e % BN;
-            rb[i] = *reinterpret_cast<const f32x4*>(p.w + ((size_t)(c * 8 + kq) * p.Npad + n0 + n) * 4);
+            for (int i = 0; i < AI; ++i) {
+                unsigned voff = a_voff[i];
+                if (!IS1X1) voff = ((a_mask[i] >> tap) & 1u) ? voff + tap_bytes : kOutOfRange;
+                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, s_a, 0));
+            }
+        }
+        if (!TUNE_ABLATE(32)) {
+#pragma unroll
+            for (int i = 0; i < BI; ++i)
+                rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, b_voff[i], s_b, 0));
         }
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            f32x4 v = ra[i];
-            if (!((a_okmask >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(&As[buf * A_STAGE + (a_r + 32 * i) * LDA + a_kq * 4]) = v;
-        }
+        for (int i = 0; i < AI; ++i)
+            *reinterpret_cast<f32x4*>(&As[buf * A_STAGE + (a_r + ARS * i) * LDA + a_kq * 4]) = ra[i];
 #pragma unroll
         for (int i = 0; i < BI; ++i)
-            *reinterpret_cast<f32x4*>(&Bs[buf * B_STAGE + (tid + 256 * i) * 4]) = rb[i];
+            *reinterpret_cast<f32x4*>(&Bs[buf * B_STAGE + (tid + NT * i) * 4]) = rb[i];
     };
 
     // ---- wave / lane coordinates -------------------------------------------------------------
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int l31 = lane & 31, hh = lane >> 5;
 
     f32x16 acc[TM][TN];
@@ -138,7 +189,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(const KArgs p) {
     // ---- epilogue coordinates (known up front so the residual can be prefetched) ------------
     constexpr int LDC = BN + 4;
     constexpr int QPR = BN / 4;         // float4 quads per tile row
-    constexpr int RPP = 256 / QPR;      // rows per pass
+    constexpr int RPP = NT / QPR;       // rows per pass
     constexpr int NP = BM / RPP;        // passes over the tile rows
     const int cq = tid % QPR, r0 = tid / QPR;
     const int n = n0 + cq * 4;
@@ -150,8 +201,8 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(const KArgs p) {
     __syncthreads();
 
     auto compute = [&](int buf) {
-        const float* Ab = As + buf * A_STAGE + (wm * (BM / 2) + l31) * LDA + hh * 4;
-        const float* Bb = Bs + buf * B_STAGE + (hh * BN + wn * (BN / 2) + l31) * 4;
+        const float* Ab = As + buf * A_STAGE + (wm * (BM / WGM) + l31) * LDA + hh * 4;
+        const float* Bb = Bs + buf * B_STAGE + (hh * BN + wn * (BN / WGN) + l31) * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 a[TM], b[TN];
@@ -172,13 +223,24 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(const KArgs p) {
     };
 
     const int last = p.nchunks - 1;
+    TUNE_T(t_loop);
     for (int c = 0; c < last; ++c) {
-        load_chunk(c + 1);          // global loads in flight under the MFMAs below
-        __builtin_amdgcn_sched_barrier(0);   // keep hipcc from sinking the loads next to their use
+        TUNE_T(t_a);
+        if (!TUNE_ABLATE(1)) load_chunk(c + 1);   // loads in flight under the MFMAs below
+        __builtin_amdgcn_sched_barrier(0);        // keep hipcc from sinking the loads next to their use
+        TUNE_T(t_b);
         compute(c & 1);
         __builtin_amdgcn_sched_barrier(0);
-        store_chunk((c + 1) & 1);
-        __syncthreads();
+        TUNE_T(t_c);
+        if (!TUNE_ABLATE(2)) {
+            store_chunk((c + 1) & 1);
+            TUNE_T(t_d);
+            __syncthreads();
+#ifdef SPECMI_TUNE
+            const long long t_e = __builtin_amdgcn_s_memtime();
+            tp[0] += t_b - t_a; tp[1] += t_c - t_b; tp[2] += t_d - t_c; tp[3] += t_e - t_d;
+#endif
+        }
     }
     // last chunk: nothing left to stage - fetch the residual rows of the epilogue under its MFMAs
     if (p.res && full) {
@@ -192,14 +254,13 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(const KArgs p) {
     __builtin_amdgcn_sched_barrier(0);
     compute(last & 1);
     __syncthreads();
+    TUNE_T(t_epi);
 
     // ---- epilogue -------------------------------------------------------------------------
     // The accumulators go through LDS once so that the HBM side is whole-row traffic: the
     // MFMA C/D layout (col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)) would give
-    // 4-byte stores at a row stride; after the transpose every lane moves 16 contiguous bytes
-    // and a wave covers 2 (BN=128) or 4 (BN=64) full output rows per instruction, for the
-    // store, the residual read and the scale/shift fetch alike.
-    // All waves have passed the loop's last barrier, so the A/B stages are free to reuse.
+    // 4-byte stores at a row stride; after the transpose every lane moves 16 contiguous bytes.
+    // All waves have passed the barrier above, so the A/B stages are free to reuse.
     float* Cs = smem;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -207,8 +268,8 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(const KArgs p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                Cs[row * LDC + wn * (BN / 2) + j * 32 + l31] = acc[i][j][r];
+                const int row = wm * (BM / WGM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                Cs[row * LDC + wn * (BN / WGN) + j * 32 + l31] = acc[i][j][r];
             }
     __syncthreads();
 
@@ -232,7 +293,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(const KArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            if (m < p.M) *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.ldo + n) = v;
+            if (m < p.M && !TUNE_ABLATE(4)) *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.ldo + n) = v;
         }
     } else {
         for (int ps = 0; ps < NP; ++ps) {
@@ -250,16 +311,32 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_f32_kernel(const KArgs p) {
             }
         }
     }
+#ifdef SPECMI_TUNE
+    if (p.tprof && (tid & 63) == 0) {
+        const long long t_end = __builtin_amdgcn_s_memtime();
+        atomicAdd(p.tprof + 0, (unsigned long long)tp[0]);
+        atomicAdd(p.tprof + 1, (unsigned long long)tp[1]);
+        atomicAdd(p.tprof + 2, (unsigned long long)tp[2]);
+        atomicAdd(p.tprof + 3, (unsigned long long)tp[3]);
+        atomicAdd(p.tprof + 4, (unsigned long long)(t_loop - t_start));
+        atomicAdd(p.tprof + 5, (unsigned long long)(t_epi - t_loop));
+        atomicAdd(p.tprof + 6, (unsigned long long)(t_end - t_epi));
+        atomicAdd(p.tprof + 7, 1ull);
+    }
+#endif
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int WGM, int WGN, bool IS1X1>
 static int launch_variant(const KArgs& k, int M, const LaunchCtx& ctx, const char* name, double flops,
                           double bytes) {
-    constexpr size_t smem = (size_t)(2 * BM * 36 + 2 * 8 * BN * 4) * sizeof(float);
+    constexpr size_t ab = (size_t)(2 * BM * 36 + 2 * 8 * BN * 4) * sizeof(float);
+    constexpr size_t cb = (size_t)BM * (BN + 4) * sizeof(float);
+    constexpr size_t smem = ab > cb ? ab : cb;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32_kernel<BM, BN>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&conv_igemm_f32_kernel<BM, BN, WGM, WGN, IS1X1>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
@@ -268,53 +345,93 @@ static int launch_variant(const KArgs& k, int M, const LaunchCtx& ctx, const cha
     const int nbm = (M + BM - 1) / BM;
     const int grid = nbm * kk.nbn;
     ProfScope ps(ctx, name, flops, bytes);
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN>), dim3(grid), dim3(256), smem, ctx.stream, kk);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WGM, WGN, IS1X1>), dim3(grid), dim3(64 * WGM * WGN), smem,
+                       ctx.stream, kk);
     return (int)hipGetLastError();
 }
 
-static int g_force_variant = 0;  // 0 auto, 1: 128x128, 2: 128x64, 3: 64x64
+#ifdef SPECMI_TUNE
+static int g_ablate = 0;
+static unsigned long long* g_tprof = nullptr;
+void conv_igemm_set_ablate(int v) { g_ablate = v; }
+void conv_igemm_set_tprof(unsigned long long* p) { g_tprof = p; }
+#endif
+static int g_force_variant = 0;  // 0 auto, 1: 128x128/4 waves, 2: 128x64/4, 3: 64x64/4, 4: 128x128/8 waves
 void conv_igemm_force_variant(int v) { g_force_variant = v; }
 
+static const char* kVariantNames[] = {"", "conv_igemm_f32<128x128,2x2>", "conv_igemm_f32<128x64,2x2>",
+                                      "conv_igemm_f32<64x64,2x2>", "conv_igemm_f32<128x128,4x2>"};
+
 static int pick_variant(int M, int Npad) {
-    if (g_force_variant == 1 && Npad % 128 == 0) return 1;
-    if (g_force_variant == 2 || g_force_variant == 3) return g_force_variant;
-    // Measured on MI355X at B=256 (profiles/): the 64x64 tile (4 workgroups = 16 waves per CU,
-    // 4 waves per SIMD sharing the 64-cycle fp32 MFMA pipe) beats 128x64 and 128x128 on every
-    // layer of the trunk: finer work quantisation over 256 CUs and better latency hiding
-    // outweigh the larger tiles' lower L2 traffic.  The bigger tiles stay selectable.
+    if (g_force_variant >= 1 && g_force_variant <= 4) {
+        const bool needs128 = (g_force_variant == 1 || g_force_variant == 4);
+        if (!needs128 || Npad % 128 == 0) return g_force_variant;
+    }
     (void)M;
     return 3;
 }
 
-const char* conv_igemm_variant(const ConvArgs& a) {
-    static const char* names[] = {"", "conv_igemm_f32<128x128>", "conv_igemm_f32<128x64>", "conv_igemm_f32<64x64>"};
-    return names[pick_variant(a.B * a.OH * a.OW, a.Npad)];
+const char* conv_igemm_variant(const ConvArgs& a) { return kVariantNames[pick_variant(a.B * a.OH * a.OW, a.Npad)]; }
+
+template <bool IS1X1>
+static int dispatch(int v, const KArgs& k, int M, const LaunchCtx& ctx, double flops, double bytes) {
+    switch (v) {
+        case 1: return launch_variant<128, 128, 2, 2, IS1X1>(k, M, ctx, kVariantNames[v], flops, bytes);
+        case 2: return launch_variant<128, 64, 2, 2, IS1X1>(k, M, ctx, kVariantNames[v], flops, bytes);
+        case 4: return launch_variant<128, 128, 4, 2, IS1X1>(k, M, ctx, kVariantNames[v], flops, bytes);
+        default: return launch_variant<64, 64, 2, 2, IS1X1>(k, M, ctx, kVariantNames[3], flops, bytes);
+    }
 }
 
-int launch_conv_igemm(const ConvArgs& a, const LaunchCtx& ctx) {
-    if (a.Cin % 32 != 0 || a.Npad % 64 != 0 || a.ldx % 4 != 0) return (int)hipErrorInvalidValue;
+static int launch_one(const ConvArgs& a, const LaunchCtx& ctx) {
     KArgs k;
     k.x = a.x; k.w = a.w; k.scale = a.scale; k.shift = a.shift; k.res = a.res; k.out = a.out;
     k.H = a.H; k.W = a.W; k.ldx = a.ldx;
     k.OW = a.OW; k.OHW = a.OH * a.OW; k.Cout = a.Cout; k.Npad = a.Npad; k.ldo = a.ldo;
-    k.KW = a.KW; k.stride = a.stride; k.pad = a.pad;
+    k.KH = a.KH; k.KW = a.KW; k.stride = a.stride; k.pad = a.pad;
     const int M = a.B * a.OH * a.OW;
     k.M = M;
     k.cpc = a.Cin / 32;
     k.nchunks = a.KH * a.KW * k.cpc;
     k.nbn = 0;
     k.relu = a.relu;
+    k.x_bytes = (unsigned)((size_t)a.B * a.H * a.W * a.ldx * 4);
+    k.w_bytes = (unsigned)((size_t)a.KH * a.KW * a.Cin * a.Npad * 4);
+#ifdef SPECMI_TUNE
+    k.ablate = g_ablate;
+    k.tprof = g_tprof;
+#endif
     k.vec_ok = (a.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0) &&
                (!a.res || (reinterpret_cast<uintptr_t>(a.res) & 15) == 0);
     const double Kd = (double)a.KH * a.KW * a.Cin;
     const double flops = 2.0 * (double)M * a.Cout * Kd;
     const double bytes = 4.0 * ((double)a.B * a.H * a.W * a.Cin + (double)M * a.Cout * (a.res ? 2.0 : 1.0) +
                                 Kd * a.Cout);
-    switch (pick_variant(M, a.Npad)) {
-        case 1: return launch_variant<128, 128>(k, M, ctx, "conv_igemm_f32<128x128>", flops, bytes);
-        case 2: return launch_variant<128, 64>(k, M, ctx, "conv_igemm_f32<128x64>", flops, bytes);
-        default: return launch_variant<64, 64>(k, M, ctx, "conv_igemm_f32<64x64>", flops, bytes);
+    const int v = pick_variant(M, a.Npad);
+    const bool is1x1 = (a.KH == 1 && a.KW == 1 && a.pad == 0);
+    return is1x1 ? dispatch<true>(v, k, M, ctx, flops, bytes) : dispatch<false>(v, k, M, ctx, flops, bytes);
+}
+
+int launch_conv_igemm(const ConvArgs& a, const LaunchCtx& ctx) {
+    if (a.Cin % 32 != 0 || a.Npad % 64 != 0 || a.ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(a.x) & 15))
+        return (int)hipErrorInvalidValue;
+    // buffer addressing is 32-bit: split the batch when the activation tensor reaches 2 GiB
+    const size_t img_bytes = (size_t)a.H * a.W * a.ldx * 4;
+    const size_t limit = (size_t)1 << 31;
+    if (img_bytes >= limit || (size_t)a.KH * a.KW * a.Cin * a.Npad * 4 >= limit) return (int)hipErrorInvalidValue;
+    const int max_b = (int)((limit - 1) / img_bytes);
+    if (a.B <= max_b) return launch_one(a, ctx);
+    for (int b0 = 0; b0 < a.B; b0 += max_b) {
+        ConvArgs s = a;
+        s.B = (a.B - b0 < max_b) ? a.B - b0 : max_b;
+        s.x = a.x + (size_t)b0 * a.H * a.W * a.ldx;
+        const size_t orow = (size_t)b0 * a.OH * a.OW * a.ldo;
+        s.out = a.out + orow;
+        if (a.res) s.res = a.res + orow;
+        const int rc = launch_one(s, ctx);
+        if (rc) return rc;
     }
+    return 0;
 }
 
 }  // namespace specmi
