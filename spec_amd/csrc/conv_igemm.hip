@@ -33,6 +33,8 @@
 //     n-fastest, so tiles sharing an A row-panel hit the same 4 MiB L2.
 //   * epilogue: accumulators are transposed through LDS so that HBM sees 16-byte,
 //     row-contiguous stores / residual reads with scale/shift/ReLU fused.
+#include <type_traits>
+
 #include "specmi_internal.h"
 
 namespace specmi {
@@ -89,6 +91,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
 #ifdef SPECMI_TUNE
     const long long t_start = __builtin_amdgcn_s_memtime();
     long long tp[4] = {0, 0, 0, 0};
+    (void)tp;
 #endif
 
     // ---- XCD-aware tile order (bijective for any grid size) ------------------------------
@@ -200,59 +203,73 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
     store_chunk(0);
     __syncthreads();
 
-    auto compute = [&](int buf) {
+    // ---- one K chunk, hand-scheduled ---------------------------------------------------------
+    // A wave issues in order, and an fp32 MFMA occupies the matrix pipe for 64 cycles while its
+    // issue takes ~4: whatever is placed BETWEEN two MFMAs in program order executes for free
+    // under the first one.  So the chunk is written as 16 steps (q, s) of TM*TN MFMAs with the
+    // other work slotted between them - next chunk's buffer loads after step 0, the fragment
+    // reads of sub-chunk q+1 inside sub-chunk q, the LDS writes of the staged next chunk in the
+    // last four steps - and sched_barrier keeps hipcc from regrouping it.
+    auto read_frags = [&](const float* Ab, const float* Bb, int q, f32x4 (&fa)[TM], f32x4 (&fb)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDA + q * 8);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bb + (q * 2 * BN + j * 32) * 4);
+    };
+    auto chunk = [&](int c, auto prefetch) {
+        constexpr bool PF = decltype(prefetch)::value;
+        const int buf = c & 1;
         const float* Ab = As + buf * A_STAGE + (wm * (BM / WGM) + l31) * LDA + hh * 4;
         const float* Bb = Bs + buf * B_STAGE + (hh * BN + wn * (BN / WGN) + l31) * 4;
+        float* Asn = As + (buf ^ 1) * A_STAGE;
+        float* Bsn = Bs + (buf ^ 1) * B_STAGE;
+        f32x4 fa[2][TM], fb[2][TN];
+        read_frags(Ab, Bb, 0, fa[0], fb[0]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            f32x4 a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDA + q * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                b[j] = *reinterpret_cast<const f32x4*>(Bb + (q * 2 * BN + j * 32) * 4);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1][i][s], fb[q & 1][j][s], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q == 0 && s == 0) {
+                    if (PF) {
+                        if (!TUNE_ABLATE(1)) load_chunk(c + 1);
+                    } else if (p.res && full) {   // last chunk: fetch the residual rows of the epilogue
+#pragma unroll
+                        for (int ps = 0; ps < NP; ++ps) {
+                            const int m = m0 + r0 + ps * RPP;
+                            const size_t o = (m < p.M) ? (size_t)m * p.ldo + n : (size_t)n;
+                            rr[ps] = *reinterpret_cast<const f32x4*>(p.res + o);
+                        }
+                    }
+                }
+                if (s == 1 && q < 3) read_frags(Ab, Bb, q + 1, fa[(q + 1) & 1], fb[(q + 1) & 1]);
+                if (PF && q == 3 && !TUNE_ABLATE(2)) {   // stage the next chunk: stores spread over the last 4 steps
+#pragma unroll
+                    for (int t = 0; t < AI + BI; ++t) {
+                        if ((t & 3) != s) continue;
+                        if (t < AI)
+                            *reinterpret_cast<f32x4*>(&Asn[(a_r + ARS * t) * LDA + a_kq * 4]) = ra[t];
+                        else
+                            *reinterpret_cast<f32x4*>(&Bsn[(tid + NT * (t - AI)) * 4]) = rb[t - AI];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
 
     const int last = p.nchunks - 1;
     TUNE_T(t_loop);
     for (int c = 0; c < last; ++c) {
-        TUNE_T(t_a);
-        if (!TUNE_ABLATE(1)) load_chunk(c + 1);   // loads in flight under the MFMAs below
-        __builtin_amdgcn_sched_barrier(0);        // keep hipcc from sinking the loads next to their use
-        TUNE_T(t_b);
-        compute(c & 1);
-        __builtin_amdgcn_sched_barrier(0);
-        TUNE_T(t_c);
-        if (!TUNE_ABLATE(2)) {
-            store_chunk((c + 1) & 1);
-            TUNE_T(t_d);
-            __syncthreads();
-#ifdef SPECMI_TUNE
-            const long long t_e = __builtin_amdgcn_s_memtime();
-            tp[0] += t_b - t_a; tp[1] += t_c - t_b; tp[2] += t_d - t_c; tp[3] += t_e - t_d;
-#endif
-        }
+        chunk(c, std::true_type{});
+        __syncthreads();
     }
-    // last chunk: nothing left to stage - fetch the residual rows of the epilogue under its MFMAs
-    if (p.res && full) {
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps) {
-            const int m = m0 + r0 + ps * RPP;
-            const size_t o = (m < p.M) ? (size_t)m * p.ldo + n : (size_t)n;
-            rr[ps] = *reinterpret_cast<const f32x4*>(p.res + o);
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    compute(last & 1);
+    chunk(last, std::false_type{});
     __syncthreads();
     TUNE_T(t_epi);
 
