@@ -64,6 +64,17 @@ def make_inputs(B, device, seed):
     return x, scale, center, img_w, img_h
 
 
+def pmc_traffic():
+    """HBM bytes per conv launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs,
+    gfx950-corrected by scripts/rocprof_summary.py); None when no summary is committed."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic_latest.json')
+    try:
+        with open(path) as f:
+            return json.load(f).get('traffic_bytes_per_launch')
+    except Exception:
+        return None
+
+
 def roofline_from_profile(entries):
     conv = [e for e in entries if e['kernel'].startswith('conv_igemm_f32')]
     ms = sum(e['ms'] for e in conv)
@@ -74,7 +85,9 @@ def roofline_from_profile(entries):
     ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     return {
         'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+        'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(),
+        'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/pmc_traffic_latest.json)',
+        'algorithmic_bytes_per_launch': round(by / max(n, 1)),
         'kernel': 'conv_igemm_f32 (all tile variants)', 'launches_per_step': n,
         'avg_launch_ms': round(ms / max(n, 1), 4),
         'algorithmic_gflop_per_launch': round(fl / max(n, 1) / 1e9, 3),

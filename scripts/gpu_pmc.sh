@@ -21,6 +21,8 @@ pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum
 cd $R
+python scripts/rocprof_summary.py traffic $(find $OUT/pmc_${TAG}_fetch $OUT/pmc_${TAG}_write -name "*.db") > $OUT/pmc_${TAG}_traffic.json 2>&1
+cat $OUT/pmc_${TAG}_traffic.json
 : > $OUT/pmc_${TAG}_summary.txt
 for d in $OUT/pmc_${TAG}_*/; do
   for db in $(find $d -name "*.db"); do python scripts/rocprof_summary.py pmc $db >> $OUT/pmc_${TAG}_summary.txt 2>&1; done

@@ -379,16 +379,23 @@ void conv_igemm_force_variant(int v) { g_force_variant = v; }
 static const char* kVariantNames[] = {"", "conv_igemm_f32<128x128,2x2>", "conv_igemm_f32<128x64,2x2>",
                                       "conv_igemm_f32<64x64,2x2>", "conv_igemm_f32<128x128,4x2>"};
 
-static int pick_variant(int M, int Npad) {
+static int pick_variant(int M, int Npad, bool is1x1) {
     if (g_force_variant >= 1 && g_force_variant <= 4) {
         const bool needs128 = (g_force_variant == 1 || g_force_variant == 4);
         if (!needs128 || Npad % 128 == 0) return g_force_variant;
     }
-    (void)M;
+    // Measured on MI355X at B=256 (tools/igemm_bench, profiles/): the 64x64 tile (4 workgroups =
+    // 16 waves per CU sharing the 64-cycle fp32 MFMA pipe) wins on the 3x3 and the small-M layers
+    // (finer work quantisation over 256 CUs); the 8-wave 128x128 tile halves the L2->LDS traffic
+    // and wins by 5-10 % on the large-M 1x1 layers that sit near the HBM roofline
+    // (layer1/layer2 expand convs with their residual, layer2.0 reduce/downsample).
+    if (is1x1 && Npad % 128 == 0 && M >= 131072) return 4;
     return 3;
 }
 
-const char* conv_igemm_variant(const ConvArgs& a) { return kVariantNames[pick_variant(a.B * a.OH * a.OW, a.Npad)]; }
+const char* conv_igemm_variant(const ConvArgs& a) {
+    return kVariantNames[pick_variant(a.B * a.OH * a.OW, a.Npad, a.KH == 1 && a.KW == 1 && a.pad == 0)];
+}
 
 template <bool IS1X1>
 static int dispatch(int v, const KArgs& k, int M, const LaunchCtx& ctx, double flops, double bytes) {
@@ -424,8 +431,8 @@ static int launch_one(const ConvArgs& a, const LaunchCtx& ctx) {
     const double flops = 2.0 * (double)M * a.Cout * Kd;
     const double bytes = 4.0 * ((double)a.B * a.H * a.W * a.Cin + (double)M * a.Cout * (a.res ? 2.0 : 1.0) +
                                 Kd * a.Cout);
-    const int v = pick_variant(M, a.Npad);
     const bool is1x1 = (a.KH == 1 && a.KW == 1 && a.pad == 0);
+    const int v = pick_variant(M, a.Npad, is1x1);
     return is1x1 ? dispatch<true>(v, k, M, ctx, flops, bytes) : dispatch<false>(v, k, M, ctx, flops, bytes);
 }
 
