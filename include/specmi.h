@@ -173,6 +173,22 @@ int specmi_maxpool3x3s2(specmi_handle* h, const float* x, int B, int H, int W, i
 int specmi_avgpool(specmi_handle* h, const float* x, int B, int HW, int C, float* out,
                    void* stream);
 
+/* ---- evaluation metrics on the path's outputs ---------------------------------- */
+
+/* eval_single (spec/utils/compute_error.py:52-86, spec/trainer.py:272-316): joints =
+ * J_regressor (J,V) @ vertices for prediction and ground truth, pelvis (joint 0) alignment,
+ * selection of `nsel` joints (`joint_sel` device int32, NULL = the first nsel), then per image
+ * MPJPE, PA-MPJPE (similarity Procrustes) and pelvis-aligned V2V, all in millimetres.  All
+ * pointers are device pointers; any output may be NULL.  J, nsel <= 32. */
+int specmi_eval_mesh(specmi_handle* h, const float* pred_vertices, const float* gt_vertices, int B,
+                     int V, const float* J_regressor, int J, const int32_t* joint_sel, int nsel,
+                     float* mpjpe_mm, float* pampjpe_mm, float* v2v_mm, void* stream);
+
+/* eval_j_24 (spec/utils/compute_error.py:33-49): pelvis-aligned MPJPE / PA-MPJPE (mm) of two
+ * (B,J,3) joint sets. */
+int specmi_eval_joints(specmi_handle* h, const float* pred_joints, const float* gt_joints, int B,
+                       int J, float* mpjpe_mm, float* pampjpe_mm, void* stream);
+
 /* ---- profiling -------------------------------------------------------------------------- */
 
 /* When on, every kernel launch is bracketed by HIP events on the launch stream. */

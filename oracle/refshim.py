@@ -47,6 +47,16 @@ def install(reference_root='/root/reference'):
     softargmax = _mod('pare.models.layers.softargmax', softargmax1d=geometry.softargmax1d)
     utils = _mod('pare.utils')
     train_utils = _mod('pare.utils.train_utils', load_pretrained_model=lambda *a, **k: None)
+    from . import metrics as _metrics
+    _mod('pare.utils.eval_utils', compute_error_verts=_metrics.compute_error_verts,
+         reconstruction_error=_metrics.reconstruction_error)
+    _mod('pare.core')
+    _mod('pare.core.constants', H36M_TO_J14=list(_metrics.H36M_TO_J14))
+    _mod('smplx', SMPL=object)
+    try:
+        import tqdm  # noqa: F401
+    except Exception:
+        _mod('tqdm', tqdm=lambda x, **k: x)
     geom = _mod('pare.utils.geometry', batch_euler2matrix=geometry.batch_euler2matrix,
                 rot6d_to_rotmat=geometry.rot6d_to_rotmat, rotmat_to_rot6d=geometry.rotmat_to_rot6d)
     pare.models, pare.utils = models, utils
@@ -73,6 +83,9 @@ def import_reference(reference_root='/root/reference'):
     mods['cam_utils'] = importlib.import_module('camcalib.cam_utils')
     mods['cam_params'] = importlib.import_module('spec.utils.cam_params')
     mods['constants'] = importlib.import_module('spec.constants')
+    # spec/utils/compute_error.py does `from ..config import ...` (yacs-based, not importable here)
+    _mod('spec.config', DATASET_FILES=[{}, {}], SMPL_MODEL_DIR='')
+    mods['compute_error'] = importlib.import_module('spec.utils.compute_error')
     for m in mods.values():
         assert m.__file__.startswith(reference_root), m.__file__
     return mods

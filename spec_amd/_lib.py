@@ -71,6 +71,10 @@ PROTOTYPES = {
                                       C.c_void_p, C.c_void_p]),
     'specmi_avgpool': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                  C.c_void_p]),
+    'specmi_eval_mesh': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                   C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'specmi_eval_joints': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
     'specmi_profile_enable': (C.c_int, [C.c_void_p, C.c_int]),
     'specmi_profile_read': (C.c_int, [C.c_void_p, C.POINTER(ProfEntry), C.c_int, C.POINTER(C.c_int)]),
 }

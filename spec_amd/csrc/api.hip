@@ -765,6 +765,26 @@ int specmi_avgpool(specmi_handle* h, const float* x, int B, int HW, int C, float
     return SPECMI_OK;
 }
 
+int specmi_eval_mesh(specmi_handle* h, const float* pred, const float* gt, int B, int V, const float* Jr, int J,
+                     const int32_t* sel, int nsel, float* mpjpe, float* pampjpe, float* v2v, void* stream) {
+    ENTER(h);
+    if (!pred || !gt || !Jr || B <= 0 || V <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
+    if (J < 1 || J > 32 || nsel < 1 || nsel > 32) return fail(h, SPECMI_ERR_ARG, "J and nsel must be in [1,32]");
+    LaunchCtx ctx{(hipStream_t)stream, &h->prof, "eval.mesh"};
+    LAUNCHCHK(h, launch_eval_mesh(pred, gt, B, V, Jr, J, sel, nsel, mpjpe, pampjpe, v2v, ctx), "eval_mesh");
+    return SPECMI_OK;
+}
+
+int specmi_eval_joints(specmi_handle* h, const float* pred, const float* gt, int B, int J, float* mpjpe, float* pampjpe,
+                       void* stream) {
+    ENTER(h);
+    if (!pred || !gt || B <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
+    if (J < 1 || J > 32) return fail(h, SPECMI_ERR_ARG, "J must be in [1,32]");
+    LaunchCtx ctx{(hipStream_t)stream, &h->prof, "eval.joints"};
+    LAUNCHCHK(h, launch_eval_joints(pred, gt, B, J, mpjpe, pampjpe, ctx), "eval_joints");
+    return SPECMI_OK;
+}
+
 int specmi_profile_enable(specmi_handle* h, int on) {
     if (!h) return SPECMI_ERR_ARG;
     h->prof.on = on != 0;

@@ -144,4 +144,12 @@ struct SmplArgs {
 };
 int launch_smpl(const SmplDev& m, const SmplArgs& a, const LaunchCtx& ctx);
 
+// ----------------------------------------------------------------------------------------
+// evaluation metrics  (eval.hip)
+// ----------------------------------------------------------------------------------------
+int launch_eval_mesh(const float* pred, const float* gt, int B, int V, const float* Jr, int J, const int* sel, int nsel,
+                     float* mpjpe, float* pampjpe, float* v2v, const LaunchCtx& ctx);
+int launch_eval_joints(const float* pred, const float* gt, int B, int J, float* mpjpe, float* pampjpe,
+                       const LaunchCtx& ctx);
+
 }  // namespace specmi

@@ -204,6 +204,13 @@ def smpl_model(seed: int = 1003, nv: int = C.NUM_SMPL_VERTS):
     return m
 
 
+def h36m_regressor(seed: int = 1003, nv: int = C.NUM_SMPL_VERTS) -> np.ndarray:
+    """A synthetic 17-row joint regressor standing in for ``data/J_regressor_h36m.npy``
+    (used by the evaluation metrics, spec/trainer.py:96-99,272-279): rows sum to 1."""
+    J = smpl_model(seed, nv)['J_regressor']
+    return np.concatenate([J[:12], J[12:17] * 0.5 + J[17:22] * 0.5], 0).astype(np.float32)
+
+
 # --------------------------------------------------------------------------------------
 # inputs
 # --------------------------------------------------------------------------------------

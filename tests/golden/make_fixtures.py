@@ -143,6 +143,22 @@ def main():
             **{f'out_{k}': v.numpy() for k, v in out.items()})
         print(tag, {k: tuple(v.shape) for k, v in out.items()})
 
+    # ---- (6) evaluation metrics through the reference's spec/utils/compute_error.py ---------
+    CE = ref['compute_error']
+    Bm, V = 5, 6890
+    rng_seed = 4242
+    Jh36m = synth.smpl_model(SEED_SMPL)['J_regressor']            # (24,V) rows sum to 1
+    J17 = synth.h36m_regressor(SEED_SMPL)                         # a 17-row regressor
+    gt_v = synth.normal(rng_seed, 'gt_verts', (Bm, V, 3), std=0.3)
+    pr_v = gt_v + synth.normal(rng_seed, 'noise', (Bm, V, 3), std=0.03) + synth.normal(rng_seed, 'shift', (Bm, 1, 3), std=0.2)
+    Jb = t(J17)[None].expand(Bm, -1, -1)
+    mpjpe, pampjpe, v2v = CE.eval_single(t(pr_v), t(gt_v), Jb)
+    pj = torch.einsum('bik,ji->bjk', t(pr_v), t(Jh36m))
+    gj = torch.einsum('bik,ji->bjk', t(gt_v), t(Jh36m))
+    mpjpe24, pampjpe24 = CE.eval_j_24(pj, gj)
+    np.savez(os.path.join(OUT, 'metrics.npz'), seed=rng_seed, batch=Bm, seed_smpl=SEED_SMPL,
+             mpjpe=mpjpe, pampjpe=pampjpe, v2v=v2v, mpjpe24=mpjpe24, pampjpe24=pampjpe24)
+
     sz = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith('.npz'))
     print('fixtures written, total bytes', sz)
 

@@ -55,3 +55,21 @@ def test_hmr_matches_reference_composition(tag, use_cam, ucf):
         assert np.array_equal(out[k].numpy(), g[f'out_{k}']), k
     own = [k for k in hm.state_dict().keys()]
     assert own == list(g['state_keys'])
+
+
+def test_metrics_match_reference_compute_error():
+    """oracle/metrics.py against spec/utils/compute_error.py (eval_single, eval_j_24) run in the
+    build container (tests/golden/metrics.npz)."""
+    from oracle import metrics as M
+    g = golden('metrics.npz')
+    Bm, seed, V = int(g['batch']), int(g['seed']), 6890
+    J24 = synth.smpl_model(int(g['seed_smpl']))['J_regressor']
+    J17 = synth.h36m_regressor(int(g['seed_smpl']))
+    gt_v = synth.normal(seed, 'gt_verts', (Bm, V, 3), std=0.3)
+    pr_v = gt_v + synth.normal(seed, 'noise', (Bm, V, 3), std=0.03) + synth.normal(seed, 'shift', (Bm, 1, 3), std=0.2)
+    mp, pa, vv = M.eval_single(t(pr_v), t(gt_v), t(J17)[None].expand(Bm, -1, -1))
+    assert np.array_equal(mp, g['mpjpe']) and np.array_equal(pa, g['pampjpe']) and np.array_equal(vv, g['v2v'])
+    pj = torch.einsum('bik,ji->bjk', t(pr_v), t(J24))
+    gj = torch.einsum('bik,ji->bjk', t(gt_v), t(J24))
+    mp24, pa24 = M.eval_j_24(pj, gj)
+    assert np.array_equal(mp24, g['mpjpe24']) and np.array_equal(pa24, g['pampjpe24'])
