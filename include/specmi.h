@@ -173,6 +173,18 @@ int specmi_maxpool3x3s2(specmi_handle* h, const float* x, int B, int H, int W, i
 int specmi_avgpool(specmi_handle* h, const float* x, int B, int HW, int C, float* out,
                    void* stream);
 
+/* ---- crop + normalise in front of the path ------------------------------------ */
+
+/* The detection loop of spec/tester.py:116-128: for each bbox (cx, cy, w, h) [device, (n,4)]
+ * get_single_image_crop_demo(frame, bbox, scale, crop_size) - 3-point affine (rot 0) +
+ * cv2.warpAffine(INTER_LINEAR, BORDER_CONSTANT) fixed-point bilinear + ToTensor + ImageNet
+ * Normalize (spec/constants.py:20-21) - from a uint8 RGB HWC frame in device memory to
+ * (n,3,S,S) fp32 NCHW.  Optional outputs: raw (n,S,S,3) uint8 crop, bbox_scale = w/200 (n),
+ * bbox_center (n,2). */
+int specmi_crop_normalize(specmi_handle* h, const uint8_t* frame_rgb_hwc, int H, int W,
+                          const float* bboxes, int n, float scale, int crop_size, float* out_nchw,
+                          uint8_t* raw_hwc, float* bbox_scale, float* bbox_center, void* stream);
+
 /* ---- evaluation metrics on the path's outputs ---------------------------------- */
 
 /* eval_single (spec/utils/compute_error.py:52-86, spec/trainer.py:272-316): joints =

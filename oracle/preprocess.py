@@ -1,0 +1,129 @@
+"""Oracle (test infrastructure): the crop + normalise step that feeds the hot path
+(``spec/tester.py:116-128``: ``get_single_image_crop_demo(img, bbox, kp_2d=None, scale=1.0,
+crop_size=224)`` per detection, then ``bbox_scale = bbox[2]/200``, ``bbox_center = bbox[:2]``).
+
+``get_single_image_crop_demo`` lives in the un-vendored ``pare.utils.vibe_image_utils`` and is
+a thin wrapper over OpenCV (``cv2.getAffineTransform`` + ``cv2.warpAffine(INTER_LINEAR,
+BORDER_CONSTANT)``) followed by torchvision ``ToTensor`` + ``Normalize``.  Neither ``pare`` nor
+``cv2`` is installed here, so this is a NumPy restatement of the published algorithms -
+**parity unpinned** against the real OpenCV binary:
+
+* ``gen_trans_from_patch`` - the 3-point affine of VIBE/PARE for rot = 0 (axis aligned);
+* ``warp_affine_linear_u8`` - OpenCV's fixed-point bilinear warp: inverse map in float64,
+  coordinates in 1/1024 px (AB_BITS = 10) rounded to 1/32 px (INTER_BITS = 5), 15-bit weight
+  table whose four entries sum to 32768, result (sum + 2^14) >> 15;
+* ToTensor / Normalize in float32: ``(u8 / 255 - mean) / std``.
+"""
+import numpy as np
+
+INTER_BITS = 5
+INTER_TAB_SIZE = 1 << INTER_BITS
+AB_BITS = 10
+AB_SCALE = 1 << AB_BITS
+REMAP_COEF_BITS = 15
+REMAP_COEF_SCALE = 1 << REMAP_COEF_BITS
+
+MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32)   # spec/constants.py:20
+STD = np.array([0.229, 0.224, 0.225], dtype=np.float32)    # spec/constants.py:21
+
+
+def gen_trans_from_patch(c_x, c_y, src_w, src_h, dst_w, dst_h, scale):
+    """2x3 forward affine (src -> dst) for rot = 0: the three point pairs are centre, centre +
+    (0, h/2), centre + (w/2, 0), with the half extents rounded to float32 as upstream does."""
+    sw = np.float32(np.float32(src_w * scale) * np.float32(0.5))
+    sh = np.float32(np.float32(src_h * scale) * np.float32(0.5))
+    cx, cy = np.float32(c_x), np.float32(c_y)
+    ax = np.float64(np.float32(dst_w * 0.5)) / np.float64(sw)
+    ay = np.float64(np.float32(dst_h * 0.5)) / np.float64(sh)
+    return np.array([[ax, 0.0, np.float64(np.float32(dst_w * 0.5)) - ax * np.float64(cx)],
+                     [0.0, ay, np.float64(np.float32(dst_h * 0.5)) - ay * np.float64(cy)]], dtype=np.float64)
+
+
+def _bilinear_tab():
+    """OpenCV's INTER_LINEAR fixed-point table: [32*32][4] int weights summing to 32768."""
+    tab = np.zeros((INTER_TAB_SIZE * INTER_TAB_SIZE, 4), dtype=np.int32)
+    for iy in range(INTER_TAB_SIZE):
+        fy = np.float32(iy) / np.float32(INTER_TAB_SIZE)
+        for ix in range(INTER_TAB_SIZE):
+            fx = np.float32(ix) / np.float32(INTER_TAB_SIZE)
+            w = np.array([(np.float32(1) - fx) * (np.float32(1) - fy), fx * (np.float32(1) - fy),
+                          (np.float32(1) - fx) * fy, fx * fy], dtype=np.float32)
+            iw = np.rint(w * np.float32(REMAP_COEF_SCALE)).astype(np.int32)      # saturate_cast<short> = round half even
+            diff = int(iw.sum()) - REMAP_COEF_SCALE
+            if diff != 0:   # OpenCV: a deficit goes to the largest entry, an excess comes off the smallest
+                k = int(np.argmax(iw)) if diff < 0 else int(np.argmin(iw))   # (never taken for 5-bit bilinear:
+                iw[k] -= diff                                                 #  the products are exact)
+            tab[iy * INTER_TAB_SIZE + ix] = iw
+    return tab
+
+
+BILINEAR_TAB = _bilinear_tab()
+
+
+def invert_affine(M):
+    """cv::warpAffine's in-place inversion of the 2x3 matrix (float64)."""
+    M = np.array(M, dtype=np.float64)
+    D = M[0, 0] * M[1, 1] - M[0, 1] * M[1, 0]
+    D = 1.0 / D if D != 0 else 0.0
+    A11, A22 = M[1, 1] * D, M[0, 0] * D
+    M[0, 0], M[0, 1], M[1, 0], M[1, 1] = A11, M[0, 1] * -D, M[1, 0] * -D, A22
+    b1 = -M[0, 0] * M[0, 2] - M[0, 1] * M[1, 2]
+    b2 = -M[1, 0] * M[0, 2] - M[1, 1] * M[1, 2]
+    M[0, 2], M[1, 2] = b1, b2
+    return M
+
+
+def _sat_int(x):
+    return np.rint(x).astype(np.int64)           # saturate_cast<int>(double) = lrint (round half even)
+
+
+def warp_affine_linear_u8(img, M, dst_w, dst_h):
+    """cv2.warpAffine(img, M, (dst_w, dst_h), flags=INTER_LINEAR, borderMode=BORDER_CONSTANT (0))."""
+    H, W, C = img.shape
+    Mi = invert_affine(M)
+    x = np.arange(dst_w)
+    adelta = _sat_int(Mi[0, 0] * x * AB_SCALE)
+    bdelta = _sat_int(Mi[1, 0] * x * AB_SCALE)
+    round_delta = AB_SCALE // INTER_TAB_SIZE // 2
+    out = np.zeros((dst_h, dst_w, C), dtype=np.uint8)
+    src = img.astype(np.int64)
+    for y in range(dst_h):
+        X0 = _sat_int((Mi[0, 1] * y + Mi[0, 2]) * AB_SCALE) + round_delta
+        Y0 = _sat_int((Mi[1, 1] * y + Mi[1, 2]) * AB_SCALE) + round_delta
+        X = (X0 + adelta) >> (AB_BITS - INTER_BITS)
+        Y = (Y0 + bdelta) >> (AB_BITS - INTER_BITS)
+        sx, sy = X >> INTER_BITS, Y >> INTER_BITS
+        w = BILINEAR_TAB[(Y & (INTER_TAB_SIZE - 1)) * INTER_TAB_SIZE + (X & (INTER_TAB_SIZE - 1))]   # (dst_w,4)
+
+        def tap(yy, xx):
+            ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)
+            v = src[np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)]
+            return np.where(ok[:, None], v, 0)
+        acc = (tap(sy, sx) * w[:, 0:1] + tap(sy, sx + 1) * w[:, 1:2] + tap(sy + 1, sx) * w[:, 2:3]
+               + tap(sy + 1, sx + 1) * w[:, 3:4])
+        out[y] = np.clip((acc + (1 << (REMAP_COEF_BITS - 1))) >> REMAP_COEF_BITS, 0, 255).astype(np.uint8)
+    return out
+
+
+def to_tensor_normalize(img_u8):
+    x = img_u8.astype(np.float32) / np.float32(255.0)
+    x = (x - MEAN) / STD
+    return np.ascontiguousarray(x.transpose(2, 0, 1)).astype(np.float32)
+
+
+def get_single_image_crop_demo(image, bbox, scale=1.0, crop_size=224):
+    """-> (norm_img (3,S,S) float32, raw_img (S,S,3) uint8)."""
+    M = gen_trans_from_patch(bbox[0], bbox[1], bbox[2], bbox[3], crop_size, crop_size, scale)
+    raw = warp_affine_linear_u8(image, M, crop_size, crop_size)
+    return to_tensor_normalize(raw), raw
+
+
+def crop_detections(image, dets, scale=1.0, crop_size=224):
+    """The per-detection loop of spec/tester.py:116-128 -> inp_images, raw, bbox_scale, bbox_center."""
+    imgs, raws, sc, ce = [], [], [], []
+    for bbox in dets:
+        n, r = get_single_image_crop_demo(image, bbox, scale, crop_size)
+        imgs.append(n); raws.append(r)
+        sc.append(np.float32(bbox[2] / 200.))
+        ce.append([np.float32(bbox[0]), np.float32(bbox[1])])
+    return np.stack(imgs), np.stack(raws), np.array(sc, np.float32), np.array(ce, np.float32)

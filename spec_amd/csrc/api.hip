@@ -765,6 +765,17 @@ int specmi_avgpool(specmi_handle* h, const float* x, int B, int HW, int C, float
     return SPECMI_OK;
 }
 
+int specmi_crop_normalize(specmi_handle* h, const uint8_t* frame, int H, int W, const float* bboxes, int n, float scale,
+                          int crop_size, float* out, uint8_t* raw, float* bbox_scale, float* bbox_center, void* stream) {
+    ENTER(h);
+    if (!frame || !bboxes || !out || H <= 0 || W <= 0 || n <= 0 || crop_size <= 0 || !(scale > 0.f))
+        return fail(h, SPECMI_ERR_ARG, "bad argument");
+    LaunchCtx ctx{(hipStream_t)stream, &h->prof, "preprocess.crop"};
+    LAUNCHCHK(h, launch_crop_normalize(frame, H, W, bboxes, n, scale, crop_size, out, raw, bbox_scale, bbox_center, ctx),
+              "crop_normalize");
+    return SPECMI_OK;
+}
+
 int specmi_eval_mesh(specmi_handle* h, const float* pred, const float* gt, int B, int V, const float* Jr, int J,
                      const int32_t* sel, int nsel, float* mpjpe, float* pampjpe, float* v2v, void* stream) {
     ENTER(h);

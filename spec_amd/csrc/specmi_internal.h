@@ -152,4 +152,10 @@ int launch_eval_mesh(const float* pred, const float* gt, int B, int V, const flo
 int launch_eval_joints(const float* pred, const float* gt, int B, int J, float* mpjpe, float* pampjpe,
                        const LaunchCtx& ctx);
 
+// ----------------------------------------------------------------------------------------
+// crop + normalise  (preprocess.hip)
+// ----------------------------------------------------------------------------------------
+int launch_crop_normalize(const unsigned char* frame, int H, int W, const float* bboxes, int n, float scale, int S,
+                          float* out, unsigned char* raw, float* bbox_scale, float* bbox_center, const LaunchCtx& ctx);
+
 }  // namespace specmi

@@ -1,0 +1,37 @@
+"""Crop + normalise on the device: the detection loop of ``spec/tester.py:116-128``
+(``get_single_image_crop_demo`` per bbox, ``bbox_scale = bbox[2]/200``, ``bbox_center``) as one
+HIP launch (``specmi_crop_normalize``) from a uint8 RGB frame that already sits in HBM."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .cam_utils import _engine
+from .engine import _dev_f32, _ptr
+
+
+@torch.no_grad()
+def crop_detections(frame_rgb_u8, dets, scale: float = 1.0, crop_size: int = 224, return_raw: bool = False):
+    """frame (H,W,3) uint8 device tensor, dets (n,4) [cx, cy, w, h] ->
+    dict(inp_images (n,3,S,S) fp32, bbox_scale (n,), bbox_center (n,2)[, raw (n,S,S,3) uint8])."""
+    if not isinstance(frame_rgb_u8, torch.Tensor) or frame_rgb_u8.device.type != 'cuda':
+        raise RuntimeError('crop_detections needs a device tensor (no CPU path in spec_amd)')
+    if frame_rgb_u8.dtype != torch.uint8 or frame_rgb_u8.dim() != 3 or frame_rgb_u8.shape[2] != 3:
+        raise ValueError('frame must be (H,W,3) uint8 RGB')
+    eng = _engine(frame_rgb_u8.device)
+    dev = eng.device
+    frame = frame_rgb_u8.contiguous()
+    boxes = _dev_f32(dets, dev)
+    if boxes.dim() != 2 or boxes.shape[1] != 4:
+        raise ValueError('dets must be (n,4) [cx, cy, w, h]')
+    n, (H, W) = boxes.shape[0], frame.shape[:2]
+    out = torch.empty(n, 3, crop_size, crop_size, device=dev, dtype=torch.float32)
+    raw = torch.empty(n, crop_size, crop_size, 3, device=dev, dtype=torch.uint8) if return_raw else None
+    sc = torch.empty(n, device=dev, dtype=torch.float32)
+    ce = torch.empty(n, 2, device=dev, dtype=torch.float32)
+    _lib.check(eng.h, eng.lib.specmi_crop_normalize(eng.h, _ptr(frame), H, W, _ptr(boxes), n, float(scale), crop_size,
+                                                    _ptr(out), _ptr(raw), _ptr(sc), _ptr(ce), eng._stream()))
+    res = {'inp_images': out, 'bbox_scale': sc, 'bbox_center': ce}
+    if return_raw:
+        res['raw'] = raw
+    return res

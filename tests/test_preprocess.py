@@ -1,0 +1,77 @@
+"""Crop + normalise: oracle KATs on CPU, bit-exact GPU parity through the C ABI."""
+import numpy as np
+import pytest
+import torch
+from scipy import ndimage
+
+from oracle import preprocess as P
+from tests.util import t
+
+
+def _frame(seed, H=180, W=260):
+    rng = np.random.default_rng(seed)
+    img = rng.random((H, W, 3)) * 255
+    return ndimage.uniform_filter(img, size=(5, 5, 1)).astype(np.uint8)
+
+
+def test_oracle_identity_crop_is_exact_copy():
+    img = _frame(1, 300, 300)
+    # a 224x224 box centred so that dst pixel u maps to src pixel u + 20: cx - 112 = 20
+    norm, raw = P.get_single_image_crop_demo(img, [132.0, 142.0, 224.0, 224.0], 1.0, 224)
+    assert np.array_equal(raw, img[30:254, 20:244])
+    ref = ((raw.astype(np.float32) / np.float32(255) - P.MEAN) / P.STD).transpose(2, 0, 1)
+    assert np.array_equal(norm, ref)
+
+
+def test_oracle_close_to_float_bilinear_and_zero_border():
+    img = _frame(2)
+    bbox = [40.3, 35.7, 150.0, 150.0]              # sticks out of the frame on the left/top
+    M = P.gen_trans_from_patch(*bbox, 224, 224, 1.0)
+    Mi = P.invert_affine(M)
+    raw = P.warp_affine_linear_u8(img, M, 224, 224)
+    ys, xs = np.mgrid[0:224, 0:224]
+    sx, sy = Mi[0, 0] * xs + Mi[0, 2], Mi[1, 1] * ys + Mi[1, 2]
+    ref = np.stack([ndimage.map_coordinates(img[..., c].astype(np.float64), [sy, sx], order=1, mode='constant')
+                    for c in range(3)], -1)
+    assert np.abs(ref - raw).max() < 1.6           # cv2's 1/32-px, 15-bit fixed point vs exact bilinear
+    assert np.all(raw[:30, :10] == 0)              # BORDER_CONSTANT
+    assert P.BILINEAR_TAB.sum(1).min() == 32768 and P.BILINEAR_TAB.sum(1).max() == 32768
+
+
+def test_oracle_detection_loop_contract():
+    img = _frame(3)
+    dets = np.array([[130.0, 90.0, 120.0, 120.0], [60.5, 70.25, 80.0, 80.0]], np.float32)
+    imgs, raws, sc, ce = P.crop_detections(img, dets)
+    assert imgs.shape == (2, 3, 224, 224) and raws.shape == (2, 224, 224, 3) and imgs.dtype == np.float32
+    assert np.array_equal(sc, dets[:, 2] / np.float32(200)) and np.array_equal(ce, dets[:, :2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('H,W', [(180, 260), (480, 640), (97, 131)])
+def test_gpu_crop_bit_exact(H, W):
+    from spec_amd.preprocess import crop_detections
+    img = _frame(H, H, W)
+    rng = np.random.default_rng(W)
+    n = 7
+    dets = np.stack([rng.uniform(0.1 * W, 0.9 * W, n), rng.uniform(0.1 * H, 0.9 * H, n),
+                     rng.uniform(40, 1.2 * H, n), np.zeros(n)], 1).astype(np.float32)
+    dets[:, 3] = dets[:, 2]                        # square boxes as the tracker emits
+    dets[0] = [W / 2, H / 2, 2.5 * W, 2.5 * W]     # far larger than the frame
+    dets[1] = [3.0, 2.0, 60.0, 60.0]               # mostly outside
+    for scale in (1.0, 1.1):
+        ref_imgs, ref_raw, ref_sc, ref_ce = P.crop_detections(img, dets, scale)
+        out = crop_detections(t(img).to('cuda:0'), t(dets).to('cuda:0'), scale=scale, return_raw=True)
+        assert np.array_equal(out['raw'].cpu().numpy(), ref_raw)
+        assert np.array_equal(out['inp_images'].cpu().numpy(), ref_imgs)
+        assert np.array_equal(out['bbox_scale'].cpu().numpy(), ref_sc)
+        assert np.array_equal(out['bbox_center'].cpu().numpy(), ref_ce)
+
+
+@pytest.mark.gpu
+def test_gpu_crop_feeds_hmr():
+    """The cropped batch goes straight into the trunk (same dtype/layout the tester builds)."""
+    from spec_amd.preprocess import crop_detections
+    out = crop_detections(t(_frame(9)).to('cuda:0'), torch.tensor([[130., 90., 120., 120.]]))
+    x = out['inp_images']
+    assert x.shape == (1, 3, 224, 224) and x.dtype == torch.float32 and x.is_contiguous()
+    assert float(x.max()) <= (1 - 0.406) / 0.225 + 1e-5 and float(x.min()) >= -0.485 / 0.229 - 1e-5
