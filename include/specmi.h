@@ -126,6 +126,13 @@ int specmi_camcalib_decode(specmi_handle* h, const float* logits_vfov, const flo
                            const float* img_w, float* vfov, float* pitch, float* roll,
                            float* f_pix, float* cam_rotmat, float* cam_intrinsics, void* stream);
 
+/* read_cam_params (spec/utils/cam_params.py:24-50) for angles that were decoded earlier, e.g.
+ * read back from the CamCalib result pickle: (pitch, roll, f_pix, img_w, img_h) (B,) device ->
+ * cam_rotmat (B,3,3), cam_intrinsics (B,3,3) (K[2,2] = 0).  Either output may be NULL. */
+int specmi_cam_params(specmi_handle* h, const float* pitch, const float* roll, const float* f_pix,
+                      const float* img_w, const float* img_h, int B, float* cam_rotmat,
+                      float* cam_intrinsics, void* stream);
+
 /* ---- forward: SPEC --------------------------------------------------------------------- */
 
 /* HMR.forward (spec/models/hmr.py:82-122).  cam_* / bbox_* / img_* may be NULL when the

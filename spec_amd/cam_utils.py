@@ -53,4 +53,20 @@ def convert_preds_to_angles(pred_vfov, pred_pitch, pred_roll, loss_type='softarg
     return out
 
 
+@torch.no_grad()
+def cam_params_from_angles(pitch, roll, f_pix, img_w, img_h, device='cuda'):
+    """(pitch, roll, f_pix, img_w, img_h) (B,) -> cam_rotmat (B,3,3), cam_intrinsics (B,3,3) on the
+    device - the R / K construction of ``spec/utils/cam_params.py:37-48`` (K[2,2] = 0)."""
+    from . import _lib
+    from .engine import _dev_f32, _ptr
+    dev = torch.device(device)
+    eng = _engine(dev if dev.type == 'cuda' else torch.device('cuda'))
+    args = [_dev_f32(torch.as_tensor(a, dtype=torch.float32).reshape(-1), eng.device) for a in (pitch, roll, f_pix, img_w, img_h)]
+    B = args[0].shape[0]
+    R = torch.empty(B, 3, 3, device=eng.device, dtype=torch.float32)
+    K = torch.empty(B, 3, 3, device=eng.device, dtype=torch.float32)
+    _lib.check(eng.h, eng.lib.specmi_cam_params(eng.h, *[_ptr(a) for a in args], B, _ptr(R), _ptr(K), eng._stream()))
+    return R, K
+
+
 VFOV_RANGE, PITCH_RANGE, ROLL_RANGE = C.VFOV_RANGE, C.PITCH_RANGE, C.ROLL_RANGE

@@ -664,6 +664,15 @@ int specmi_camcalib_decode(specmi_handle* h, const float* lv, const float* lp, c
     return SPECMI_OK;
 }
 
+int specmi_cam_params(specmi_handle* h, const float* pitch, const float* roll, const float* f_pix, const float* img_w,
+                      const float* img_h, int B, float* R, float* K, void* stream) {
+    ENTER(h);
+    if (!pitch || !roll || !f_pix || !img_w || !img_h || B <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
+    LaunchCtx ctx{(hipStream_t)stream, &h->prof, "camcalib.cam_params"};
+    LAUNCHCHK(h, launch_cam_params(pitch, roll, f_pix, img_w, img_h, B, R, K, ctx), "cam_params");
+    return SPECMI_OK;
+}
+
 int specmi_hmr_head_forward(specmi_handle* h, const float* feat, int B, int fh, int fw, const float* R, const float* K,
                             const float* img_h, float* pred_pose, float* pred_shape, float* pred_cam,
                             float* pred_pose_6d, void* stream) {

@@ -108,6 +108,31 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// R = batch_euler2matrix([pitch, 0, roll]) through the quaternion route and K with K[2,2] = 0
+// (spec/utils/cam_params.py:37-46)
+__device__ __forceinline__ void build_cam_RK(float pt, float rl, float f, float w, float h, float* R, float* K) {
+    if (R) {
+        const float hx = pt / 2.0f, hy = 0.0f / 2.0f, hz = rl / 2.0f;
+        const float cz = cosf(hz), sz = sinf(hz), cy = cosf(hy), sy = sinf(hy), cx = cosf(hx), sx = sinf(hx);
+        float qw = cx * cy * cz - sx * sy * sz;
+        float qx = cx * sy * sz + cy * cz * sx;
+        float qy = cx * cz * sy - sx * cy * sz;
+        float qz = cx * cy * sz + sx * cz * sy;
+        const float nq = sqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
+        qw /= nq; qx /= nq; qy /= nq; qz /= nq;
+        const float w2 = qw * qw, x2 = qx * qx, y2 = qy * qy, z2 = qz * qz;
+        const float wx = qw * qx, wy = qw * qy, wz = qw * qz, xy = qx * qy, xz = qx * qz, yz = qy * qz;
+        R[0] = w2 + x2 - y2 - z2; R[1] = 2 * xy - 2 * wz;     R[2] = 2 * wy + 2 * xz;
+        R[3] = 2 * wz + 2 * xy;     R[4] = w2 - x2 + y2 - z2; R[5] = 2 * yz - 2 * wx;
+        R[6] = 2 * xz - 2 * wy;     R[7] = 2 * wx + 2 * yz;     R[8] = w2 - x2 - y2 + z2;
+    }
+    if (K) {
+        K[0] = f;   K[1] = 0.f; K[2] = w / 2.0f;
+        K[3] = 0.f; K[4] = f;   K[5] = h / 2.0f;
+        K[6] = 0.f; K[7] = 0.f; K[8] = 0.f;   // K[2,2] stays 0 as in the reference
+    }
+}
+
 __global__ void __launch_bounds__(192) camcalib_decode_kernel(const float* __restrict__ lv, const float* __restrict__ lp,
                                                                const float* __restrict__ lr, int nbins,
                                                                const float* __restrict__ img_h,
@@ -149,29 +174,7 @@ __global__ void __launch_bounds__(192) camcalib_decode_kernel(const float* __res
         const float h = img_h ? img_h[b] : 0.f, w = img_w ? img_w[b] : 0.f;
         const float f = h / 2.0f / tanf(vf / 2.0f);
         if (f_pix) f_pix[b] = f;
-        if (R) {
-            // batch_euler2matrix([pitch, 0, roll]) = quat2mat(euler2quat): half angles
-            const float hx = pt / 2.0f, hy = 0.0f / 2.0f, hz = rl / 2.0f;
-            const float cz = cosf(hz), sz = sinf(hz), cy = cosf(hy), sy = sinf(hy), cx = cosf(hx), sx = sinf(hx);
-            float qw = cx * cy * cz - sx * sy * sz;
-            float qx = cx * sy * sz + cy * cz * sx;
-            float qy = cx * cz * sy - sx * cy * sz;
-            float qz = cx * cy * sz + sx * cz * sy;
-            const float nq = sqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
-            qw /= nq; qx /= nq; qy /= nq; qz /= nq;
-            const float w2 = qw * qw, x2 = qx * qx, y2 = qy * qy, z2 = qz * qz;
-            const float wx = qw * qx, wy = qw * qy, wz = qw * qz, xy = qx * qy, xz = qx * qz, yz = qy * qz;
-            float* o = R + (size_t)b * 9;
-            o[0] = w2 + x2 - y2 - z2; o[1] = 2 * xy - 2 * wz;     o[2] = 2 * wy + 2 * xz;
-            o[3] = 2 * wz + 2 * xy;     o[4] = w2 - x2 + y2 - z2; o[5] = 2 * yz - 2 * wx;
-            o[6] = 2 * xz - 2 * wy;     o[7] = 2 * wx + 2 * yz;     o[8] = w2 - x2 - y2 + z2;
-        }
-        if (K) {
-            float* o = K + (size_t)b * 9;
-            o[0] = f;   o[1] = 0.f; o[2] = w / 2.0f;
-            o[3] = 0.f; o[4] = f;   o[5] = h / 2.0f;
-            o[6] = 0.f; o[7] = 0.f; o[8] = 0.f;   // K[2,2] stays 0 (spec/utils/cam_params.py:39-46)
-        }
+        build_cam_RK(pt, rl, f, w, h, R ? R + (size_t)b * 9 : nullptr, K ? K + (size_t)b * 9 : nullptr);
     }
 }
 
@@ -181,6 +184,23 @@ int launch_camcalib_decode(const float* lv, const float* lp, const float* lr, in
     ProfScope ps(ctx, "camcalib_decode", 0.0, 4.0 * B * (3.0 * nbins + 24));
     hipLaunchKernelGGL(camcalib_decode_kernel, dim3(B), dim3(192), 0, ctx.stream, lv, lp, lr, nbins, img_h, img_w, vfov,
                        pitch, roll, f_pix, R, K);
+    return (int)hipGetLastError();
+}
+
+// read_cam_params (spec/utils/cam_params.py:24-50) for already-decoded angles: (pitch, roll, f_pix, w, h) -> R, K
+__global__ void cam_params_kernel(const float* __restrict__ pitch, const float* __restrict__ roll,
+                                  const float* __restrict__ f_pix, const float* __restrict__ img_w,
+                                  const float* __restrict__ img_h, int B, float* __restrict__ R, float* __restrict__ K) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    build_cam_RK(pitch[b], roll[b], f_pix[b], img_w[b], img_h[b], R ? R + (size_t)b * 9 : nullptr,
+                 K ? K + (size_t)b * 9 : nullptr);
+}
+
+int launch_cam_params(const float* pitch, const float* roll, const float* f_pix, const float* img_w, const float* img_h,
+                      int B, float* R, float* K, const LaunchCtx& ctx) {
+    ProfScope ps(ctx, "cam_params", 0.0, 4.0 * B * 23);
+    hipLaunchKernelGGL(cam_params_kernel, dim3((B + 63) / 64), dim3(64), 0, ctx.stream, pitch, roll, f_pix, img_w, img_h, B, R, K);
     return (int)hipGetLastError();
 }
 

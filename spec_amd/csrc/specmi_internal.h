@@ -102,6 +102,9 @@ int launch_camcalib_decode(const float* lv, const float* lp, const float* lr, in
                            const float* img_h, const float* img_w, float* vfov, float* pitch,
                            float* roll, float* f_pix, float* R, float* K, const LaunchCtx& ctx);
 
+int launch_cam_params(const float* pitch, const float* roll, const float* f_pix, const float* img_w, const float* img_h,
+                      int B, float* R, float* K, const LaunchCtx& ctx);
+
 // ----------------------------------------------------------------------------------------
 // SMPL  (smpl.hip)
 // ----------------------------------------------------------------------------------------

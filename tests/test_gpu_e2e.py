@@ -169,3 +169,18 @@ def test_reload_after_parameter_change(models):
     assert torch.allclose(b, a + 1.0, atol=1e-5)
     with torch.no_grad():
         cc.fc_vfov.bias.sub_(1.0)
+
+
+def test_demo_flow_writes_reference_formats(tmp_path):
+    """scripts/spec_demo.py --synthetic: CamCalib -> decode -> device crops -> SPEC -> pickles."""
+    import subprocess, sys, os, joblib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'spec_demo.py'), '--synthetic', '2',
+                        '--output_folder', str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert 'SPEC FPS' in r.stdout
+    cam = joblib.load(os.path.join(str(tmp_path), 'camcalib', 'synthetic_000.jpg.pkl'))
+    assert set(cam) == {'vfov', 'f_pix', 'pitch', 'roll'}
+    res = joblib.load(os.path.join(str(tmp_path), 'spec_results', 'synthetic_000.pkl'))
+    assert res['smpl_vertices'].shape == (1, 6890, 3) and res['smpl_joints2d'].shape == (1, 49, 2)
+    assert np.isfinite(res['smpl_vertices']).all()
