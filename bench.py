@@ -131,6 +131,8 @@ def main():
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--no-overlap', action='store_true', help='run CamCalib and SPEC back to back on one stream')
     ap.add_argument('--force-variant', type=int, default=0, help='debug: force a conv tile (1:128x128 2:128x64 3:64x64)')
+    ap.add_argument('--subbatch', type=int, default=-1, help='trunk sub-batch for the early stages (0 = off, -1 = library default)')
+    ap.add_argument('--subbatch-layers', type=int, default=-1)
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -152,6 +154,11 @@ def main():
     cc, hm, cs, hs = build_models(device)
     pipe = SpecPipeline(cc, hm, overlap=not args.no_overlap)
     seq_pipe = SpecPipeline(cc, hm, overlap=False)    # per-kernel profiling pass runs serially
+    for m in (cc, hm):
+        if args.subbatch >= 0:
+            m._engine.set_option('trunk_subbatch', args.subbatch)
+        if args.subbatch_layers >= 0:
+            m._engine.set_option('trunk_subbatch_layers', args.subbatch_layers)
     if args.force_variant:
         cc._engine.set_option('force_conv_variant', args.force_variant)
     B = args.batch

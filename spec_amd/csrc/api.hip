@@ -373,21 +373,6 @@ static int ensure_ws(specmi_handle* h, int B, int H, int W) {
 // ------------------------------------------------------------------------------------------
 // launch sequences
 // ------------------------------------------------------------------------------------------
-static int run_conv(specmi_handle* h, const ConvW& c, const float* x, int B, int H, int W, const float* res, int relu,
-                    float* out, int* OHo, int* OWo, hipStream_t s, const std::string& label) {
-    ConvArgs a;
-    a.x = x; a.w = c.w; a.scale = c.scale; a.shift = c.shift; a.res = res; a.out = out;
-    a.B = B; a.H = H; a.W = W; a.Cin = c.cin; a.ldx = c.cin;
-    a.OH = conv_out(H, c.k, c.stride, c.pad); a.OW = conv_out(W, c.k, c.stride, c.pad);
-    a.Cout = c.cout; a.Npad = c.Npad; a.ldo = c.cout;
-    a.KH = c.k; a.KW = c.k; a.stride = c.stride; a.pad = c.pad; a.relu = relu;
-    LaunchCtx ctx{s, &h->prof, label.c_str()};
-    LAUNCHCHK(h, launch_conv_igemm(a, ctx), label.c_str());
-    if (OHo) *OHo = a.OH;
-    if (OWo) *OWo = a.OW;
-    return SPECMI_OK;
-}
-
 static int run_fc(specmi_handle* h, const FcW& fc, const float* x, int ldx, int B, const float* res, float* out,
                   int ldo, hipStream_t s, const char* label) {
     ConvArgs a;
@@ -401,48 +386,106 @@ static int run_fc(specmi_handle* h, const FcW& fc, const float* x, int ldx, int 
 }
 
 // images NCHW -> layer4 map NHWC in *feat (a workspace buffer unless feat_out given)
+// One launch of the trunk's op list: the stem, the max-pool or a fused conv, with the buffer each
+// operand lives in (act[] index, -1 = none, -2 = the caller's feature buffer) and its per-image size.
+struct TrunkOp {
+    int kind;  // 0 stem, 1 maxpool, 2 conv
+    const ConvW* c;
+    int in_buf, out_buf, res_buf;
+    int H, W;            // input spatial size
+    int OH, OW;          // output spatial size
+    int relu;
+    std::string label;
+    size_t in_img, out_img;  // floats per image of input / output (and residual)
+};
+
+static int exec_op(specmi_handle* h, const TrunkOp& op, const float* images, float* feat_out, int b0, int nb,
+                   int Himg, int Wimg, hipStream_t s) {
+    auto buf = [&](int idx) -> float* { return idx == -2 ? feat_out : h->act[idx]; };
+    LaunchCtx ctx{s, &h->prof, op.label.c_str()};
+    if (op.kind == 0) {
+        LAUNCHCHK(h, launch_stem(images + (size_t)b0 * 3 * Himg * Wimg, h->stem.w, h->stem.scale, h->stem.shift,
+                                 buf(op.out_buf) + (size_t)b0 * op.out_img, nb, Himg, Wimg, op.OH, op.OW, 1, ctx), "stem");
+        return SPECMI_OK;
+    }
+    if (op.kind == 1) {
+        LAUNCHCHK(h, launch_maxpool3x3s2(buf(op.in_buf) + (size_t)b0 * op.in_img, buf(op.out_buf) + (size_t)b0 * op.out_img, nb,
+                                         op.H, op.W, 64, op.OH, op.OW, ctx), "maxpool");
+        return SPECMI_OK;
+    }
+    const ConvW& c = *op.c;
+    ConvArgs a;
+    a.x = buf(op.in_buf) + (size_t)b0 * op.in_img;
+    a.w = c.w; a.scale = c.scale; a.shift = c.shift;
+    a.res = op.res_buf == -1 ? nullptr : buf(op.res_buf) + (size_t)b0 * op.out_img;
+    a.out = buf(op.out_buf) + (size_t)b0 * op.out_img;
+    a.B = nb; a.H = op.H; a.W = op.W; a.Cin = c.cin; a.ldx = c.cin;
+    a.OH = op.OH; a.OW = op.OW; a.Cout = c.cout; a.Npad = c.Npad; a.ldo = c.cout;
+    a.KH = c.k; a.KW = c.k; a.stride = c.stride; a.pad = c.pad; a.relu = op.relu;
+    LAUNCHCHK(h, launch_conv_igemm(a, ctx), op.label.c_str());
+    return SPECMI_OK;
+}
+
+// images NCHW -> layer4 map NHWC in *feat (a workspace buffer unless feat_out given).
+// Option "trunk_subbatch" = S > 0: the stem, the max-pool and the first "trunk_subbatch_layers"
+// ResNet stages are run S images at a time (activations of a slice are <= 103 MB at S = 32 and stay
+// resident in the 256 MiB Infinity Cache between layers); later stages see the whole batch.
 static int run_trunk(specmi_handle* h, const float* images, int B, int H, int W, float* feat_out, const float** feat,
                      int* fh, int* fw, hipStream_t s) {
     int rc;
     if (H < 32 || W < 32) return fail(h, SPECMI_ERR_ARG, "image size %dx%d too small", H, W);
     if ((rc = ensure_ws(h, B, H, W))) return rc;
+    std::vector<TrunkOp> ops;
+    std::vector<int> stage_of;   // resnet stage (0 = stem/pool, 1..4) of each op
     const int oh1 = conv_out(H, 7, 2, 3), ow1 = conv_out(W, 7, 2, 3);
-    {
-        LaunchCtx ctx{s, &h->prof, "backbone.conv1"};
-        LAUNCHCHK(h, launch_stem(images, h->stem.w, h->stem.scale, h->stem.shift, h->act[0], B, H, W, oh1, ow1, 1, ctx),
-                  "stem");
-    }
     int ch = conv_out(oh1, 3, 2, 1), cw = conv_out(ow1, 3, 2, 1);
-    {
-        LaunchCtx ctx{s, &h->prof, "backbone.maxpool"};
-        LAUNCHCHK(h, launch_maxpool3x3s2(h->act[0], h->act[1], B, oh1, ow1, 64, ch, cw, ctx), "maxpool");
-    }
+    ops.push_back({0, nullptr, -1, 0, -1, H, W, oh1, ow1, 1, "backbone.conv1", (size_t)3 * H * W, (size_t)oh1 * ow1 * 64});
+    stage_of.push_back(0);
+    ops.push_back({1, nullptr, 0, 1, -1, oh1, ow1, ch, cw, 0, "backbone.maxpool", (size_t)oh1 * ow1 * 64, (size_t)ch * cw * 64});
+    stage_of.push_back(0);
     int xi = 1;  // index of the buffer holding the block input
+    int final_buf = 1;
     for (size_t bi = 0; bi < h->blocks.size(); ++bi) {
         const Bneck& bk = h->blocks[bi];
         const bool last = (bi + 1 == h->blocks.size());
         int free_idx[3], nf = 0;
         for (int i = 0; i < 4; ++i)
             if (i != xi) free_idx[nf++] = i;
-        float* x = h->act[xi];
-        float* t1 = h->act[free_idx[0]];
-        float* t2 = h->act[free_idx[1]];
-        float* idb = h->act[free_idx[2]];
-        int oh, ow;
+        const int t1 = free_idx[0], t2 = free_idx[1], idb = free_idx[2];
+        const int stage = bk.c1.name[5] - '0';   // "layerN.b.conv1"
         const std::string p = "backbone." + bk.c1.name.substr(0, bk.c1.name.rfind('.'));
-        if ((rc = run_conv(h, bk.c1, x, B, ch, cw, nullptr, 1, t1, nullptr, nullptr, s, p + ".conv1"))) return rc;
-        if ((rc = run_conv(h, bk.c2, t1, B, ch, cw, nullptr, 1, t2, &oh, &ow, s, p + ".conv2"))) return rc;
-        const float* identity = x;
+        const int oh = conv_out(ch, 3, bk.c2.stride, 1), ow = conv_out(cw, 3, bk.c2.stride, 1);
+        auto add = [&](const ConvW& c, int in, int out, int res, int ih, int iw, int ooh, int oow, int relu, const char* nm) {
+            ops.push_back({2, &c, in, out, res, ih, iw, ooh, oow, relu, p + nm, (size_t)ih * iw * c.cin, (size_t)ooh * oow * c.cout});
+            stage_of.push_back(stage);
+        };
+        add(bk.c1, xi, t1, -1, ch, cw, ch, cw, 1, ".conv1");
+        add(bk.c2, t1, t2, -1, ch, cw, oh, ow, 1, ".conv2");
+        int identity = xi;
         if (bk.has_ds) {
-            if ((rc = run_conv(h, bk.ds, x, B, ch, cw, nullptr, 0, idb, nullptr, nullptr, s, p + ".downsample"))) return rc;
+            add(bk.ds, xi, idb, -1, ch, cw, oh, ow, 0, ".downsample");
             identity = idb;
         }
-        float* out = (last && feat_out) ? feat_out : t1;  // t1 is dead after conv2
-        if ((rc = run_conv(h, bk.c3, t2, B, oh, ow, identity, 1, out, nullptr, nullptr, s, p + ".conv3"))) return rc;
+        const int out = (last && feat_out) ? -2 : t1;  // t1 is dead after conv2
+        add(bk.c3, t2, out, identity, oh, ow, oh, ow, 1, ".conv3");
         ch = oh; cw = ow;
-        xi = free_idx[0];
-        if (last) *feat = out;
+        xi = t1;
+        final_buf = out;
     }
+    const int S = opt_i(h, "trunk_subbatch", 0);
+    const int Lsplit = opt_i(h, "trunk_subbatch_layers", 2);
+    size_t first_full = 0;
+    if (S > 0 && S < B) {
+        while (first_full < ops.size() && stage_of[first_full] <= Lsplit) ++first_full;
+        for (int b0 = 0; b0 < B; b0 += S) {
+            const int nb = (B - b0 < S) ? B - b0 : S;
+            for (size_t i = 0; i < first_full; ++i)
+                if ((rc = exec_op(h, ops[i], images, feat_out, b0, nb, H, W, s))) return rc;
+        }
+    }
+    for (size_t i = first_full; i < ops.size(); ++i)
+        if ((rc = exec_op(h, ops[i], images, feat_out, 0, B, H, W, s))) return rc;
+    *feat = final_buf == -2 ? feat_out : h->act[final_buf];
     *fh = ch; *fw = cw;
     return SPECMI_OK;
 }
