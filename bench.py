@@ -131,6 +131,7 @@ def main():
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--no-overlap', action='store_true', help='run CamCalib and SPEC back to back on one stream')
     ap.add_argument('--force-variant', type=int, default=0, help='debug: force a conv tile (1:128x128 2:128x64 3:64x64)')
+    ap.add_argument('--graph', action='store_true', help='capture the step in a hipGraph and replay it')
     ap.add_argument('--subbatch', type=int, default=-1, help='trunk sub-batch for the early stages (0 = off, -1 = library default)')
     ap.add_argument('--subbatch-layers', type=int, default=-1)
     args = ap.parse_args()
@@ -164,8 +165,13 @@ def main():
     B = args.batch
     x, scale, center, img_w, img_h = make_inputs(B, device, 20210001 + rank)
 
+    run = pipe
+    if args.graph:
+        from spec_amd.pipeline import GraphedPipeline
+        run = GraphedPipeline(pipe, x, scale, center, img_w, img_h)
+
     def step():
-        out = pipe(x, scale, center, img_w, img_h)
+        out = run(x, scale, center, img_w, img_h)
         if world > 1:
             return gather_outputs(out)
         return out

@@ -377,11 +377,12 @@ static int g_force_variant = 0;  // 0 auto, 1: 128x128/4 waves, 2: 128x64/4, 3: 
 void conv_igemm_force_variant(int v) { g_force_variant = v; }
 
 static const char* kVariantNames[] = {"", "conv_igemm_f32<128x128,2x2>", "conv_igemm_f32<128x64,2x2>",
-                                      "conv_igemm_f32<64x64,2x2>", "conv_igemm_f32<128x128,4x2>"};
+                                      "conv_igemm_f32<64x64,2x2>", "conv_igemm_f32<128x128,4x2>",
+                                      "conv_igemm_f32<128x64,4x2>", "conv_igemm_f32<64x128,2x4>"};
 
 static int pick_variant(int M, int Npad, bool is1x1) {
-    if (g_force_variant >= 1 && g_force_variant <= 4) {
-        const bool needs128 = (g_force_variant == 1 || g_force_variant == 4);
+    if (g_force_variant >= 1 && g_force_variant <= 6) {
+        const bool needs128 = (g_force_variant == 1 || g_force_variant == 4 || g_force_variant == 6);
         if (!needs128 || Npad % 128 == 0) return g_force_variant;
     }
     // Measured on MI355X at B=256 (tools/igemm_bench, profiles/): the 64x64 tile (4 workgroups =
@@ -403,6 +404,10 @@ static int dispatch(int v, const KArgs& k, int M, const LaunchCtx& ctx, double f
         case 1: return launch_variant<128, 128, 2, 2, IS1X1>(k, M, ctx, kVariantNames[v], flops, bytes);
         case 2: return launch_variant<128, 64, 2, 2, IS1X1>(k, M, ctx, kVariantNames[v], flops, bytes);
         case 4: return launch_variant<128, 128, 4, 2, IS1X1>(k, M, ctx, kVariantNames[v], flops, bytes);
+#ifdef SPECMI_TUNE
+        case 5: return launch_variant<128, 64, 4, 2, IS1X1>(k, M, ctx, kVariantNames[v], flops, bytes);
+        case 6: return launch_variant<64, 128, 2, 4, IS1X1>(k, M, ctx, kVariantNames[v], flops, bytes);
+#endif
         default: return launch_variant<64, 64, 2, 2, IS1X1>(k, M, ctx, kVariantNames[3], flops, bytes);
     }
 }

@@ -75,6 +75,30 @@ class SpecPipeline:
         return out
 
 
+class GraphedPipeline:
+    """The whole step captured once into a hipGraph (via torch.cuda.CUDAGraph) and replayed: for
+    small batches the ~130 kernel launches of a step are launch-bound, a replay costs one
+    submission.  Inputs are copied into static buffers; outputs are the static output tensors
+    (valid until the next call)."""
+
+    def __init__(self, pipeline: SpecPipeline, images, bbox_scale, bbox_center, img_w, img_h, warmup: int = 2):
+        self.static_in = [t.clone() for t in (images, bbox_scale, bbox_center, img_w, img_h)]
+        for _ in range(warmup):                      # allocates workspaces, sets kernel attributes
+            pipeline(*self.static_in)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_out = pipeline(*self.static_in)
+
+    @torch.no_grad()
+    def __call__(self, images, bbox_scale, bbox_center, img_w, img_h):
+        for dst, src in zip(self.static_in, (images, bbox_scale, bbox_center, img_w, img_h)):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+        self.graph.replay()
+        return self.static_out
+
+
 def shard_range(total: int, rank: int, world: int):
     """Contiguous rank-major image slice [lo, hi) of a global batch (config 4: 2048 -> 256 per GPU).
     Remainders go to the lowest ranks, so any total / world is covered exactly once."""
