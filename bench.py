@@ -264,6 +264,7 @@ def main():
             line['stages_ms'] = {k: v['ms'] for k, v in stages.items()}
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()          # rank 0 may still be in its profiling pass
         dist.destroy_process_group()
 
 

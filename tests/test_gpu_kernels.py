@@ -244,3 +244,17 @@ def test_hmr_head_iterative_regressor(hmr_engine, B):
     for k in ('pred_pose_6d', 'pred_shape', 'pred_cam', 'pred_pose'):
         err = rel_err(out[k].cpu().numpy(), ref[k].numpy())
         assert err < 2e-5, (k, err)
+
+
+def test_conv_batch_split_beyond_2gib(eng):
+    """Buffer addressing is 32-bit: an activation tensor >= 2 GiB is processed in batch slices."""
+    B, H, cin, cout = 172, 56, 1024, 64           # 172*56*56*1024*4 B = 2.06 GiB
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, H, H, cin, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5
+    sc, sh = torch.ones(cout), torch.zeros(cout)
+    y = eng.conv2d(x.to(DEV), w.numpy(), sc.numpy(), sh.numpy(), 1, 0, relu=False).cpu()
+    idx = [0, 1, 85, 86, 170, 171]                # both sides of the slice boundary
+    ref = _conv_ref(x[idx], w, sc, sh, 1, 0, None, False)
+    assert rel_err(y[idx].numpy(), ref.numpy()) < 2e-5
+    assert torch.isfinite(y).all()
