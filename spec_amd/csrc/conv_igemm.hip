@@ -73,15 +73,16 @@ struct KArgs {
 
 constexpr unsigned kOutOfRange = 0x80000000u;  // >= any buffer extent: the load returns zeros
 
-template <int BM, int BN, int WGM, int WGN, bool IS1X1>
+template <int BM, int BN, int WGM, int WGN, bool IS1X1, int BK>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KArgs p) {
-    constexpr int BK = 32;
     constexpr int LDA = BK + 4;
+    constexpr int KQ = BK / 4;   // 16-byte k-quads per chunk row
+    constexpr int NQ = BK / 8;   // 8-k sub-chunks per chunk
     constexpr int NT = 64 * WGM * WGN;                         // threads: WGM x WGN waves
     constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);  // 32x32 MFMA tiles per wave
-    constexpr int AI = BM * 8 / NT, BI = BN * 8 / NT;          // float4 loads per thread per chunk
-    constexpr int ARS = NT / 8;                                // A rows covered per load pass
-    constexpr int A_STAGE = BM * LDA, B_STAGE = 8 * BN * 4;
+    constexpr int AI = BM * KQ / NT, BI = BN * KQ / NT;        // float4 loads per thread per chunk
+    constexpr int ARS = NT / KQ;                               // A rows covered per load pass
+    constexpr int A_STAGE = BM * LDA, B_STAGE = KQ * BN * 4;
     static_assert(TM >= 1 && TN >= 1 && AI >= 1 && BI >= 1, "tile too small for the wave grid");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
@@ -104,7 +105,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
     // ---- buffer descriptors (wave-uniform) and per-thread row offsets -----------------------
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
-    const int a_kq = tid & 7, a_r = tid >> 3;
+    const int a_kq = tid % KQ, a_r = tid / KQ;
     unsigned a_voff[AI];   // byte offset of (row's tap-(0,0) pixel, quad a_kq); out-of-range when the row is past M (1x1)
     unsigned a_mask[AI];   // 3x3: bit t = filter tap t lies inside the image for this row
 #pragma unroll
@@ -152,7 +153,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
             tap_bytes = (unsigned)((ky * p.W + kx) * p.ldx * 4);
         }
         const unsigned s_a = (unsigned)(c0 * BK * 4);
-        const unsigned s_b = (unsigned)(c * 8 * p.Npad * 16);
+        const unsigned s_b = (unsigned)(c * KQ * p.Npad * 16);
         if (!TUNE_ABLATE(16)) {
 #pragma unroll
             for (int i = 0; i < AI; ++i) {
@@ -226,7 +227,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
         f32x4 fa[2][TM], fb[2][TN];
         read_frags(Ab, Bb, 0, fa[0], fb[0]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -247,8 +248,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
                         }
                     }
                 }
-                if (s == 1 && q < 3) read_frags(Ab, Bb, q + 1, fa[(q + 1) & 1], fb[(q + 1) & 1]);
-                if (PF && q == 3 && !TUNE_ABLATE(2)) {   // stage the next chunk: stores spread over the last 4 steps
+                if (s == 1 && q < NQ - 1) read_frags(Ab, Bb, q + 1, fa[(q + 1) & 1], fb[(q + 1) & 1]);
+                if (PF && q == NQ - 1 && !TUNE_ABLATE(2)) {   // stage the next chunk: stores spread over the last 4 steps
 #pragma unroll
                     for (int t = 0; t < AI + BI; ++t) {
                         if ((t & 3) != s) continue;
@@ -343,16 +344,16 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
 #endif
 }
 
-template <int BM, int BN, int WGM, int WGN, bool IS1X1>
+template <int BM, int BN, int WGM, int WGN, bool IS1X1, int BK = 32>
 static int launch_variant(const KArgs& k, int M, const LaunchCtx& ctx, const char* name, double flops,
                           double bytes) {
-    constexpr size_t ab = (size_t)(2 * BM * 36 + 2 * 8 * BN * 4) * sizeof(float);
+    constexpr size_t ab = (size_t)(2 * BM * (BK + 4) + 2 * (BK / 4) * BN * 4) * sizeof(float);
     constexpr size_t cb = (size_t)BM * (BN + 4) * sizeof(float);
     constexpr size_t smem = ab > cb ? ab : cb;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&conv_igemm_f32_kernel<BM, BN, WGM, WGN, IS1X1>),
+            reinterpret_cast<const void*>(&conv_igemm_f32_kernel<BM, BN, WGM, WGN, IS1X1, BK>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -362,7 +363,9 @@ static int launch_variant(const KArgs& k, int M, const LaunchCtx& ctx, const cha
     const int nbm = (M + BM - 1) / BM;
     const int grid = nbm * kk.nbn;
     ProfScope ps(ctx, name, flops, bytes);
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WGM, WGN, IS1X1>), dim3(grid), dim3(64 * WGM * WGN), smem,
+    kk.cpc = k.cpc * 32 / BK;
+    kk.nchunks = k.nchunks * 32 / BK;
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WGM, WGN, IS1X1, BK>), dim3(grid), dim3(64 * WGM * WGN), smem,
                        ctx.stream, kk);
     return (int)hipGetLastError();
 }
@@ -378,10 +381,10 @@ void conv_igemm_force_variant(int v) { g_force_variant = v; }
 
 static const char* kVariantNames[] = {"", "conv_igemm_f32<128x128,2x2>", "conv_igemm_f32<128x64,2x2>",
                                       "conv_igemm_f32<64x64,2x2>", "conv_igemm_f32<128x128,4x2>",
-                                      "conv_igemm_f32<128x64,4x2>", "conv_igemm_f32<64x128,2x4>"};
+                                      "conv_igemm_f32<128x64,4x2>", "conv_igemm_f32<64x128,2x4>", "conv_igemm_f32<64x64,2x2,bk16>"};
 
 static int pick_variant(int M, int Npad, bool is1x1) {
-    if (g_force_variant >= 1 && g_force_variant <= 6) {
+    if (g_force_variant >= 1 && g_force_variant <= 7) {
         const bool needs128 = (g_force_variant == 1 || g_force_variant == 4 || g_force_variant == 6);
         if (!needs128 || Npad % 128 == 0) return g_force_variant;
     }
@@ -407,6 +410,7 @@ static int dispatch(int v, const KArgs& k, int M, const LaunchCtx& ctx, double f
 #ifdef SPECMI_TUNE
         case 5: return launch_variant<128, 64, 4, 2, IS1X1>(k, M, ctx, kVariantNames[v], flops, bytes);
         case 6: return launch_variant<64, 128, 2, 4, IS1X1>(k, M, ctx, kVariantNames[v], flops, bytes);
+        case 7: return launch_variant<64, 64, 2, 2, IS1X1, 16>(k, M, ctx, kVariantNames[v], flops, bytes);
 #endif
         default: return launch_variant<64, 64, 2, 2, IS1X1>(k, M, ctx, kVariantNames[3], flops, bytes);
     }

@@ -204,3 +204,18 @@ def test_graph_replay_matches_eager(models):
     x2 = t(synth.images(92, B)).to(DEV)            # new inputs are copied into the static buffers
     ref2 = pipe(x2, sc, ce, iw, ih)['smpl_vertices'].clone()
     assert torch.equal(g(x2, sc, ce, iw, ih)['smpl_vertices'], ref2)
+
+
+def test_eval_flow_synthetic(tmp_path):
+    """scripts/spec_eval.py --synthetic: batches of 64 through the path, device metrics, eval dump."""
+    import subprocess, sys, os, joblib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'spec_eval.py'), '--synthetic', '96',
+                        '--log_dir', str(tmp_path)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = dict(l.split(': ') for l in r.stdout.splitlines() if ': ' in l and l[0] in 'WP')
+    # noise of 1 cm per coordinate on 6890 vertices: joints barely move, V2V ~ sqrt(3)*10*0.92 mm
+    assert float(lines['W-MPJPE-24']) < 2.0 and float(lines['PA-MPJPE-24']) < 2.0
+    assert 14.0 < float(lines['W-V2V']) < 18.0
+    ev = joblib.load(os.path.join(str(tmp_path), 'evaluation_results_spec-syn.pkl'))
+    assert ev['pred_vertices'].shape == (96, 6890, 3) and ev['pred_pose'].shape == (96, 24, 3, 3)

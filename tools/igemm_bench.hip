@@ -79,6 +79,8 @@ int main(int argc, char** argv) {
         {"l4.conv3  1x1 512->2048 7 +res", 512, 2048, 1, 1, 7, 1, 3},
         {"l4.conv1  1x1 2048->512 7", 2048, 512, 1, 1, 7, 0, 2},
         {"l4.conv2  3x3 512      7", 512, 512, 3, 1, 7, 0, 2},
+        {"bigK      1x1 8192->256 14", 8192, 256, 1, 1, 14, 0, 0},
+        {"bigK3x3   3x3 1024->256 14", 1024, 256, 3, 1, 14, 0, 0},
     };
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
