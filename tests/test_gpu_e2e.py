@@ -214,8 +214,8 @@ def test_eval_flow_synthetic(tmp_path):
                         '--log_dir', str(tmp_path)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = dict(l.split(': ') for l in r.stdout.splitlines() if ': ' in l and l[0] in 'WP')
-    # noise of 1 cm per coordinate on 6890 vertices: joints barely move, V2V ~ sqrt(3)*10*0.92 mm
-    assert float(lines['W-MPJPE-24']) < 2.0 and float(lines['PA-MPJPE-24']) < 2.0
+    # noise of 1 cm per coordinate: a 48-vertex regressor row averages it down to a few mm, V2V ~ sqrt(3)*10*0.92 mm
+    assert 0.5 < float(lines['W-MPJPE-24']) < 6.0 and 0.5 < float(lines['PA-MPJPE-24']) < 6.0
     assert 14.0 < float(lines['W-V2V']) < 18.0
     ev = joblib.load(os.path.join(str(tmp_path), 'evaluation_results_spec-syn.pkl'))
     assert ev['pred_vertices'].shape == (96, 6890, 3) and ev['pred_pose'].shape == (96, 24, 3, 3)
