@@ -55,6 +55,7 @@ struct KArgs {
     int OW, OHW, Cout, Npad, ldo;
     int KH, KW, stride, pad;
     int M, nbn, nchunks, cpc;  // cpc = chunks per filter tap = Cin / 32
+    unsigned mg_ohw, sh_ohw, mg_ow, sh_ow;  // magic multipliers: n / OHW, n / OW for n < 2^31
     int relu;
     int vec_ok;  // out/res rows are 16-byte aligned: float4 epilogue traffic allowed
 #ifdef SPECMI_TUNE
@@ -108,14 +109,22 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
     const int a_kq = tid % KQ, a_r = tid / KQ;
     unsigned a_voff[AI];   // byte offset of (row's tap-(0,0) pixel, quad a_kq); out-of-range when the row is past M (1x1)
     unsigned a_mask[AI];   // 3x3: bit t = filter tap t lies inside the image for this row
+    // The tile prologue sits on every workgroup's critical path, so the pixel decode avoids the
+    // ~40-instruction integer divide: 1x1/stride-1 rows address the input with m itself, other
+    // shapes divide by OH*OW and OW with host-computed magic multipliers.
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
         const int m = m0 + a_r + ARS * i;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
-        const int b = mm / p.OHW;
+        if (IS1X1 && p.stride == 1) {
+            a_voff[i] = ok ? (unsigned)(mm * p.ldx * 4 + a_kq * 16) : kOutOfRange;
+            a_mask[i] = 0;
+            continue;
+        }
+        const int b = p.OHW == 1 ? mm : (int)(__umulhi((unsigned)mm, p.mg_ohw) >> p.sh_ohw);
         const int rem = mm - b * p.OHW;
-        const int oy = rem / p.OW;
+        const int oy = p.OW == 1 ? rem : (int)(__umulhi((unsigned)rem, p.mg_ow) >> p.sh_ow);
         const int ox = rem - oy * p.OW;
         const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
         const int pix0 = (b * p.H + iy0) * p.W + ix0;
@@ -125,13 +134,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
             a_mask[i] = 0;
         } else {
             a_voff[i] = off;
-            unsigned mk = 0;
+            unsigned colbits = 0, mk = 0;   // tap (ky,kx) is inside the image iff row ky and column kx are
+            for (int kx = 0; kx < p.KW; ++kx) colbits |= ((unsigned)(ix0 + kx) < (unsigned)p.W ? 1u : 0u) << kx;
             for (int ky = 0; ky < p.KH; ++ky)
-                for (int kx = 0; kx < p.KW; ++kx) {
-                    const bool in = ok && (unsigned)(iy0 + ky) < (unsigned)p.H && (unsigned)(ix0 + kx) < (unsigned)p.W;
-                    mk |= (in ? 1u : 0u) << (ky * p.KW + kx);
-                }
-            a_mask[i] = mk;
+                if ((unsigned)(iy0 + ky) < (unsigned)p.H) mk |= colbits << (ky * p.KW);
+            a_mask[i] = ok ? mk : 0u;
         }
     }
     unsigned b_voff[BI];
@@ -416,6 +423,17 @@ static int dispatch(int v, const KArgs& k, int M, const LaunchCtx& ctx, double f
     }
 }
 
+// floor(n / d) == umulhi(n, mg) >> sh for every n < 2^31 and 2 <= d < 2^31:
+// L = 31 + ceil(log2 d), mg = floor(2^L / d) + 1 (< 2^32), sh = L - 32.  d == 1 is handled in the kernel.
+static void magic_u32(unsigned d, unsigned* mg, unsigned* sh) {
+    if (d < 2) { *mg = 0; *sh = 0; return; }
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    const unsigned L = 31 + s;
+    *mg = (unsigned)((1ull << L) / d + 1ull);
+    *sh = L - 32;
+}
+
 static int launch_one(const ConvArgs& a, const LaunchCtx& ctx) {
     KArgs k;
     k.x = a.x; k.w = a.w; k.scale = a.scale; k.shift = a.shift; k.res = a.res; k.out = a.out;
@@ -428,6 +446,8 @@ static int launch_one(const ConvArgs& a, const LaunchCtx& ctx) {
     k.nchunks = a.KH * a.KW * k.cpc;
     k.nbn = 0;
     k.relu = a.relu;
+    magic_u32((unsigned)k.OHW, &k.mg_ohw, &k.sh_ohw);
+    magic_u32((unsigned)a.OW, &k.mg_ow, &k.sh_ow);
     k.x_bytes = (unsigned)((size_t)a.B * a.H * a.W * a.ldx * 4);
     k.w_bytes = (unsigned)((size_t)a.KH * a.KW * a.Cin * a.Npad * 4);
 #ifdef SPECMI_TUNE
