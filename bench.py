@@ -83,6 +83,23 @@ def roofline_from_profile(entries):
     n = sum(e['launches'] for e in conv)
     total_ms = sum(e['ms'] for e in entries)
     ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    # second MFMA kernel family: the fused Winograd F(2x2,3x3) 3x3 convolutions.  Its profiler flops are the
+    # ALGORITHMIC (direct-convolution) flops; the matrix cores execute 16/36 of them, which is what the
+    # MFMA roofline bounds.
+    wino = [e for e in entries if e['kernel'].startswith('conv_wino_f32')]
+    wms = sum(e['ms'] for e in wino)
+    wfl = sum(e['flops'] for e in wino)
+    wn = sum(e['launches'] for e in wino)
+    wino_info = None
+    if wms > 0:
+        walg = wfl / (wms * 1e-3) / 1e12
+        wino_info = {
+            'kernel': 'conv_wino_f32 (F(2x2,3x3), 3x3 stride-1 layers)', 'launches_per_step': wn,
+            'avg_launch_ms': round(wms / max(wn, 1), 4),
+            'algorithmic_TFLOPs': round(walg, 2), 'executed_mfma_TFLOPs': round(walg * 16.0 / 36.0, 2),
+            'frac_executed_of_peak': round(walg * 16.0 / 36.0 / PEAK_FP32_MFMA_TFLOPS, 4),
+            'share_of_step_kernel_time': round(wms / total_ms, 4) if total_ms > 0 else None,
+        }
     return {
         'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
         'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(),
@@ -93,6 +110,7 @@ def roofline_from_profile(entries):
         'algorithmic_gflop_per_launch': round(fl / max(n, 1) / 1e9, 3),
         'algorithmic_hbm_GBps': round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0,
         'share_of_step_kernel_time': round(ms / total_ms, 4) if total_ms > 0 else None,
+        'second_kernel': wino_info,
     }
 
 

@@ -29,6 +29,7 @@ struct ConvW {
     int cin = 0, cout = 0, k = 1, stride = 1, pad = 0;
     int Kp = 0, Npad = 0;
     float *w = nullptr, *scale = nullptr, *shift = nullptr;  // device
+    float* wino = nullptr;  // device: Winograd-domain filters (3x3 stride-1 layers only)
 };
 
 struct Bneck {
@@ -204,6 +205,12 @@ static int commit_conv(specmi_handle* h, const std::string& prefix, ConvW& c) {
     if ((rc = dev_upload(h, packed.data(), packed.size() * 4, (void**)&c.w, h->param_allocs))) return rc;
     if ((rc = dev_upload(h, scale.data(), scale.size() * 4, (void**)&c.scale, h->param_allocs))) return rc;
     if ((rc = dev_upload(h, shift.data(), shift.size() * 4, (void**)&c.shift, h->param_allocs))) return rc;
+    c.wino = nullptr;
+    if (c.k == 3 && c.stride == 1 && c.pad == 1 && c.cin % 16 == 0 && c.cout % 128 == 0) {
+        std::vector<float> u;
+        pack_wino_weights(w->f.data(), c.cout, c.cin, u);
+        if ((rc = dev_upload(h, u.data(), u.size() * 4, (void**)&c.wino, h->param_allocs))) return rc;
+    }
     return SPECMI_OK;
 }
 
@@ -422,6 +429,11 @@ static int exec_op(specmi_handle* h, const TrunkOp& op, const float* images, flo
     a.B = nb; a.H = op.H; a.W = op.W; a.Cin = c.cin; a.ldx = c.cin;
     a.OH = op.OH; a.OW = op.OW; a.Cout = c.cout; a.Npad = c.Npad; a.ldo = c.cout;
     a.KH = c.k; a.KW = c.k; a.stride = c.stride; a.pad = c.pad; a.relu = op.relu;
+    if (c.wino && opt_i(h, "winograd", 1) && conv_wino_supported(a)) {
+        a.w = c.wino;
+        LAUNCHCHK(h, launch_conv_wino(a, ctx), op.label.c_str());
+        return SPECMI_OK;
+    }
     LAUNCHCHK(h, launch_conv_igemm(a, ctx), op.label.c_str());
     return SPECMI_OK;
 }
@@ -771,7 +783,11 @@ int specmi_conv2d(specmi_handle* h, const float* x, int B, int H, int W, int Cin
     sc.assign(Npad, 0.f); sh.assign(Npad, 0.f);
     std::memcpy(sc.data(), scale_host, (size_t)Cout * 4);
     std::memcpy(sh.data(), shift_host, (size_t)Cout * 4);
+    // option "winograd": 1 (default) = F(2x2,3x3) where the shape allows it, 0 = always the direct implicit GEMM
+    const bool wino = !stem && opt_i(h, "winograd", 1) && KH == 3 && stride == 1 && pad == 1 && Cin % 16 == 0 &&
+                      Cout % 128 == 0 && !residual;
     if (stem) pack_stem_weights(w_host, packed);
+    else if (wino) pack_wino_weights(w_host, Cout, Cin, packed);
     else {
         if (Cin % 32) return fail(h, SPECMI_ERR_ARG, "Cin must be a multiple of 32 (got %d)", Cin);
         pack_gemm_weights(w_host, Cout, Cin, KH, KW, Cin * KH * KW, Npad, packed);
@@ -792,7 +808,7 @@ int specmi_conv2d(specmi_handle* h, const float* x, int B, int H, int W, int Cin
         a.x = x; a.w = dw; a.scale = dsc; a.shift = dsh; a.res = residual; a.out = out;
         a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.ldx = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout; a.Npad = Npad;
         a.ldo = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.relu = relu;
-        lrc = launch_conv_igemm(a, ctx);
+        lrc = wino ? launch_conv_wino(a, ctx) : launch_conv_igemm(a, ctx);
     }
     hipError_t se = hipStreamSynchronize(s);
     free_pool(tmp);

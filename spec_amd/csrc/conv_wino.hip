@@ -1,0 +1,321 @@
+// conv_wino.hip - 3x3 / stride-1 / pad-1 convolution as Winograd F(2x2, 3x3) on the gfx950 fp32
+// matrix cores, fused end to end (input transform -> 16 frequency GEMMs -> output transform ->
+// BatchNorm scale/shift -> ReLU) in one launch.
+//
+// Serves the conv2 of every stride-1 ResNet-50 bottleneck of both trunks (reference call sites
+// spec/models/hmr.py:92, camcalib/model.py:73; torchvision Bottleneck.conv2 + bn2 + relu).  The
+// direct implicit GEMM (conv_igemm.hip) spends 9 MACs per (pixel, ci, co); F(2x2,3x3) spends
+// 16 per 2x2 output tile = 4 per pixel, i.e. 2.25x fewer matrix-core cycles for the same result
+// up to fp32 rounding (|err| ~ 1e-6 relative, the same class cuDNN picks for these layers).
+//
+//   Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A      d: 4x4 input patch, g: 3x3 filter, Y: 2x2
+//
+// Work decomposition (CDNA4, wave64):
+//   * GEMM view per frequency f in 0..15:  D_f[t][co] = sum_ci V_f[t][ci] * U_f[ci][co] with
+//     t = 2x2 output tile index in [0, B*TH*TW).  A workgroup (4 waves) owns 32 tiles x 128
+//     output channels; wave w owns co block w (32 channels) for ALL 16 frequencies: 16
+//     accumulator tiles of v_mfma_f32_32x32x2_f32 = 256 accumulator registers per lane, so the
+//     output transform is lane-local (no cross-wave exchange) and one wave per SIMD runs.
+//   * A operand (transformed input V): the 256 threads each own one (tile, channel pair) per
+//     16-channel stage: 16 buffer_load_b64 of the raw 4x4 patch (image border = hardware range
+//     check -> 0.0), B^T d B on packed fp32 adds, 16 ds_write_b64 into the stage buffer laid out
+//     [f][c2][tile][2] exactly as the MFMA A fragments are read back (ds_read_b64, conflict free).
+//   * B operand (transformed filters U = G g G^T, computed in fp64 at commit): never staged -
+//     every wave streams its own fragments straight from L2 with coalesced buffer_load_b64
+//     ([co block][ci/4][f][lane][2] in HBM), one 4-channel micro-chunk ahead, rolling registers.
+//   * K loop: stage = 16 input channels = 4 micro-chunks of 32 MFMAs; V is double buffered, one
+//     barrier per stage; the loads / transform / LDS writes of stage s+1 are slotted between the
+//     MFMAs of stage s.
+#include "specmi_internal.h"
+
+namespace specmi {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WArgs {
+    const float* x;
+    const float* u;
+    const float* scale;
+    const float* shift;
+    float* out;
+    unsigned x_bytes, u_bytes;
+    int H, W, ldx, Cout, ldo;
+    int TH, TW, THW, Mt;   // 2x2 output tiles per column / row / image / launch
+    int nbn;               // Cout / 128
+    int nstage;            // Cin / 16
+    unsigned mg_thw, sh_thw, mg_tw, sh_tw;
+    int relu;
+};
+
+constexpr unsigned kOOB = 0x80000000u;
+constexpr int WINO_C2_STRIDE = 272;                  // bytes: 32 tiles x 8 B + 16 B pad (conflict-free b64 writes)
+constexpr int WINO_F_STRIDE = 8 * WINO_C2_STRIDE;    // 8 channel pairs per stage
+constexpr int WINO_BUF = 16 * WINO_F_STRIDE;         // 34816 B per stage buffer
+
+__device__ __forceinline__ int wino_div(int n, int d, unsigned mg, unsigned sh) {
+    return d == 1 ? n : (int)(__umulhi((unsigned)n, mg) >> sh);
+}
+
+__global__ void __launch_bounds__(256) conv_wino_f32_kernel(const WArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- XCD-aware tile order: XCD x keeps one co block column (its U slice stays in its L2) ----
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q8 = nblk >> 3, r8 = nblk & 7;
+    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int nbm = nblk / p.nbn;
+    const int tile_n = L / nbm, tile_m = L - tile_n * nbm;
+    const int m0 = tile_m * 32;
+
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
+
+    // ---- loader role: thread = (tile tl, channel pair c2l) ------------------------------------
+    const int c2l = tid & 7, tl = tid >> 3;
+    unsigned a_voff[16];
+    {
+        const int t = m0 + tl;
+        const bool ok = t < p.Mt;
+        const int tt = ok ? t : 0;
+        const int b = wino_div(tt, p.THW, p.mg_thw, p.sh_thw);
+        const int rem = tt - b * p.THW;
+        const int ty = wino_div(rem, p.TW, p.mg_tw, p.sh_tw);
+        const int tx = rem - ty * p.TW;
+        const int iy0 = 2 * ty - 1, ix0 = 2 * tx - 1;
+        const int pix0 = (b * p.H + iy0) * p.W + ix0;
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                const bool in = ok && (unsigned)(iy0 + dy) < (unsigned)p.H && (unsigned)(ix0 + dx) < (unsigned)p.W;
+                a_voff[dy * 4 + dx] = in ? (unsigned)((pix0 + dy * p.W + dx) * p.ldx * 4 + c2l * 8) : kOOB;
+            }
+    }
+    f32x2 raw[16];
+    auto load_raw1 = [&](int st, int q) {
+        raw[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrs, a_voff[q], (unsigned)(st * 64), 0));
+    };
+    // V = B^T d B on both channels of the pair at once (packed fp32 adds), cut into 16 pieces so that
+    // the K loop can slot one piece under each MFMA pair: pieces 0-7 = row pass, 8-15 = column pass +
+    // the LDS writes of one half row of frequencies.
+    f32x2 T[16];
+    char* const vw_base = smem + c2l * WINO_C2_STRIDE + tl * 8;
+    auto transform_piece = [&](int s, char* dst) {
+        if (s < 8) {
+            const int j = s >> 1;
+            if ((s & 1) == 0) {
+                T[0 + j] = raw[0 + j] - raw[8 + j];
+                T[4 + j] = raw[4 + j] + raw[8 + j];
+            } else {
+                T[8 + j] = raw[8 + j] - raw[4 + j];
+                T[12 + j] = raw[4 + j] - raw[12 + j];
+            }
+        } else {
+            const int i = (s - 8) >> 1;
+            if ((s & 1) == 0) {
+                *reinterpret_cast<f32x2*>(dst + (4 * i + 0) * WINO_F_STRIDE) = T[4 * i + 0] - T[4 * i + 2];
+                *reinterpret_cast<f32x2*>(dst + (4 * i + 1) * WINO_F_STRIDE) = T[4 * i + 1] + T[4 * i + 2];
+            } else {
+                *reinterpret_cast<f32x2*>(dst + (4 * i + 2) * WINO_F_STRIDE) = T[4 * i + 2] - T[4 * i + 1];
+                *reinterpret_cast<f32x2*>(dst + (4 * i + 3) * WINO_F_STRIDE) = T[4 * i + 1] - T[4 * i + 3];
+            }
+        }
+    };
+
+    // ---- consumer role: wave = co block, lane = (tile row l31 / co column l31, k half hh) -------
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int nb = tile_n * 4 + wave;
+    const int nmu = p.nstage * 4;
+    const unsigned u_voff = (unsigned)(lane * 8);
+    const unsigned u_block = (unsigned)(nb * nmu) * 8192u;   // bytes: 16 f x 64 lanes x 8 B per micro-chunk
+    f32x2 bq[16];
+    auto load_u = [&](int mu, int f) {
+        bq[f] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(urs, u_voff, u_block + (unsigned)(mu * 8192 + f * 512), 0));
+    };
+    const char* const vr_base = smem + hh * WINO_C2_STRIDE + l31 * 8;
+    auto read_a = [&](const char* vr, int u, int f) {
+        return *reinterpret_cast<const f32x2*>(vr + f * WINO_F_STRIDE + u * 2 * WINO_C2_STRIDE);
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    // ---- prologue --------------------------------------------------------------------------
+#pragma unroll
+    for (int q = 0; q < 16; ++q) load_raw1(0, q);
+#pragma unroll
+    for (int f = 0; f < 16; ++f) load_u(0, f);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) transform_piece(s, vw_base);
+    {
+        const int st1 = p.nstage > 1 ? 1 : 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) load_raw1(st1, q);
+    }
+    __syncthreads();
+    f32x2 af[2][16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f) af[0][f] = read_a(vr_base, 0, f);
+
+    // ---- K loop, hand-scheduled -------------------------------------------------------------
+    // A wave issues in order and an fp32 MFMA holds the matrix pipe for 64 cycles, so whatever sits
+    // between two MFMA pairs in program order runs under them.  One stage = 4 micro-chunks x 16
+    // steps; step (u, f) = the two MFMAs of frequency f plus one slice of everything else:
+    //   every step : stream U(mu+1, f) into the registers just consumed, fetch the A fragment of
+    //                frequency f for the next micro-chunk
+    //   u == 1     : one piece of the input transform of stage st+1 (writes V into the next buffer)
+    //   u == 2     : one raw patch load of stage st+2
+    // V is triple buffered: the single barrier of a stage sits after u == 2, so micro-chunk 3 already
+    // prefetches the first fragments of stage st+1 and no wave ever waits on LDS after a barrier.
+    int o_cur = 0, o_nxt = WINO_BUF, o_nn = 2 * WINO_BUF;
+    for (int st = 0; st < p.nstage; ++st) {
+        const char* vr_cur = vr_base + o_cur;
+        const char* vr_nxt = vr_base + o_nxt;
+        char* vw_nxt = vw_base + o_nxt;
+        const int st2 = st + 2 < p.nstage ? st + 2 : p.nstage - 1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int mu = st * 4 + u;
+            const int mu1 = mu + 1 < nmu ? mu + 1 : nmu - 1;
+#pragma unroll
+            for (int f = 0; f < 16; ++f) {
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u & 1][f][0], bq[f][0], acc[f], 0, 0, 0);
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u & 1][f][1], bq[f][1], acc[f], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                load_u(mu1, f);
+                af[(u + 1) & 1][f] = (u < 3) ? read_a(vr_cur, u + 1, f) : read_a(vr_nxt, 0, f);
+                if (u == 1) transform_piece(f, vw_nxt);
+                if (u == 2) load_raw1(st2, f);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (u == 2) __syncthreads();
+        }
+        const int t = o_cur; o_cur = o_nxt; o_nxt = o_nn; o_nn = t;
+    }
+
+    // ---- epilogue: lane-local output transform, BN scale/shift, ReLU, store -------------------
+    const int co = nb * 32 + l31;
+    const float sc = p.scale[co], sh = p.shift[co];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int t = m0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        float S[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            S[0][j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
+            S[1][j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+        }
+        float Y[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            Y[i][0] = S[i][0] + S[i][1] + S[i][2];
+            Y[i][1] = S[i][1] - S[i][2] - S[i][3];
+        }
+        if (t >= p.Mt) continue;
+        const int b = wino_div(t, p.THW, p.mg_thw, p.sh_thw);
+        const int rem = t - b * p.THW;
+        const int ty = wino_div(rem, p.TW, p.mg_tw, p.sh_tw);
+        const int tx = rem - ty * p.TW;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int y = 2 * ty + i, x = 2 * tx + j;
+                if (y < p.H && x < p.W) {
+                    float v = fmaf(Y[i][j], sc, sh);
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    p.out[((size_t)(b * p.H + y) * p.W + x) * p.ldo + co] = v;
+                }
+            }
+    }
+}
+
+static void wino_magic(unsigned d, unsigned* mg, unsigned* sh) {
+    if (d < 2) { *mg = 0; *sh = 0; return; }
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    const unsigned L = 31 + s;
+    *mg = (unsigned)((1ull << L) / d + 1ull);
+    *sh = L - 32;
+}
+
+bool conv_wino_supported(const ConvArgs& a) {
+    return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Cin % 16 == 0 && a.Cout % 128 == 0 &&
+           a.ldx % 2 == 0 && !a.res && a.OH == a.H && a.OW == a.W;
+}
+
+// OIHW (cout, cin, 3, 3) -> U = G g G^T packed [cout/32][cin/4][f = 4i+j][h][n][jj], ci = 4*mu + 2*h + jj
+void pack_wino_weights(const float* w, int cout, int cin, std::vector<float>& out) {
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    out.assign((size_t)16 * cin * cout, 0.f);
+    const int nmu = cin / 4;
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            const float* g = w + ((size_t)co * cin + ci) * 9;
+            double Gg[4][3];
+            for (int i = 0; i < 4; ++i)
+                for (int b = 0; b < 3; ++b) Gg[i][b] = G[i][0] * g[0 * 3 + b] + G[i][1] * g[1 * 3 + b] + G[i][2] * g[2 * 3 + b];
+            const int nb = co / 32, n = co % 32, mu = ci / 4, h = (ci % 4) / 2, jj = ci % 2;
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) {
+                    const double uij = Gg[i][0] * G[j][0] + Gg[i][1] * G[j][1] + Gg[i][2] * G[j][2];
+                    const int f = 4 * i + j;
+                    out[((((size_t)nb * nmu + mu) * 16 + f) * 2 + h) * 64 + n * 2 + jj] = (float)uij;
+                }
+        }
+}
+
+static int wino_launch_one(const ConvArgs& a, const LaunchCtx& ctx) {
+    WArgs k;
+    k.x = a.x; k.u = a.w; k.scale = a.scale; k.shift = a.shift; k.out = a.out;
+    k.H = a.H; k.W = a.W; k.ldx = a.ldx; k.Cout = a.Cout; k.ldo = a.ldo;
+    k.TH = (a.H + 1) / 2; k.TW = (a.W + 1) / 2; k.THW = k.TH * k.TW;
+    k.Mt = a.B * k.THW;
+    k.nbn = a.Cout / 128;
+    k.nstage = a.Cin / 16;
+    k.relu = a.relu;
+    wino_magic((unsigned)k.THW, &k.mg_thw, &k.sh_thw);
+    wino_magic((unsigned)k.TW, &k.mg_tw, &k.sh_tw);
+    k.x_bytes = (unsigned)((size_t)a.B * a.H * a.W * a.ldx * 4);
+    k.u_bytes = (unsigned)((size_t)16 * a.Cin * a.Cout * 4);
+    constexpr int smem = 3 * WINO_BUF;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_f32_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int nbm = (k.Mt + 31) / 32;
+    const double M = (double)a.B * a.H * a.W;
+    const double flops = 2.0 * M * a.Cout * 9.0 * a.Cin;   // algorithmic (direct-convolution) flops
+    const double bytes = 4.0 * (M * a.Cin + M * a.Cout + 9.0 * a.Cin * a.Cout);
+    ProfScope ps(ctx, "conv_wino_f32<32t x128,F(2x2,3x3)>", flops, bytes);
+    hipLaunchKernelGGL(conv_wino_f32_kernel, dim3(nbm * k.nbn), dim3(256), smem, ctx.stream, k);
+    return (int)hipGetLastError();
+}
+
+int launch_conv_wino(const ConvArgs& a, const LaunchCtx& ctx) {
+    if (!conv_wino_supported(a) || (reinterpret_cast<uintptr_t>(a.x) & 7)) return (int)hipErrorInvalidValue;
+    const size_t img_bytes = (size_t)a.H * a.W * a.ldx * 4;
+    const size_t limit = (size_t)1 << 31;
+    if (img_bytes >= limit || (size_t)16 * a.Cin * a.Cout * 4 >= limit) return (int)hipErrorInvalidValue;
+    const int max_b = (int)((limit - 1) / img_bytes);
+    for (int b0 = 0; b0 < a.B; b0 += max_b) {
+        ConvArgs s = a;
+        s.B = (a.B - b0 < max_b) ? a.B - b0 : max_b;
+        s.x = a.x + (size_t)b0 * a.H * a.W * a.ldx;
+        s.out = a.out + (size_t)b0 * a.OH * a.OW * a.ldo;
+        const int rc = wino_launch_one(s, ctx);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+}  // namespace specmi

@@ -59,9 +59,11 @@ def test_conv_layer_parity(eng, shape, variant):
     use_res = (k == 1 and cout >= 4 * cin // 2)
     res = torch.randn(B, oh, oh, cout, generator=g) if use_res else None
     eng.set_option('force_conv_variant', variant)
+    eng.set_option('winograd', 1 if variant == 0 else 0)   # variant 0 = what the trunk runs; 1-3 = direct tiles
     y = eng.conv2d(x.to(DEV), w.numpy(), sc.numpy(), sh.numpy(), stride, pad,
                    residual=None if res is None else res.to(DEV), relu=True).cpu()
     eng.set_option('force_conv_variant', 0)
+    eng.set_option('winograd', 1)
     ref = _conv_ref(x, w, sc, sh, stride, pad, res, True)
     assert y.shape == ref.shape
     err = rel_err(y.numpy(), ref.numpy())
@@ -83,6 +85,44 @@ def test_conv_ragged_sizes_and_tiles(eng, B, H, W):
             ref = _conv_ref(x, w, sc, sh, stride, pad, None, False)
             assert rel_err(y.numpy(), ref.numpy()) < 2e-5
     eng.set_option('force_conv_variant', 0)
+
+
+@pytest.mark.parametrize('B,H,W', [(1, 7, 7), (3, 7, 9), (5, 5, 3), (2, 14, 14), (1, 56, 40), (7, 1, 1), (2, 2, 33)])
+@pytest.mark.parametrize('cin,cout', [(16, 128), (48, 384), (128, 128)])
+def test_conv_winograd_ragged(eng, B, H, W, cin, cout):
+    """Fused Winograd F(2x2,3x3) path: odd sizes (half-empty edge tiles), tile count not a multiple of
+    the 32-tile workgroup, one and several 16-channel stages, several co blocks; against the fp32
+    direct convolution of PyTorch-CPU AND against this library's own direct implicit GEMM."""
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + W + cin)
+    x = torch.randn(B, H, W, cin, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    sc = torch.rand(cout, generator=g) + 0.5
+    sh = torch.randn(cout, generator=g) * 0.1
+    for relu in (False, True):
+        eng.set_option('winograd', 1)
+        y = eng.conv2d(x.to(DEV), w.numpy(), sc.numpy(), sh.numpy(), 1, 1, relu=relu).cpu()
+        ref = _conv_ref(x, w, sc, sh, 1, 1, None, relu)
+        assert y.shape == ref.shape
+        assert rel_err(y.numpy(), ref.numpy()) < 2e-5
+        if cin % 32 == 0:
+            eng.set_option('winograd', 0)
+            yd = eng.conv2d(x.to(DEV), w.numpy(), sc.numpy(), sh.numpy(), 1, 1, relu=relu).cpu()
+            eng.set_option('winograd', 1)
+            assert rel_err(y.numpy(), yd.numpy()) < 2e-5
+
+
+def test_conv_winograd_kernel_is_used(eng):
+    """The profiler names the kernel each launch ran: 3x3/s1 with Cout % 128 == 0 must hit conv_wino."""
+    x = torch.randn(1, 8, 8, 32)
+    w = torch.randn(128, 32, 3, 3) * 0.05
+    eng.profile(True)
+    eng.conv2d(x.to(DEV), w.numpy(), np.ones(128, np.float32), np.zeros(128, np.float32), 1, 1, relu=False)
+    eng.set_option('winograd', 0)
+    eng.conv2d(x.to(DEV), w.numpy(), np.ones(128, np.float32), np.zeros(128, np.float32), 1, 1, relu=False)
+    eng.set_option('winograd', 1)
+    names = [e['kernel'] for e in eng.profile_read()]
+    eng.profile(False)
+    assert any('conv_wino' in n for n in names) and any('conv_igemm' in n for n in names), names
 
 
 def test_conv_identity_asymmetric(eng):
