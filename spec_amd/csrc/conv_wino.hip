@@ -57,10 +57,21 @@ __device__ __forceinline__ int wino_div(int n, int d, unsigned mg, unsigned sh) 
     return d == 1 ? n : (int)(__umulhi((unsigned)n, mg) >> sh);
 }
 
-__global__ void __launch_bounds__(256) conv_wino_f32_kernel(const WArgs p) {
+// NF = frequencies per wave.
+//   NF == 16: workgroup = 32 tiles x 128 co, wave w = co block w, all frequencies (256 accumulator
+//             registers, one wave per SIMD), V triple buffered.
+//   NF == 8 : workgroup = 32 tiles x 64 co, wave = (co block w & 1, frequency columns j in {2fh, 2fh+1}
+//             with fh = w >> 1): 128 accumulator registers, two workgroups per CU, V double buffered;
+//             the two frequency halves of a co block meet in the output transform through LDS.
+template <int NF>
+__global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(const WArgs p) {
+    constexpr int NWN = NF == 16 ? 4 : 2;          // co blocks (of 32) per workgroup
+    constexpr bool TRIPLE = NF == 16;
+    constexpr int SPS = 16 / NF;                    // loader pieces per MFMA step
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nbw = wave % NWN, fh = wave / NWN;
 
     // ---- XCD-aware tile order: XCD x keeps one co block column (its U slice stays in its L2) ----
     const int nblk = gridDim.x, bid = blockIdx.x;
@@ -99,8 +110,8 @@ __global__ void __launch_bounds__(256) conv_wino_f32_kernel(const WArgs p) {
         raw[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrs, a_voff[q], (unsigned)(st * 64), 0));
     };
     // V = B^T d B on both channels of the pair at once (packed fp32 adds), cut into 16 pieces so that
-    // the K loop can slot one piece under each MFMA pair: pieces 0-7 = row pass, 8-15 = column pass +
-    // the LDS writes of one half row of frequencies.
+    // the K loop can slot them under the MFMAs: pieces 0-7 = row pass, 8-15 = column pass + the LDS
+    // writes of one half row of frequencies.
     f32x2 T[16];
     char* const vw_base = smem + c2l * WINO_C2_STRIDE + tl * 8;
     auto transform_piece = [&](int s, char* dst) {
@@ -125,24 +136,26 @@ __global__ void __launch_bounds__(256) conv_wino_f32_kernel(const WArgs p) {
         }
     };
 
-    // ---- consumer role: wave = co block, lane = (tile row l31 / co column l31, k half hh) -------
+    // ---- consumer role: lane = (tile row l31 / co column l31, k half hh) ------------------------
+    // local frequency fl -> f = 4i + j:  NF == 16: f = fl;  NF == 8: i = fl >> 1, j = 2 fh + (fl & 1)
+    auto f_of = [](int fl) { return NF == 16 ? fl : 4 * (fl >> 1) + (fl & 1); };
     const int l31 = lane & 31, hh = lane >> 5;
-    const int nb = tile_n * 4 + wave;
+    const int nb = tile_n * NWN + nbw;
     const int nmu = p.nstage * 4;
     const unsigned u_voff = (unsigned)(lane * 8);
-    const unsigned u_block = (unsigned)(nb * nmu) * 8192u;   // bytes: 16 f x 64 lanes x 8 B per micro-chunk
-    f32x2 bq[16];
-    auto load_u = [&](int mu, int f) {
-        bq[f] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(urs, u_voff, u_block + (unsigned)(mu * 8192 + f * 512), 0));
+    const unsigned u_block = (unsigned)(nb * nmu) * 8192u + (unsigned)(fh * 2 * 512);   // 16 f x 512 B per micro-chunk
+    f32x2 bq[NF];
+    auto load_u = [&](int mu, int fl) {
+        bq[fl] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(urs, u_voff, u_block + (unsigned)(mu * 8192 + f_of(fl) * 512), 0));
     };
-    const char* const vr_base = smem + hh * WINO_C2_STRIDE + l31 * 8;
-    auto read_a = [&](const char* vr, int u, int f) {
-        return *reinterpret_cast<const f32x2*>(vr + f * WINO_F_STRIDE + u * 2 * WINO_C2_STRIDE);
+    const char* const vr_base = smem + hh * WINO_C2_STRIDE + l31 * 8 + fh * 2 * WINO_F_STRIDE;
+    auto read_a = [&](const char* vr, int u, int fl) {
+        return *reinterpret_cast<const f32x2*>(vr + f_of(fl) * WINO_F_STRIDE + u * 2 * WINO_C2_STRIDE);
     };
 
-    f32x16 acc[16];
+    f32x16 acc[NF];
 #pragma unroll
-    for (int f = 0; f < 16; ++f)
+    for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
 
@@ -150,7 +163,7 @@ __global__ void __launch_bounds__(256) conv_wino_f32_kernel(const WArgs p) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) load_raw1(0, q);
 #pragma unroll
-    for (int f = 0; f < 16; ++f) load_u(0, f);
+    for (int f = 0; f < NF; ++f) load_u(0, f);
 #pragma unroll
     for (int s = 0; s < 16; ++s) transform_piece(s, vw_base);
     {
@@ -159,21 +172,22 @@ __global__ void __launch_bounds__(256) conv_wino_f32_kernel(const WArgs p) {
         for (int q = 0; q < 16; ++q) load_raw1(st1, q);
     }
     __syncthreads();
-    f32x2 af[2][16];
+    f32x2 af[2][NF];
 #pragma unroll
-    for (int f = 0; f < 16; ++f) af[0][f] = read_a(vr_base, 0, f);
+    for (int f = 0; f < NF; ++f) af[0][f] = read_a(vr_base, 0, f);
 
     // ---- K loop, hand-scheduled -------------------------------------------------------------
     // A wave issues in order and an fp32 MFMA holds the matrix pipe for 64 cycles, so whatever sits
-    // between two MFMA pairs in program order runs under them.  One stage = 4 micro-chunks x 16
-    // steps; step (u, f) = the two MFMAs of frequency f plus one slice of everything else:
+    // between two MFMA pairs in program order runs under them.  One stage = 4 micro-chunks x NF
+    // steps; step (u, fl) = the two MFMAs of one frequency plus one slice of everything else:
     //   every step : stream U(mu+1, f) into the registers just consumed, fetch the A fragment of
-    //                frequency f for the next micro-chunk
-    //   u == 1     : one piece of the input transform of stage st+1 (writes V into the next buffer)
-    //   u == 2     : one raw patch load of stage st+2
-    // V is triple buffered: the single barrier of a stage sits after u == 2, so micro-chunk 3 already
-    // prefetches the first fragments of stage st+1 and no wave ever waits on LDS after a barrier.
-    int o_cur = 0, o_nxt = WINO_BUF, o_nn = 2 * WINO_BUF;
+    //                the same frequency for the next micro-chunk
+    //   u == 1     : pieces of the input transform of stage st+1 (writes V into the next buffer)
+    //   u == 2     : raw patch loads of stage st+2
+    // TRIPLE: the single barrier of a stage sits after u == 2, so micro-chunk 3 already prefetches the
+    // first fragments of stage st+1 and no wave waits on LDS after a barrier.  Otherwise (two
+    // workgroups per CU cover for each other) the barrier closes the stage.
+    int o_cur = 0, o_nxt = WINO_BUF, o_nn = TRIPLE ? 2 * WINO_BUF : 0;
     for (int st = 0; st < p.nstage; ++st) {
         const char* vr_cur = vr_base + o_cur;
         const char* vr_nxt = vr_base + o_nxt;
@@ -184,55 +198,102 @@ __global__ void __launch_bounds__(256) conv_wino_f32_kernel(const WArgs p) {
             const int mu = st * 4 + u;
             const int mu1 = mu + 1 < nmu ? mu + 1 : nmu - 1;
 #pragma unroll
-            for (int f = 0; f < 16; ++f) {
-                acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u & 1][f][0], bq[f][0], acc[f], 0, 0, 0);
-                acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u & 1][f][1], bq[f][1], acc[f], 0, 0, 0);
+            for (int fl = 0; fl < NF; ++fl) {
+                acc[fl] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u & 1][fl][0], bq[fl][0], acc[fl], 0, 0, 0);
+                acc[fl] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u & 1][fl][1], bq[fl][1], acc[fl], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                load_u(mu1, f);
-                af[(u + 1) & 1][f] = (u < 3) ? read_a(vr_cur, u + 1, f) : read_a(vr_nxt, 0, f);
-                if (u == 1) transform_piece(f, vw_nxt);
-                if (u == 2) load_raw1(st2, f);
+                load_u(mu1, fl);
+                if (u < 3) af[(u + 1) & 1][fl] = read_a(vr_cur, u + 1, fl);
+                else if (TRIPLE) af[0][fl] = read_a(vr_nxt, 0, fl);
+                if (u == 1) {
+#pragma unroll
+                    for (int k = 0; k < SPS; ++k) transform_piece(fl * SPS + k, vw_nxt);
+                }
+                if (u == 2) {
+#pragma unroll
+                    for (int k = 0; k < SPS; ++k) load_raw1(st2, fl * SPS + k);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (u == 2) __syncthreads();
+            if (TRIPLE && u == 2) __syncthreads();
         }
-        const int t = o_cur; o_cur = o_nxt; o_nxt = o_nn; o_nn = t;
+        if (!TRIPLE) {
+            __syncthreads();
+#pragma unroll
+            for (int fl = 0; fl < NF; ++fl) af[0][fl] = read_a(vr_nxt, 0, fl);
+        }
+        const int t = o_cur; o_cur = o_nxt; o_nxt = TRIPLE ? o_nn : t; o_nn = t;
     }
 
     // ---- epilogue: lane-local output transform, BN scale/shift, ReLU, store -------------------
     const int co = nb * 32 + l31;
     const float sc = p.scale[co], sh = p.shift[co];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int t = m0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        float S[2][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            S[0][j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
-            S[1][j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
-        }
-        float Y[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            Y[i][0] = S[i][0] + S[i][1] + S[i][2];
-            Y[i][1] = S[i][1] - S[i][2] - S[i][3];
-        }
-        if (t >= p.Mt) continue;
-        const int b = wino_div(t, p.THW, p.mg_thw, p.sh_thw);
+    auto tile_pix = [&](int t, int& b, int& ty, int& tx) {
+        b = wino_div(t, p.THW, p.mg_thw, p.sh_thw);
         const int rem = t - b * p.THW;
-        const int ty = wino_div(rem, p.TW, p.mg_tw, p.sh_tw);
-        const int tx = rem - ty * p.TW;
+        ty = wino_div(rem, p.TW, p.mg_tw, p.sh_tw);
+        tx = rem - ty * p.TW;
+    };
+    auto emit = [&](float v, int b, int y, int x) {
+        if (y < p.H && x < p.W) {
+            v = fmaf(v, sc, sh);
+            if (p.relu) v = fmaxf(v, 0.f);
+            p.out[((size_t)(b * p.H + y) * p.W + x) * p.ldo + co] = v;
+        }
+    };
+    if (NF == 16) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int r = 0; r < 16; ++r) {
+            const int t = m0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            float S[2][4];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int y = 2 * ty + i, x = 2 * tx + j;
-                if (y < p.H && x < p.W) {
-                    float v = fmaf(Y[i][j], sc, sh);
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    p.out[((size_t)(b * p.H + y) * p.W + x) * p.ldo + co] = v;
-                }
+            for (int j = 0; j < 4; ++j) {
+                S[0][j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
+                S[1][j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
             }
+            if (t >= p.Mt) continue;
+            int b, ty, tx;
+            tile_pix(t, b, ty, tx);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                emit(S[i][0] + S[i][1] + S[i][2], b, 2 * ty + i, 2 * tx);
+                emit(S[i][1] - S[i][2] - S[i][3], b, 2 * ty + i, 2 * tx + 1);
+            }
+        }
+    } else {
+        // This wave holds D[i][j] for j in {2fh, 2fh+1} (acc[2i + jl]).  Y[a][0] = S[a][0]+S[a][1]+S[a][2],
+        // Y[a][1] = S[a][1]-S[a][2]-S[a][3] with S = row transform (lane-local): the fh = 0 wave finishes
+        // output column 0 and needs S[a][2] from its partner; the fh = 1 wave finishes column 1 and
+        // needs S[a][1].  32 floats per lane cross through LDS (the stage buffers are idle by now).
+        float* xch = reinterpret_cast<float*>(smem);
+        float mine[16][2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float S[2][2];
+#pragma unroll
+            for (int jl = 0; jl < 2; ++jl) {
+                S[0][jl] = acc[0 + jl][r] + acc[2 + jl][r] + acc[4 + jl][r];
+                S[1][jl] = acc[2 + jl][r] - acc[4 + jl][r] - acc[6 + jl][r];
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                // fh == 0: keep S0+S1 (for Y[a][0]), send S1 (for Y[a][1]);  fh == 1: keep -S2-S3, send S2
+                mine[r][a] = fh == 0 ? S[a][0] + S[a][1] : -S[a][0] - S[a][1];
+                xch[((wave * 16 + r) * 2 + a) * 64 + lane] = fh == 0 ? S[a][1] : S[a][0];
+            }
+        }
+        __syncthreads();
+        const int partner = wave ^ NWN;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = m0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (t >= p.Mt) continue;
+            int b, ty, tx;
+            tile_pix(t, b, ty, tx);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+                emit(mine[r][a] + xch[((partner * 16 + r) * 2 + a) * 64 + lane], b, 2 * ty + a, 2 * tx + fh);
+        }
     }
 }
 
@@ -246,7 +307,7 @@ static void wino_magic(unsigned d, unsigned* mg, unsigned* sh) {
 }
 
 bool conv_wino_supported(const ConvArgs& a) {
-    return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Cin % 16 == 0 && a.Cout % 128 == 0 &&
+    return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Cin % 16 == 0 && a.Cout % 64 == 0 &&
            a.ldx % 2 == 0 && !a.res && a.OH == a.H && a.OW == a.W;
 }
 
@@ -271,34 +332,54 @@ void pack_wino_weights(const float* w, int cout, int cin, std::vector<float>& ou
         }
 }
 
+static int g_wino_variant = 0;   // 0 auto, 16 / 8 = force the frequencies-per-wave variant
+void conv_wino_force_variant(int v) { g_wino_variant = v; }
+
+static int wino_pick(const ConvArgs& a) {
+    if (g_wino_variant == 8) return 8;
+    if (g_wino_variant == 16 && a.Cout % 128 == 0) return 16;
+    // Measured on MI355X at B=256 (tools/wino_bench): two 128-accumulator waves per SIMD cover each other's
+    // prologue / epilogue and win by ~10 % up to Cin = 256; from Cin = 512 (32 stages per tile) the
+    // 128-channel workgroup (half the A traffic per MFMA) is ahead.
+    return (a.Cout % 128 == 0 && a.Cin >= 512) ? 16 : 8;
+}
+
+template <int NF>
+static int wino_launch_variant(WArgs k, int Cout, const LaunchCtx& ctx, double flops, double bytes) {
+    constexpr int NT = NF == 16 ? 128 : 64;
+    constexpr int smem = (NF == 16 ? 3 : 2) * WINO_BUF;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_f32_kernel<NF>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    k.nbn = Cout / NT;
+    const int nbm = (k.Mt + 31) / 32;
+    ProfScope ps(ctx, NF == 16 ? "conv_wino_f32<32t x128,F(2x2,3x3)>" : "conv_wino_f32<32t x64,F(2x2,3x3)>", flops, bytes);
+    hipLaunchKernelGGL(conv_wino_f32_kernel<NF>, dim3(nbm * k.nbn), dim3(256), smem, ctx.stream, k);
+    return (int)hipGetLastError();
+}
+
 static int wino_launch_one(const ConvArgs& a, const LaunchCtx& ctx) {
     WArgs k;
     k.x = a.x; k.u = a.w; k.scale = a.scale; k.shift = a.shift; k.out = a.out;
     k.H = a.H; k.W = a.W; k.ldx = a.ldx; k.Cout = a.Cout; k.ldo = a.ldo;
     k.TH = (a.H + 1) / 2; k.TW = (a.W + 1) / 2; k.THW = k.TH * k.TW;
     k.Mt = a.B * k.THW;
-    k.nbn = a.Cout / 128;
+    k.nbn = 0;
     k.nstage = a.Cin / 16;
     k.relu = a.relu;
     wino_magic((unsigned)k.THW, &k.mg_thw, &k.sh_thw);
     wino_magic((unsigned)k.TW, &k.mg_tw, &k.sh_tw);
     k.x_bytes = (unsigned)((size_t)a.B * a.H * a.W * a.ldx * 4);
     k.u_bytes = (unsigned)((size_t)16 * a.Cin * a.Cout * 4);
-    constexpr int smem = 3 * WINO_BUF;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_f32_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    const int nbm = (k.Mt + 31) / 32;
     const double M = (double)a.B * a.H * a.W;
     const double flops = 2.0 * M * a.Cout * 9.0 * a.Cin;   // algorithmic (direct-convolution) flops
     const double bytes = 4.0 * (M * a.Cin + M * a.Cout + 9.0 * a.Cin * a.Cout);
-    ProfScope ps(ctx, "conv_wino_f32<32t x128,F(2x2,3x3)>", flops, bytes);
-    hipLaunchKernelGGL(conv_wino_f32_kernel, dim3(nbm * k.nbn), dim3(256), smem, ctx.stream, k);
-    return (int)hipGetLastError();
+    return wino_pick(a) == 16 ? wino_launch_variant<16>(k, a.Cout, ctx, flops, bytes)
+                              : wino_launch_variant<8>(k, a.Cout, ctx, flops, bytes);
 }
 
 int launch_conv_wino(const ConvArgs& a, const LaunchCtx& ctx) {

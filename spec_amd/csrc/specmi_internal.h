@@ -79,10 +79,11 @@ const char* conv_igemm_variant(const ConvArgs& a);
 // ----------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution as Winograd F(2x2,3x3) on fp32 MFMA  (conv_wino.hip)
 // ----------------------------------------------------------------------------------------
-// a.w must point at pack_wino_weights() output; Cin % 16 == 0, Cout % 128 == 0, no residual.
+// a.w must point at pack_wino_weights() output; Cin % 16 == 0, Cout % 64 == 0, no residual.
 bool conv_wino_supported(const ConvArgs& a);
 void pack_wino_weights(const float* w_oihw, int cout, int cin, std::vector<float>& out);
 int launch_conv_wino(const ConvArgs& a, const LaunchCtx& ctx);
+void conv_wino_force_variant(int nf);   // 0 auto, 16 / 8 frequencies per wave (tests, tuning)
 
 // ----------------------------------------------------------------------------------------
 // stem + pooling  (stem.hip)

@@ -88,10 +88,10 @@ def test_conv_ragged_sizes_and_tiles(eng, B, H, W):
 
 
 @pytest.mark.parametrize('B,H,W', [(1, 7, 7), (3, 7, 9), (5, 5, 3), (2, 14, 14), (1, 56, 40), (7, 1, 1), (2, 2, 33)])
-@pytest.mark.parametrize('cin,cout', [(16, 128), (48, 384), (128, 128)])
-def test_conv_winograd_ragged(eng, B, H, W, cin, cout):
+@pytest.mark.parametrize('cin,cout,nf', [(16, 128, 16), (48, 384, 8), (128, 128, 0), (32, 64, 0), (64, 192, 0), (512, 128, 0)])
+def test_conv_winograd_ragged(eng, B, H, W, cin, cout, nf):
     """Fused Winograd F(2x2,3x3) path: odd sizes (half-empty edge tiles), tile count not a multiple of
-    the 32-tile workgroup, one and several 16-channel stages, several co blocks; against the fp32
+    the 32-tile workgroup, one and several 16-channel stages, several co blocks, both wave layouts; against the fp32
     direct convolution of PyTorch-CPU AND against this library's own direct implicit GEMM."""
     g = torch.Generator().manual_seed(B * 1000 + H * 10 + W + cin)
     x = torch.randn(B, H, W, cin, generator=g)
@@ -100,7 +100,9 @@ def test_conv_winograd_ragged(eng, B, H, W, cin, cout):
     sh = torch.randn(cout, generator=g) * 0.1
     for relu in (False, True):
         eng.set_option('winograd', 1)
+        eng.set_option('force_wino_variant', nf)   # 16 / 8 frequencies per wave, 0 = the launcher's choice
         y = eng.conv2d(x.to(DEV), w.numpy(), sc.numpy(), sh.numpy(), 1, 1, relu=relu).cpu()
+        eng.set_option('force_wino_variant', 0)
         ref = _conv_ref(x, w, sc, sh, 1, 1, None, relu)
         assert y.shape == ref.shape
         assert rel_err(y.numpy(), ref.numpy()) < 2e-5

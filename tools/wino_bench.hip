@@ -40,9 +40,13 @@ int main(int argc, char** argv) {
     int B = argc > 1 ? atoi(argv[1]) : 256;
     int check = argc > 2 ? atoi(argv[2]) : 1;
     int only = argc > 3 ? atoi(argv[3]) : -1;
+    int variant = argc > 4 ? atoi(argv[4]) : 0;
+    conv_wino_force_variant(variant);
     std::vector<Layer> layers = {
         {"odd      3x3  16->128  7x9 ", 16, 128, 7, 9, 0, 3},
         {"odd2     3x3  32->256  5x3 ", 32, 256, 5, 3, 0, 5},
+        {"odd3     3x3  48->64   9x7 ", 48, 64, 9, 7, 0, 4},
+        {"l1.conv2 3x3  64->64  56   ", 64, 64, 56, 56, 3, 0},
         {"l2.conv2 3x3 128->128 28   ", 128, 128, 28, 28, 3, 0},
         {"l3.conv2 3x3 256->256 14   ", 256, 256, 14, 14, 5, 0},
         {"l4.conv2 3x3 512->512 7    ", 512, 512, 7, 7, 2, 0},
