@@ -39,19 +39,23 @@ struct WArgs {
     const float* scale;
     const float* shift;
     float* out;
-    unsigned x_bytes, u_bytes;
+    unsigned x_bytes, u_bytes, out_bytes;
     int H, W, ldx, Cout, ldo;
     int TH, TW, THW, Mt;   // 2x2 output tiles per column / row / image / launch
     int nbn;               // Cout / 128
     int nstage;            // Cin / 16
     unsigned mg_thw, sh_thw, mg_tw, sh_tw;
     int relu;
+#ifdef WINO_PROF
+    unsigned long long* tprof;   // [prologue, loop, epilogue, count] summed s_memtime ticks (wave 0 of each workgroup)
+#endif
 };
 
 constexpr unsigned kOOB = 0x80000000u;
 constexpr int WINO_C2_STRIDE = 272;                  // bytes: 32 tiles x 8 B + 16 B pad (conflict-free b64 writes)
 constexpr int WINO_F_STRIDE = 8 * WINO_C2_STRIDE;    // 8 channel pairs per stage
 constexpr int WINO_BUF = 16 * WINO_F_STRIDE;         // 34816 B per stage buffer
+constexpr int WINO_TAB = 32 * 16;                    // per tile: byte offsets of its 2x2 outputs (or out of range)
 
 __device__ __forceinline__ int wino_div(int n, int d, unsigned mg, unsigned sh) {
     return d == 1 ? n : (int)(__umulhi((unsigned)n, mg) >> sh);
@@ -68,7 +72,11 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
     constexpr int NWN = NF == 16 ? 4 : 2;          // co blocks (of 32) per workgroup
     constexpr bool TRIPLE = NF == 16;
     constexpr int SPS = 16 / NF;                    // loader pieces per MFMA step
+    constexpr int UD = NF == 16 ? 1 : 2;            // U prefetch distance in micro-chunks (NF MFMA pairs each)
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef WINO_PROF
+    const long long t_start = __builtin_amdgcn_s_memtime();
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nbw = wave % NWN, fh = wave / NWN;
@@ -104,6 +112,14 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
                 const bool in = ok && (unsigned)(iy0 + dy) < (unsigned)p.H && (unsigned)(ix0 + dx) < (unsigned)p.W;
                 a_voff[dy * 4 + dx] = in ? (unsigned)((pix0 + dy * p.W + dx) * p.ldx * 4 + c2l * 8) : kOOB;
             }
+        // the epilogue's store addresses, decoded once per tile here instead of once per lane there
+        if (c2l < 4) {
+            const int a = c2l >> 1, dx = c2l & 1;
+            const int oy = 2 * ty + a, ox = 2 * tx + dx;
+            const bool in = ok && oy < p.H && ox < p.W;
+            reinterpret_cast<unsigned*>(smem + (TRIPLE ? 3 : 2) * WINO_BUF)[tl * 4 + c2l] =
+                in ? (unsigned)(((b * p.H + oy) * p.W + ox) * p.ldo * 4) : kOOB;
+        }
     }
     f32x2 raw[16];
     auto load_raw1 = [&](int st, int q) {
@@ -144,9 +160,9 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
     const int nmu = p.nstage * 4;
     const unsigned u_voff = (unsigned)(lane * 8);
     const unsigned u_block = (unsigned)(nb * nmu) * 8192u + (unsigned)(fh * 2 * 512);   // 16 f x 512 B per micro-chunk
-    f32x2 bq[NF];
-    auto load_u = [&](int mu, int fl) {
-        bq[fl] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(urs, u_voff, u_block + (unsigned)(mu * 8192 + f_of(fl) * 512), 0));
+    f32x2 bq[UD][NF];
+    auto load_u = [&](int slot, int mu, int fl) {
+        bq[slot][fl] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(urs, u_voff, u_block + (unsigned)(mu * 8192 + f_of(fl) * 512), 0));
     };
     const char* const vr_base = smem + hh * WINO_C2_STRIDE + l31 * 8 + fh * 2 * WINO_F_STRIDE;
     auto read_a = [&](const char* vr, int u, int fl) {
@@ -163,7 +179,9 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
 #pragma unroll
     for (int q = 0; q < 16; ++q) load_raw1(0, q);
 #pragma unroll
-    for (int f = 0; f < NF; ++f) load_u(0, f);
+    for (int d = 0; d < UD; ++d)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) load_u(d, d, f);   // nmu >= 4 > UD
 #pragma unroll
     for (int s = 0; s < 16; ++s) transform_piece(s, vw_base);
     {
@@ -172,21 +190,24 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
         for (int q = 0; q < 16; ++q) load_raw1(st1, q);
     }
     __syncthreads();
-    f32x2 af[2][NF];
+    f32x2 af[NF];
 #pragma unroll
-    for (int f = 0; f < NF; ++f) af[0][f] = read_a(vr_base, 0, f);
+    for (int f = 0; f < NF; ++f) af[f] = read_a(vr_base, 0, f);
 
     // ---- K loop, hand-scheduled -------------------------------------------------------------
     // A wave issues in order and an fp32 MFMA holds the matrix pipe for 64 cycles, so whatever sits
     // between two MFMA pairs in program order runs under them.  One stage = 4 micro-chunks x NF
     // steps; step (u, fl) = the two MFMAs of one frequency plus one slice of everything else:
-    //   every step : stream U(mu+1, f) into the registers just consumed, fetch the A fragment of
-    //                the same frequency for the next micro-chunk
+    //   every step : stream U(mu+1, f) and the A fragment of the next micro-chunk into the registers
+    //                just consumed (rolling: they are needed NF steps later)
     //   u == 1     : pieces of the input transform of stage st+1 (writes V into the next buffer)
     //   u == 2     : raw patch loads of stage st+2
     // TRIPLE: the single barrier of a stage sits after u == 2, so micro-chunk 3 already prefetches the
     // first fragments of stage st+1 and no wave waits on LDS after a barrier.  Otherwise (two
     // workgroups per CU cover for each other) the barrier closes the stage.
+#ifdef WINO_PROF
+    const long long t_loop = __builtin_amdgcn_s_memtime();
+#endif
     int o_cur = 0, o_nxt = WINO_BUF, o_nn = TRIPLE ? 2 * WINO_BUF : 0;
     for (int st = 0; st < p.nstage; ++st) {
         const char* vr_cur = vr_base + o_cur;
@@ -196,15 +217,15 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int mu = st * 4 + u;
-            const int mu1 = mu + 1 < nmu ? mu + 1 : nmu - 1;
+            const int mu1 = mu + UD < nmu ? mu + UD : nmu - 1;
 #pragma unroll
             for (int fl = 0; fl < NF; ++fl) {
-                acc[fl] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u & 1][fl][0], bq[fl][0], acc[fl], 0, 0, 0);
-                acc[fl] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u & 1][fl][1], bq[fl][1], acc[fl], 0, 0, 0);
+                acc[fl] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fl][0], bq[u % UD][fl][0], acc[fl], 0, 0, 0);
+                acc[fl] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fl][1], bq[u % UD][fl][1], acc[fl], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                load_u(mu1, fl);
-                if (u < 3) af[(u + 1) & 1][fl] = read_a(vr_cur, u + 1, fl);
-                else if (TRIPLE) af[0][fl] = read_a(vr_nxt, 0, fl);
+                load_u(u % UD, mu1, fl);
+                if (u < 3) af[fl] = read_a(vr_cur, u + 1, fl);   // rolling: consumed NF steps from now
+                else if (TRIPLE) af[fl] = read_a(vr_nxt, 0, fl);
                 if (u == 1) {
 #pragma unroll
                     for (int k = 0; k < SPS; ++k) transform_piece(fl * SPS + k, vw_nxt);
@@ -220,44 +241,43 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
         if (!TRIPLE) {
             __syncthreads();
 #pragma unroll
-            for (int fl = 0; fl < NF; ++fl) af[0][fl] = read_a(vr_nxt, 0, fl);
+            for (int fl = 0; fl < NF; ++fl) af[fl] = read_a(vr_nxt, 0, fl);
         }
         const int t = o_cur; o_cur = o_nxt; o_nxt = TRIPLE ? o_nn : t; o_nn = t;
     }
 
+#ifdef WINO_PROF
+    const long long t_epi = __builtin_amdgcn_s_memtime();
+#endif
     // ---- epilogue: lane-local output transform, BN scale/shift, ReLU, store -------------------
+    // Accumulator register r of a lane belongs to tile (r & 3) + 8 (r >> 2) + 4 hh: its four output
+    // addresses come from the table the loader threads left in LDS (16 bytes per tile, out-of-range
+    // offset = no store), so an output costs one add, one fma, one max and a buffer store.
     const int co = nb * 32 + l31;
     const float sc = p.scale[co], sh = p.shift[co];
-    auto tile_pix = [&](int t, int& b, int& ty, int& tx) {
-        b = wino_div(t, p.THW, p.mg_thw, p.sh_thw);
-        const int rem = t - b * p.THW;
-        ty = wino_div(rem, p.TW, p.mg_tw, p.sh_tw);
-        tx = rem - ty * p.TW;
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+    const char* tab = smem + (TRIPLE ? 3 : 2) * WINO_BUF + hh * 64;
+    const unsigned co_b = (unsigned)(co * 4);
+    auto emit = [&](float v, unsigned off) {
+        v = fmaf(v, sc, sh);
+        if (p.relu) v = fmaxf(v, 0.f);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ors, off + co_b, 0, 0);
     };
-    auto emit = [&](float v, int b, int y, int x) {
-        if (y < p.H && x < p.W) {
-            v = fmaf(v, sc, sh);
-            if (p.relu) v = fmaxf(v, 0.f);
-            p.out[((size_t)(b * p.H + y) * p.W + x) * p.ldo + co] = v;
-        }
-    };
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     if (NF == 16) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int t = m0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const u32x4 to = *reinterpret_cast<const u32x4*>(tab + ((r & 3) + 8 * (r >> 2)) * 16);
             float S[2][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 S[0][j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
                 S[1][j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
             }
-            if (t >= p.Mt) continue;
-            int b, ty, tx;
-            tile_pix(t, b, ty, tx);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                emit(S[i][0] + S[i][1] + S[i][2], b, 2 * ty + i, 2 * tx);
-                emit(S[i][1] - S[i][2] - S[i][3], b, 2 * ty + i, 2 * tx + 1);
+                emit(S[i][0] + S[i][1] + S[i][2], to[2 * i]);
+                emit(S[i][1] - S[i][2] - S[i][3], to[2 * i + 1]);
             }
         }
     } else {
@@ -286,15 +306,21 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
         const int partner = wave ^ NWN;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int t = m0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            if (t >= p.Mt) continue;
-            int b, ty, tx;
-            tile_pix(t, b, ty, tx);
+            const u32x4 to = *reinterpret_cast<const u32x4*>(tab + ((r & 3) + 8 * (r >> 2)) * 16);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
-                emit(mine[r][a] + xch[((partner * 16 + r) * 2 + a) * 64 + lane], b, 2 * ty + a, 2 * tx + fh);
+                emit(mine[r][a] + xch[((partner * 16 + r) * 2 + a) * 64 + lane], fh == 0 ? to[2 * a] : to[2 * a + 1]);
         }
     }
+#ifdef WINO_PROF
+    if (p.tprof && tid == 0) {
+        const long long t_end = __builtin_amdgcn_s_memtime();
+        atomicAdd(p.tprof + 0, (unsigned long long)(t_loop - t_start));
+        atomicAdd(p.tprof + 1, (unsigned long long)(t_epi - t_loop));
+        atomicAdd(p.tprof + 2, (unsigned long long)(t_end - t_epi));
+        atomicAdd(p.tprof + 3, 1ull);
+    }
+#endif
 }
 
 static void wino_magic(unsigned d, unsigned* mg, unsigned* sh) {
@@ -332,6 +358,10 @@ void pack_wino_weights(const float* w, int cout, int cin, std::vector<float>& ou
         }
 }
 
+#ifdef WINO_PROF
+static unsigned long long* g_wino_tprof = nullptr;
+void conv_wino_set_tprof(unsigned long long* p) { g_wino_tprof = p; }
+#endif
 static int g_wino_variant = 0;   // 0 auto, 16 / 8 = force the frequencies-per-wave variant
 void conv_wino_force_variant(int v) { g_wino_variant = v; }
 
@@ -347,7 +377,7 @@ static int wino_pick(const ConvArgs& a) {
 template <int NF>
 static int wino_launch_variant(WArgs k, int Cout, const LaunchCtx& ctx, double flops, double bytes) {
     constexpr int NT = NF == 16 ? 128 : 64;
-    constexpr int smem = (NF == 16 ? 3 : 2) * WINO_BUF;
+    constexpr int smem = (NF == 16 ? 3 : 2) * WINO_BUF + WINO_TAB;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_f32_kernel<NF>),
@@ -375,6 +405,10 @@ static int wino_launch_one(const ConvArgs& a, const LaunchCtx& ctx) {
     wino_magic((unsigned)k.TW, &k.mg_tw, &k.sh_tw);
     k.x_bytes = (unsigned)((size_t)a.B * a.H * a.W * a.ldx * 4);
     k.u_bytes = (unsigned)((size_t)16 * a.Cin * a.Cout * 4);
+    k.out_bytes = (unsigned)((size_t)a.B * a.H * a.W * a.ldo * 4);
+#ifdef WINO_PROF
+    k.tprof = g_wino_tprof;
+#endif
     const double M = (double)a.B * a.H * a.W;
     const double flops = 2.0 * M * a.Cout * 9.0 * a.Cin;   // algorithmic (direct-convolution) flops
     const double bytes = 4.0 * (M * a.Cin + M * a.Cout + 9.0 * a.Cin * a.Cout);
@@ -384,7 +418,8 @@ static int wino_launch_one(const ConvArgs& a, const LaunchCtx& ctx) {
 
 int launch_conv_wino(const ConvArgs& a, const LaunchCtx& ctx) {
     if (!conv_wino_supported(a) || (reinterpret_cast<uintptr_t>(a.x) & 7)) return (int)hipErrorInvalidValue;
-    const size_t img_bytes = (size_t)a.H * a.W * a.ldx * 4;
+    const size_t in_bytes = (size_t)a.H * a.W * a.ldx * 4, o_bytes = (size_t)a.H * a.W * a.ldo * 4;
+    const size_t img_bytes = in_bytes > o_bytes ? in_bytes : o_bytes;   // both sides use 32-bit buffer offsets
     const size_t limit = (size_t)1 << 31;
     if (img_bytes >= limit || (size_t)16 * a.Cin * a.Cout * 4 >= limit) return (int)hipErrorInvalidValue;
     const int max_b = (int)((limit - 1) / img_bytes);

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <vector>
 
+#define WINO_PROF 1
 #include "../spec_amd/csrc/conv_wino.hip"
 
 using namespace specmi;
@@ -99,6 +100,7 @@ int main(int argc, char** argv) {
             CK(hipFree(dref));
         }
         float ms = 0;
+        unsigned long long* dtp; CK(hipMalloc(&dtp, 64)); CK(hipMemset(dtp, 0, 64));
         if (L.count) {
             hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
             for (int i = 0; i < 60; ++i) launch_conv_wino(a, ctx);
@@ -109,6 +111,12 @@ int main(int argc, char** argv) {
             CK(hipEventSynchronize(e1));
             CK(hipEventElapsedTime(&ms, e0, e1));
             ms /= iters;
+            conv_wino_set_tprof(dtp);
+            launch_conv_wino(a, ctx);
+            CK(hipDeviceSynchronize());
+            conv_wino_set_tprof(nullptr);
+            unsigned long long tp[4]; CK(hipMemcpy(tp, dtp, 32, hipMemcpyDeviceToHost));
+            if (tp[3]) printf("    per-WG ticks(10ns): prologue %.0f  loop %.0f  epilogue %.0f   (n=%llu)\n", (double)tp[0] / tp[3], (double)tp[1] / tp[3], (double)tp[2] / tp[3], tp[3]);
         }
         const double fl = 2.0 * b * L.h * L.w * (double)L.cout * 9.0 * L.cin;
         printf("%s B=%-3d %8.3f ms  %7.1f TF/s(direct-equiv)  x%d  max|err| %.3g (ref max %.3g)\n", L.name, b, ms,
