@@ -31,6 +31,7 @@
 namespace specmi {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct WArgs {
@@ -42,7 +43,8 @@ struct WArgs {
     unsigned x_bytes, u_bytes, out_bytes;
     int H, W, ldx, Cout, ldo;
     int TH, TW, THW, Mt;   // 2x2 output tiles per column / row / image / launch
-    int nbn;               // Cout / 128
+    int nbm;               // tile rows: ceil(Mt / 32)
+    int nbn;               // co columns: Cout / (32 * co blocks per workgroup)
     int nstage;            // Cin / 16
     unsigned mg_thw, sh_thw, mg_tw, sh_tw;
     int relu;
@@ -51,6 +53,11 @@ struct WArgs {
 #endif
 };
 
+#ifdef WINO_ABLATE   // compile-time perf ablation (wrong results): 1 no U loads, 2 no raw loads, 4 no transform, 8 no A reads, 16 no stage barrier
+#define WABL(bit) ((WINO_ABLATE) & (bit))
+#else
+#define WABL(bit) 0
+#endif
 constexpr unsigned kOOB = 0x80000000u;
 constexpr int WINO_C2_STRIDE = 272;                  // bytes: 32 tiles x 8 B + 16 B pad (conflict-free b64 writes)
 constexpr int WINO_F_STRIDE = 8 * WINO_C2_STRIDE;    // 8 channel pairs per stage
@@ -67,36 +74,43 @@ __device__ __forceinline__ int wino_div(int n, int d, unsigned mg, unsigned sh) 
 //   NF == 8 : workgroup = 32 tiles x 64 co, wave = (co block w & 1, frequency columns j in {2fh, 2fh+1}
 //             with fh = w >> 1): 128 accumulator registers, two workgroups per CU, V double buffered;
 //             the two frequency halves of a co block meet in the output transform through LDS.
+// Workgroups are persistent: workgroup (tile_n, j) walks the tile rows j, j + G, j + 2G ... of its co
+// column, and the (tile, stage) sequence is one continuous software pipeline - the raw loads, the input
+// transform and the U / A fragments of the next tile's first stages are issued under the MFMAs of the
+// current tile's last stages, so only the first tile of a workgroup pays a prologue.
 template <int NF>
 __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(const WArgs p) {
     constexpr int NWN = NF == 16 ? 4 : 2;          // co blocks (of 32) per workgroup
     constexpr bool TRIPLE = NF == 16;
     constexpr int SPS = 16 / NF;                    // loader pieces per MFMA step
     constexpr int UD = NF == 16 ? 1 : 2;            // U prefetch distance in micro-chunks (NF MFMA pairs each)
+    constexpr int TAB0 = (TRIPLE ? 3 : 2) * WINO_BUF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef WINO_PROF
     const long long t_start = __builtin_amdgcn_s_memtime();
+    long long t_epi_sum = 0;
 #endif
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nbw = wave % NWN, fh = wave / NWN;
 
-    // ---- XCD-aware tile order: XCD x keeps one co block column (its U slice stays in its L2) ----
-    const int nblk = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, q8 = nblk >> 3, r8 = nblk & 7;
-    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int nbm = nblk / p.nbn;
-    const int tile_n = L / nbm, tile_m = L - tile_n * nbm;
-    const int m0 = tile_m * 32;
+    // co column = blockIdx % nbn: with nbn in {1, 2, 4, 8} an XCD (blockIdx % 8) keeps one column, so its
+    // U slice stays in that XCD's L2
+    const int tile_n = blockIdx.x % p.nbn;
+    const int G = gridDim.x / p.nbn;               // workgroups per co column
+    int tile_m = blockIdx.x / p.nbn;
 
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
 
     // ---- loader role: thread = (tile tl, channel pair c2l) ------------------------------------
     const int c2l = tid & 7, tl = tid >> 3;
     unsigned a_voff[16];
-    {
-        const int t = m0 + tl;
+    // decode tile row tm: the 16 patch offsets of this thread's tile and, for the epilogue, the byte
+    // offsets of the tile's 2x2 outputs (table slot `slot`; out-of-range offset = no load / no store)
+    auto decode_tile = [&](int tm, int slot) {
+        const int t = tm * 32 + tl;
         const bool ok = t < p.Mt;
         const int tt = ok ? t : 0;
         const int b = wino_div(tt, p.THW, p.mg_thw, p.sh_thw);
@@ -104,44 +118,42 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
         const int ty = wino_div(rem, p.TW, p.mg_tw, p.sh_tw);
         const int tx = rem - ty * p.TW;
         const int iy0 = 2 * ty - 1, ix0 = 2 * tx - 1;
-        const int pix0 = (b * p.H + iy0) * p.W + ix0;
+        // per-thread base + wave-uniform (dy, dx) term: the uniform part stays in SGPRs
+        const unsigned base = (unsigned)(((b * p.H + iy0) * p.W + ix0) * p.ldx * 4 + c2l * 8);
 #pragma unroll
         for (int dy = 0; dy < 4; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 4; ++dx) {
                 const bool in = ok && (unsigned)(iy0 + dy) < (unsigned)p.H && (unsigned)(ix0 + dx) < (unsigned)p.W;
-                a_voff[dy * 4 + dx] = in ? (unsigned)((pix0 + dy * p.W + dx) * p.ldx * 4 + c2l * 8) : kOOB;
+                a_voff[dy * 4 + dx] = in ? base + (unsigned)((dy * p.W + dx) * p.ldx * 4) : kOOB;
             }
-        // the epilogue's store addresses, decoded once per tile here instead of once per lane there
         if (c2l < 4) {
-            const int a = c2l >> 1, dx = c2l & 1;
-            const int oy = 2 * ty + a, ox = 2 * tx + dx;
+            const int oy = 2 * ty + (c2l >> 1), ox = 2 * tx + (c2l & 1);
             const bool in = ok && oy < p.H && ox < p.W;
-            reinterpret_cast<unsigned*>(smem + (TRIPLE ? 3 : 2) * WINO_BUF)[tl * 4 + c2l] =
+            reinterpret_cast<unsigned*>(smem + TAB0 + slot * WINO_TAB)[tl * 4 + c2l] =
                 in ? (unsigned)(((b * p.H + oy) * p.W + ox) * p.ldo * 4) : kOOB;
         }
-    }
+    };
     f32x2 raw[16];
     auto load_raw1 = [&](int st, int q) {
         raw[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrs, a_voff[q], (unsigned)(st * 64), 0));
     };
-    // V = B^T d B on both channels of the pair at once (packed fp32 adds), cut into 16 pieces so that
-    // the K loop can slot them under the MFMAs: pieces 0-7 = row pass, 8-15 = column pass + the LDS
-    // writes of one half row of frequencies.
+    // V = B^T d B on both channels of the pair at once (packed fp32 adds), cut into 12 pieces so that the
+    // K loop can slot them under the MFMAs: pieces 0-3 = row pass of patch column j (the four raw values
+    // of the column die, four T values are born: T and raw share registers), pieces 4-11 = column pass
+    // of half a T row + the LDS writes of its two frequencies.
     f32x2 T[16];
     char* const vw_base = smem + c2l * WINO_C2_STRIDE + tl * 8;
     auto transform_piece = [&](int s, char* dst) {
-        if (s < 8) {
-            const int j = s >> 1;
-            if ((s & 1) == 0) {
-                T[0 + j] = raw[0 + j] - raw[8 + j];
-                T[4 + j] = raw[4 + j] + raw[8 + j];
-            } else {
-                T[8 + j] = raw[8 + j] - raw[4 + j];
-                T[12 + j] = raw[4 + j] - raw[12 + j];
-            }
+        if (s < 4) {
+            const int j = s;
+            const f32x2 r0 = raw[0 + j], r1 = raw[4 + j], r2 = raw[8 + j], r3 = raw[12 + j];
+            T[0 + j] = r0 - r2;
+            T[4 + j] = r1 + r2;
+            T[8 + j] = r2 - r1;
+            T[12 + j] = r1 - r3;
         } else {
-            const int i = (s - 8) >> 1;
+            const int i = (s - 4) >> 1;
             if ((s & 1) == 0) {
                 *reinterpret_cast<f32x2*>(dst + (4 * i + 0) * WINO_F_STRIDE) = T[4 * i + 0] - T[4 * i + 2];
                 *reinterpret_cast<f32x2*>(dst + (4 * i + 1) * WINO_F_STRIDE) = T[4 * i + 1] + T[4 * i + 2];
@@ -151,44 +163,60 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
             }
         }
     };
+    // pieces of step fl of the u == 1 micro-chunk (NF steps): NF == 16: piece fl (12 used); NF == 8: one row
+    // piece per step for steps 0-3, two column pieces per step for steps 4-7
+    auto transform_step = [&](int fl, char* dst) {
+        if (NF == 16) {
+            if (fl < 12) transform_piece(fl, dst);
+        } else if (fl < 4) {
+            transform_piece(fl, dst);
+        } else {
+            transform_piece(4 + 2 * (fl - 4), dst);
+            transform_piece(5 + 2 * (fl - 4), dst);
+        }
+    };
 
     // ---- consumer role: lane = (tile row l31 / co column l31, k half hh) ------------------------
     // local frequency fl -> f = 4i + j:  NF == 16: f = fl;  NF == 8: i = fl >> 1, j = 2 fh + (fl & 1)
     auto f_of = [](int fl) { return NF == 16 ? fl : 4 * (fl >> 1) + (fl & 1); };
     const int l31 = lane & 31, hh = lane >> 5;
     const int nb = tile_n * NWN + nbw;
-    const int nmu = p.nstage * 4;
-    const unsigned u_voff = (unsigned)(lane * 8);
-    const unsigned u_block = (unsigned)(nb * nmu) * 8192u + (unsigned)(fh * 2 * 512);   // 16 f x 512 B per micro-chunk
-    f32x2 bq[UD][NF];
-    auto load_u = [&](int slot, int mu, int fl) {
-        bq[slot][fl] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(urs, u_voff, u_block + (unsigned)(mu * 8192 + f_of(fl) * 512), 0));
+    const int S = p.nstage, nmu = S * 4;
+    // U fragments: one 16-byte load per lane covers the frequency pair (f, f+1) of a micro-chunk
+    // ([co block][mu][f / 2][lane][(f & 1) * 2 + jj] in HBM) - vector-memory instructions, not bytes, are
+    // what the CU's address unit runs out of next to 16 patch loads per stage
+    const unsigned u_voff = (unsigned)(lane * 16);
+    const unsigned u_block = (unsigned)(nb * nmu) * 8192u + (unsigned)(fh * 1024);   // 8 pairs x 1 KiB per micro-chunk
+    f32x4 bq[UD][NF / 2];
+    auto load_u = [&](int slot, int mu, int fp) {   // fp = local pair index: local frequencies 2 fp, 2 fp + 1
+        bq[slot][fp] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, u_voff, u_block + (unsigned)(mu * 8192 + (f_of(2 * fp) >> 1) * 1024), 0));
     };
     const char* const vr_base = smem + hh * WINO_C2_STRIDE + l31 * 8 + fh * 2 * WINO_F_STRIDE;
     auto read_a = [&](const char* vr, int u, int fl) {
         return *reinterpret_cast<const f32x2*>(vr + f_of(fl) * WINO_F_STRIDE + u * 2 * WINO_C2_STRIDE);
     };
+    const int co = nb * 32 + l31;
+    const float sc = p.scale[co], sh = p.shift[co];
+    const unsigned co_b = (unsigned)(co * 4);
+    auto emit = [&](float v, unsigned off) {
+        v = fmaf(v, sc, sh);
+        if (p.relu) v = fmaxf(v, 0.f);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ors, off + co_b, 0, 0);
+    };
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-    f32x16 acc[NF];
-#pragma unroll
-    for (int f = 0; f < NF; ++f)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
-
-    // ---- prologue --------------------------------------------------------------------------
+    // ---- prologue of the workgroup's first tile --------------------------------------------------
+    decode_tile(tile_m, 0);
 #pragma unroll
     for (int q = 0; q < 16; ++q) load_raw1(0, q);
 #pragma unroll
     for (int d = 0; d < UD; ++d)
 #pragma unroll
-        for (int f = 0; f < NF; ++f) load_u(d, d, f);   // nmu >= 4 > UD
+        for (int f = 0; f < NF / 2; ++f) load_u(d, d, f);   // nmu >= 4 > UD
 #pragma unroll
-    for (int s = 0; s < 16; ++s) transform_piece(s, vw_base);
-    {
-        const int st1 = p.nstage > 1 ? 1 : 0;
+    for (int s = 0; s < 12; ++s) transform_piece(s, vw_base);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) load_raw1(st1, q);
-    }
+    for (int q = 0; q < 16; ++q) load_raw1(S > 1 ? 1 : 0, q);
     __syncthreads();
     f32x2 af[NF];
 #pragma unroll
@@ -198,126 +226,139 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
     // A wave issues in order and an fp32 MFMA holds the matrix pipe for 64 cycles, so whatever sits
     // between two MFMA pairs in program order runs under them.  One stage = 4 micro-chunks x NF
     // steps; step (u, fl) = the two MFMAs of one frequency plus one slice of everything else:
-    //   every step : stream U(mu+1, f) and the A fragment of the next micro-chunk into the registers
+    //   every step : stream U(mu+UD, f) and the A fragment of the next micro-chunk into the registers
     //                just consumed (rolling: they are needed NF steps later)
-    //   u == 1     : pieces of the input transform of stage st+1 (writes V into the next buffer)
-    //   u == 2     : raw patch loads of stage st+2
+    //   u == 1     : pieces of the input transform of the next stage (writes V into the next buffer)
+    //   u == 2     : raw patch loads of the stage after that
+    // "next stage" runs on into the next tile of this workgroup: its patch offsets replace the current
+    // ones before stage S-2 (whose loads are the first that need them).
     // TRIPLE: the single barrier of a stage sits after u == 2, so micro-chunk 3 already prefetches the
-    // first fragments of stage st+1 and no wave waits on LDS after a barrier.  Otherwise (two
+    // first fragments of the next stage and no wave waits on LDS after a barrier.  Otherwise (two
     // workgroups per CU cover for each other) the barrier closes the stage.
 #ifdef WINO_PROF
     const long long t_loop = __builtin_amdgcn_s_memtime();
 #endif
     int o_cur = 0, o_nxt = WINO_BUF, o_nn = TRIPLE ? 2 * WINO_BUF : 0;
-    for (int st = 0; st < p.nstage; ++st) {
-        const char* vr_cur = vr_base + o_cur;
-        const char* vr_nxt = vr_base + o_nxt;
-        char* vw_nxt = vw_base + o_nxt;
-        const int st2 = st + 2 < p.nstage ? st + 2 : p.nstage - 1;
+    for (int it = 0;; ++it) {
+        const int next_m = tile_m + G;
+        const bool has_next = next_m < p.nbm;
+        const int nm = has_next ? next_m : tile_m;   // nothing follows: keep prefetching this tile (unused)
+        f32x16 acc[NF];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int mu = st * 4 + u;
-            const int mu1 = mu + UD < nmu ? mu + UD : nmu - 1;
+        for (int f = 0; f < NF; ++f)
 #pragma unroll
-            for (int fl = 0; fl < NF; ++fl) {
-                acc[fl] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fl][0], bq[u % UD][fl][0], acc[fl], 0, 0, 0);
-                acc[fl] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fl][1], bq[u % UD][fl][1], acc[fl], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                load_u(u % UD, mu1, fl);
-                if (u < 3) af[fl] = read_a(vr_cur, u + 1, fl);   // rolling: consumed NF steps from now
-                else if (TRIPLE) af[fl] = read_a(vr_nxt, 0, fl);
-                if (u == 1) {
+            for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+        for (int st = 0; st < S; ++st) {
+            if (S > 1 && st == (S > 2 ? S - 2 : 0)) decode_tile(nm, (it + 1) & 1);
+            const char* vr_cur = vr_base + o_cur;
+            const char* vr_nxt = vr_base + o_nxt;
+            char* vw_nxt = vw_base + o_nxt;
+            // stage after next; past the tile's end it is the next tile's stage 0 / 1 (S == 1 never has a next tile)
+            const int st2 = st + 2 < S ? st + 2 : (st + 2 - S < S ? st + 2 - S : S - 1);
 #pragma unroll
-                    for (int k = 0; k < SPS; ++k) transform_piece(fl * SPS + k, vw_nxt);
+            for (int u = 0; u < 4; ++u) {
+                const int mu = st * 4 + u;
+                const int mu1 = mu + UD < nmu ? mu + UD : mu + UD - nmu;
+#pragma unroll
+                for (int fl = 0; fl < NF; ++fl) {
+                    acc[fl] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fl][0], bq[u % UD][fl >> 1][(fl & 1) * 2 + 0], acc[fl], 0, 0, 0);
+                    acc[fl] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fl][1], bq[u % UD][fl >> 1][(fl & 1) * 2 + 1], acc[fl], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!WABL(1) && (fl & 1)) load_u(u % UD, mu1, fl >> 1);
+                    if (!WABL(8)) {
+                    if (u < 3) af[fl] = read_a(vr_cur, u + 1, fl);   // rolling: consumed NF steps from now
+                    else if (TRIPLE) af[fl] = read_a(vr_nxt, 0, fl);
+                    }
+                    if (u == 1 && !WABL(4)) transform_step(fl, vw_nxt);
+                    if (u == 2 && !WABL(2)) {
+#pragma unroll
+                        for (int k = 0; k < SPS; ++k) load_raw1(st2, fl * SPS + k);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                if (u == 2) {
-#pragma unroll
-                    for (int k = 0; k < SPS; ++k) load_raw1(st2, fl * SPS + k);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                if (TRIPLE && u == 2) __syncthreads();
             }
-            if (TRIPLE && u == 2) __syncthreads();
+            if (!TRIPLE) {
+                if (!WABL(16)) __syncthreads();
+#pragma unroll
+                for (int fl = 0; fl < NF; ++fl) af[fl] = read_a(vr_nxt, 0, fl);
+            }
+            const int t = o_cur; o_cur = o_nxt; o_nxt = TRIPLE ? o_nn : t; o_nn = t;
         }
-        if (!TRIPLE) {
+
+        // ---- epilogue of this tile: lane-local output transform, BN scale/shift, ReLU, store ------
+        // Accumulator register r of a lane belongs to tile (r & 3) + 8 (r >> 2) + 4 hh: its four output
+        // addresses come from the table the loader threads left in LDS (16 bytes per tile), so an
+        // output costs one add, one fma, one max and a buffer store.
+#ifdef WINO_PROF
+        const long long t_e0 = __builtin_amdgcn_s_memtime();
+#endif
+        const char* tab = smem + TAB0 + (it & 1) * WINO_TAB + hh * 64;
+        if (NF == 16) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const u32x4 to = *reinterpret_cast<const u32x4*>(tab + ((r & 3) + 8 * (r >> 2)) * 16);
+                float Sx[2][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    Sx[0][j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
+                    Sx[1][j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    emit(Sx[i][0] + Sx[i][1] + Sx[i][2], to[2 * i]);
+                    emit(Sx[i][1] - Sx[i][2] - Sx[i][3], to[2 * i + 1]);
+                }
+            }
+        } else {
+            // This wave holds D[i][j] for j in {2fh, 2fh+1} (acc[2i + jl]).  Y[a][0] = S[a][0]+S[a][1]+S[a][2],
+            // Y[a][1] = S[a][1]-S[a][2]-S[a][3] with S = row transform (lane-local): the fh = 0 wave finishes
+            // output column 0 and needs S[a][2] from its partner; the fh = 1 wave finishes column 1 and
+            // needs S[a][1].  32 floats per lane cross through the stage buffer that the last stage just
+            // released (the other one already holds the next tile's first stage).
+            char* const xw = smem + o_nxt + wave * 8192 + lane * 4;               // this wave's 8 KB: [r][a][lane]
+            const char* const xr = smem + o_nxt + (wave ^ NWN) * 8192 + lane * 4;   // the partner's
+            float mine[16][2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float Sx[2][2];
+#pragma unroll
+                for (int jl = 0; jl < 2; ++jl) {
+                    Sx[0][jl] = acc[0 + jl][r] + acc[2 + jl][r] + acc[4 + jl][r];
+                    Sx[1][jl] = acc[2 + jl][r] - acc[4 + jl][r] - acc[6 + jl][r];
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    // fh == 0: keep S0+S1 (for Y[a][0]), send S1 (for Y[a][1]);  fh == 1: keep -S2-S3, send S2
+                    mine[r][a] = fh == 0 ? Sx[a][0] + Sx[a][1] : -Sx[a][0] - Sx[a][1];
+                    *reinterpret_cast<float*>(xw + (r * 2 + a) * 256) = fh == 0 ? Sx[a][1] : Sx[a][0];
+                }
+            }
             __syncthreads();
 #pragma unroll
-            for (int fl = 0; fl < NF; ++fl) af[fl] = read_a(vr_nxt, 0, fl);
+            for (int r = 0; r < 16; ++r) {
+                const u32x4 to = *reinterpret_cast<const u32x4*>(tab + ((r & 3) + 8 * (r >> 2)) * 16);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    emit(mine[r][a] + *reinterpret_cast<const float*>(xr + (r * 2 + a) * 256), fh == 0 ? to[2 * a] : to[2 * a + 1]);
+            }
+            if (has_next) __syncthreads();   // the next tile's stage 0 transforms into this buffer
         }
-        const int t = o_cur; o_cur = o_nxt; o_nxt = TRIPLE ? o_nn : t; o_nn = t;
-    }
-
+        // a two-stage tile rewrites the store table before its first barrier
+        if (NF == 16 && has_next && S <= 2) __syncthreads();
 #ifdef WINO_PROF
-    const long long t_epi = __builtin_amdgcn_s_memtime();
+        t_epi_sum += __builtin_amdgcn_s_memtime() - t_e0;
 #endif
-    // ---- epilogue: lane-local output transform, BN scale/shift, ReLU, store -------------------
-    // Accumulator register r of a lane belongs to tile (r & 3) + 8 (r >> 2) + 4 hh: its four output
-    // addresses come from the table the loader threads left in LDS (16 bytes per tile, out-of-range
-    // offset = no store), so an output costs one add, one fma, one max and a buffer store.
-    const int co = nb * 32 + l31;
-    const float sc = p.scale[co], sh = p.shift[co];
-    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
-    const char* tab = smem + (TRIPLE ? 3 : 2) * WINO_BUF + hh * 64;
-    const unsigned co_b = (unsigned)(co * 4);
-    auto emit = [&](float v, unsigned off) {
-        v = fmaf(v, sc, sh);
-        if (p.relu) v = fmaxf(v, 0.f);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ors, off + co_b, 0, 0);
-    };
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    if (NF == 16) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const u32x4 to = *reinterpret_cast<const u32x4*>(tab + ((r & 3) + 8 * (r >> 2)) * 16);
-            float S[2][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                S[0][j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
-                S[1][j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                emit(S[i][0] + S[i][1] + S[i][2], to[2 * i]);
-                emit(S[i][1] - S[i][2] - S[i][3], to[2 * i + 1]);
-            }
-        }
-    } else {
-        // This wave holds D[i][j] for j in {2fh, 2fh+1} (acc[2i + jl]).  Y[a][0] = S[a][0]+S[a][1]+S[a][2],
-        // Y[a][1] = S[a][1]-S[a][2]-S[a][3] with S = row transform (lane-local): the fh = 0 wave finishes
-        // output column 0 and needs S[a][2] from its partner; the fh = 1 wave finishes column 1 and
-        // needs S[a][1].  32 floats per lane cross through LDS (the stage buffers are idle by now).
-        float* xch = reinterpret_cast<float*>(smem);
-        float mine[16][2];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float S[2][2];
-#pragma unroll
-            for (int jl = 0; jl < 2; ++jl) {
-                S[0][jl] = acc[0 + jl][r] + acc[2 + jl][r] + acc[4 + jl][r];
-                S[1][jl] = acc[2 + jl][r] - acc[4 + jl][r] - acc[6 + jl][r];
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                // fh == 0: keep S0+S1 (for Y[a][0]), send S1 (for Y[a][1]);  fh == 1: keep -S2-S3, send S2
-                mine[r][a] = fh == 0 ? S[a][0] + S[a][1] : -S[a][0] - S[a][1];
-                xch[((wave * 16 + r) * 2 + a) * 64 + lane] = fh == 0 ? S[a][1] : S[a][0];
-            }
-        }
-        __syncthreads();
-        const int partner = wave ^ NWN;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const u32x4 to = *reinterpret_cast<const u32x4*>(tab + ((r & 3) + 8 * (r >> 2)) * 16);
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-                emit(mine[r][a] + xch[((partner * 16 + r) * 2 + a) * 64 + lane], fh == 0 ? to[2 * a] : to[2 * a + 1]);
-        }
+        if (!has_next) break;
+        tile_m = next_m;
     }
 #ifdef WINO_PROF
     if (p.tprof && tid == 0) {
         const long long t_end = __builtin_amdgcn_s_memtime();
         atomicAdd(p.tprof + 0, (unsigned long long)(t_loop - t_start));
-        atomicAdd(p.tprof + 1, (unsigned long long)(t_epi - t_loop));
-        atomicAdd(p.tprof + 2, (unsigned long long)(t_end - t_epi));
+        atomicAdd(p.tprof + 1, (unsigned long long)(t_end - t_loop - t_epi_sum));
+        atomicAdd(p.tprof + 2, (unsigned long long)t_epi_sum);
         atomicAdd(p.tprof + 3, 1ull);
     }
 #endif
@@ -337,7 +378,7 @@ bool conv_wino_supported(const ConvArgs& a) {
            a.ldx % 2 == 0 && !a.res && a.OH == a.H && a.OW == a.W;
 }
 
-// OIHW (cout, cin, 3, 3) -> U = G g G^T packed [cout/32][cin/4][f = 4i+j][h][n][jj], ci = 4*mu + 2*h + jj
+// OIHW (cout, cin, 3, 3) -> U = G g G^T packed [cout/32][cin/4][f/2][lane = h*32+n][(f&1)*2 + jj], f = 4i+j, ci = 4*mu + 2*h + jj
 void pack_wino_weights(const float* w, int cout, int cin, std::vector<float>& out) {
     static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     out.assign((size_t)16 * cin * cout, 0.f);
@@ -353,15 +394,18 @@ void pack_wino_weights(const float* w, int cout, int cin, std::vector<float>& ou
                 for (int j = 0; j < 4; ++j) {
                     const double uij = Gg[i][0] * G[j][0] + Gg[i][1] * G[j][1] + Gg[i][2] * G[j][2];
                     const int f = 4 * i + j;
-                    out[((((size_t)nb * nmu + mu) * 16 + f) * 2 + h) * 64 + n * 2 + jj] = (float)uij;
+                    out[((((size_t)nb * nmu + mu) * 8 + (f >> 1)) * 64 + h * 32 + n) * 4 + (f & 1) * 2 + jj] = (float)uij;
                 }
         }
 }
 
 #ifdef WINO_PROF
 static unsigned long long* g_wino_tprof = nullptr;
+
 void conv_wino_set_tprof(unsigned long long* p) { g_wino_tprof = p; }
 #endif
+static int g_wino_persistent = 1;
+void conv_wino_set_persistent(int v) { g_wino_persistent = v; }
 static int g_wino_variant = 0;   // 0 auto, 16 / 8 = force the frequencies-per-wave variant
 void conv_wino_force_variant(int v) { g_wino_variant = v; }
 
@@ -377,7 +421,7 @@ static int wino_pick(const ConvArgs& a) {
 template <int NF>
 static int wino_launch_variant(WArgs k, int Cout, const LaunchCtx& ctx, double flops, double bytes) {
     constexpr int NT = NF == 16 ? 128 : 64;
-    constexpr int smem = (NF == 16 ? 3 : 2) * WINO_BUF + WINO_TAB;
+    constexpr int smem = (NF == 16 ? 3 : 2) * WINO_BUF + 2 * WINO_TAB;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_f32_kernel<NF>),
@@ -386,9 +430,14 @@ static int wino_launch_variant(WArgs k, int Cout, const LaunchCtx& ctx, double f
         attr_set = true;
     }
     k.nbn = Cout / NT;
-    const int nbm = (k.Mt + 31) / 32;
+    k.nbm = (k.Mt + 31) / 32;
+    // persistent grid: as many workgroups as the chip holds at once (256 CUs x 1 or 2), split evenly over the
+    // co columns; a single 16-channel stage cannot pipeline across tiles (the loads run two stages ahead)
+    int G = (256 * (NF == 16 ? 1 : 2)) / k.nbn;
+    if (G < 1) G = 1;
+    if (G > k.nbm || k.nstage < 2 || g_wino_persistent == 0) G = k.nbm;
     ProfScope ps(ctx, NF == 16 ? "conv_wino_f32<32t x128,F(2x2,3x3)>" : "conv_wino_f32<32t x64,F(2x2,3x3)>", flops, bytes);
-    hipLaunchKernelGGL(conv_wino_f32_kernel<NF>, dim3(nbm * k.nbn), dim3(256), smem, ctx.stream, k);
+    hipLaunchKernelGGL(conv_wino_f32_kernel<NF>, dim3(G * k.nbn), dim3(256), smem, ctx.stream, k);
     return (int)hipGetLastError();
 }
 

@@ -43,6 +43,7 @@ int main(int argc, char** argv) {
     int only = argc > 3 ? atoi(argv[3]) : -1;
     int variant = argc > 4 ? atoi(argv[4]) : 0;
     conv_wino_force_variant(variant);
+    conv_wino_set_persistent(argc > 5 ? atoi(argv[5]) : 1);
     std::vector<Layer> layers = {
         {"odd      3x3  16->128  7x9 ", 16, 128, 7, 9, 0, 3},
         {"odd2     3x3  32->256  5x3 ", 32, 256, 5, 3, 0, 5},
