@@ -143,13 +143,6 @@ static void pack_gemm_weights(const float* w, int cout, int cin, int kh, int kw,
                 }
 }
 
-// stem: (64,3,7,7) -> [147][64], k = c*49 + ky*7 + kx
-static void pack_stem_weights(const float* w, std::vector<float>& out) {
-    out.assign(147 * 64, 0.f);
-    for (int n = 0; n < 64; ++n)
-        for (int k = 0; k < 147; ++k) out[k * 64 + n] = w[n * 147 + k];
-}
-
 // eval-mode BatchNorm as y = x*alpha + beta, computed like ATen's CPU kernel (fp32):
 // invstd = 1/sqrt(var+eps); alpha = invstd*gamma; beta = bias - mean*alpha
 static void fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, int n, float eps,
@@ -193,7 +186,7 @@ static int commit_conv(specmi_handle* h, const std::string& prefix, ConvW& c) {
     if ((rc = need(h, prefix + c.bn_name + ".running_var", {c.cout}, false, &v))) return rc;
     std::vector<float> packed, scale, shift;
     if (c.cin == 3) {
-        c.Kp = 147;
+        c.Kp = 148;
         c.Npad = 64;
         pack_stem_weights(w->f.data(), packed);
     } else {

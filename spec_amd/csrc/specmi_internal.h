@@ -88,7 +88,8 @@ void conv_wino_force_variant(int nf);   // 0 auto, 16 / 8 frequencies per wave (
 // ----------------------------------------------------------------------------------------
 // stem + pooling  (stem.hip)
 // ----------------------------------------------------------------------------------------
-// x NCHW (B,3,H,W); w packed [147][64] (k = c*49+ky*7+kx); out NHWC (B,OH,OW,64), BN+ReLU.
+// x NCHW (B,3,H,W); w = pack_stem_weights() output; out NHWC (B,OH,OW,64), BN+ReLU.
+void pack_stem_weights(const float* w_oihw, std::vector<float>& out);
 int launch_stem(const float* x, const float* w, const float* scale, const float* shift,
                 float* out, int B, int H, int W, int OH, int OW, int relu, const LaunchCtx& ctx);
 int launch_maxpool3x3s2(const float* x, float* out, int B, int H, int W, int C, int OH, int OW,

@@ -2,12 +2,8 @@
 //
 //   * stem_conv7x7_kernel : Conv2d(3,64,7,s2,p3) + BatchNorm(eval) + ReLU, NCHW fp32 image in,
 //     NHWC out.  (pare resnet50 conv1/bn1/relu; reference call sites spec/models/hmr.py:92,
-//     camcalib/model.py:73.)  K = 147 is a poor MFMA fit and fp32 MFMA runs at the VALU rate
-//     anyway, so this is a direct VALU convolution: the 21x69x3 input patch of an 8x32
-//     output tile and the whole 147x64 filter bank are staged in LDS (55 KB, 2 blocks/CU);
-//     a lane owns 4 horizontally adjacent output pixels x 16 output channels, so the 13 input
-//     values of a (channel, filter-row) are read from LDS once and reused for 7 taps x 4
-//     pixels, and the 16 filter values of a tap are a wave-uniform (broadcast) LDS read.
+//     camcalib/model.py:73.)  Implicit GEMM on the fp32 matrix cores with K = 147 (+1 zero), the
+//     input patch and the filter bank in LDS - see the comment at the kernel.
 //   * maxpool3x3s2_kernel : MaxPool2d(3,2,1) on NHWC, float4 per lane, HBM-bound.
 //   * avgpool_kernel      : AdaptiveAvgPool2d(1) on NHWC -> row-strided (B, ldo) output so the
 //     pooled features land directly inside the regressor's concatenated input row.
@@ -15,101 +11,151 @@
 
 namespace specmi {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int ST_TH = 8, ST_TW = 32;               // output tile (rows x cols)
-constexpr int ST_PH = 2 * ST_TH + 5;               // 21 input rows
-constexpr int ST_PW = 72;                          // 2*32+5 = 69 input cols, padded to 72
-constexpr int ST_K = 147;
-constexpr int ST_SMEM_FLOATS = ST_K * 64 + 3 * ST_PH * ST_PW;  // 9408 + 4536
+// ---- stem as an implicit GEMM on the fp32 matrix cores -------------------------------------------
+// out[px][co] = sum_k patch[px][k] * w[k][co], k = (c, ky, kx) = 49 c + 7 ky + kx, K = 147 padded to 148.
+// A persistent workgroup (4 waves) walks 8x16 output tiles; a wave owns two tile rows = 32 pixels x 64
+// channels = two 32x32 accumulator tiles.  Per tile the 3 x 21 x 37 input patch is staged in LDS
+// (register-staged one tile ahead, zero padding = out-of-range buffer offset); the filter bank lives in
+// LDS for the workgroup's lifetime as [k pair][k half][32][co, co+32] so a lane's two B operands are one
+// conflict-free ds_read_b64.  The A operand of MFMA lane (pixel m, k half h) is patch[c][2 oy + ky][2 ox + kx]:
+// a ds_read_b32 at (per-lane base) + (compile-time offset of the even k); the odd k of the pair sits 1, 32
+// (next filter row) or 564 (next channel) floats further, i.e. one of three per-lane base registers.
+constexpr int SM_TH = 8, SM_TW = 16;          // output tile
+constexpr int SM_PH = 2 * SM_TH + 5;           // 21 patch rows
+constexpr int SM_PW = 38;                      // 2*16+5 = 37 patch columns, padded to an even count
+constexpr int SM_CS = SM_PH * SM_PW;           // floats per patch channel
+constexpr int SM_PATCH = 3 * SM_CS;            // 2394
+constexpr int SM_KK = 74;                      // k pairs
+constexpr int SM_WF = SM_KK * 128;             // filter floats in LDS
+constexpr int SM_NLD = (SM_PATCH + 255) / 256; // patch loads per thread (10)
+constexpr unsigned kStemOOB = 0x80000000u;
 
-__global__ void __launch_bounds__(256) stem_conv7x7_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                            const float* __restrict__ scale,
-                                                            const float* __restrict__ shift, float* __restrict__ out,
-                                                            int H, int W, int OH, int OW, int relu) {
+struct StemArgs {
+    const float* x; const float* w; const float* scale; const float* shift; float* out;
+    unsigned x_bytes, out_bytes;
+    int B, H, W, OH, OW, relu;
+    int tiles_x, tiles_y, ntiles;
+};
+
+__global__ void __launch_bounds__(256) stem_conv7x7_kernel(const StemArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* wl = smem;                // [147][64]
-    float* patch = smem + ST_K * 64; // [3][21][72]
+    float* wl = smem;              // [74][2][32][2]
+    float* patch = smem + SM_WF;   // [3][21][38]
     const int tid = threadIdx.x;
-    const int b = blockIdx.z;
-    const int oy0 = blockIdx.y * ST_TH, ox0 = blockIdx.x * ST_TW;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
 
-    for (int i = tid; i < ST_K * 64 / 4; i += 256)
-        reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(w)[i];
-    const int iy_base = oy0 * 2 - 3, ix_base = ox0 * 2 - 3;
-    for (int i = tid; i < 3 * ST_PH * ST_PW; i += 256) {
-        const int c = i / (ST_PH * ST_PW);
-        const int rem = i - c * (ST_PH * ST_PW);
-        const int rr = rem / ST_PW, cc = rem - rr * ST_PW;
-        const int iy = iy_base + rr, ix = ix_base + cc;
-        float v = 0.f;
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-            v = x[((size_t)(b * 3 + c) * H + iy) * W + ix];
-        patch[i] = v;
+    for (int i = tid; i < SM_WF / 4; i += 256)
+        reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(p.w)[i];
+
+    // loader role: element idx = tid + 256 i of the patch -> (channel, row, col), fixed for the kernel's life
+    int ld_rel[SM_NLD];    // element offset relative to the patch origin in the image
+    int ld_rc[SM_NLD];     // row << 8 | col   (row = 255: element beyond the patch)
+#pragma unroll
+    for (int i = 0; i < SM_NLD; ++i) {
+        const int idx = tid + 256 * i;
+        const int c = idx / SM_CS, rem = idx - c * SM_CS;
+        const int rr = rem / SM_PW, cc = rem - rr * SM_PW;
+        ld_rel[i] = (c * p.H + rr) * p.W + cc;
+        ld_rc[i] = idx < SM_PATCH ? (rr << 8 | cc) : (0x7FFF << 8);   // beyond the patch: never inside an image
     }
-    __syncthreads();
-
-    const int lane = tid & 63, cg = tid >> 6;  // wave = channel group of 16
-    const int r = lane >> 3, q = lane & 7;     // output row in tile, pixel quad
-    float acc[4][16];
+    float stg[SM_NLD];
+    auto tile_coords = [&](int t, int& b, int& oy0, int& ox0) {
+        b = t / (p.tiles_x * p.tiles_y);
+        const int r = t - b * (p.tiles_x * p.tiles_y);
+        const int ty = r / p.tiles_x;
+        oy0 = ty * SM_TH;
+        ox0 = (r - ty * p.tiles_x) * SM_TW;
+    };
+    auto load_patch = [&](int t) {
+        int b, oy0, ox0;
+        tile_coords(t, b, oy0, ox0);
+        const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
+        const int base = (b * 3 * p.H + iy0) * p.W + ix0;
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int c = 0; c < 16; ++c) acc[p][c] = 0.f;
-
-    for (int c = 0; c < 3; ++c) {
-#pragma unroll 1
-        for (int ky = 0; ky < 7; ++ky) {
-            const float* prow = patch + (c * ST_PH + 2 * r + ky) * ST_PW + 8 * q;
-            float in[16];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(prow + 4 * j);
-                in[4 * j + 0] = v[0]; in[4 * j + 1] = v[1]; in[4 * j + 2] = v[2]; in[4 * j + 3] = v[3];
-            }
-            const float* wrow = wl + ((c * 7 + ky) * 7) * 64 + cg * 16;
-#pragma unroll
-            for (int kx = 0; kx < 7; ++kx) {
-                float wv[16];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(wrow + kx * 64 + 4 * j);
-                    wv[4 * j + 0] = v[0]; wv[4 * j + 1] = v[1]; wv[4 * j + 2] = v[2]; wv[4 * j + 3] = v[3];
-                }
-#pragma unroll
-                for (int p = 0; p < 4; ++p)
-#pragma unroll
-                    for (int ch = 0; ch < 16; ++ch) acc[p][ch] = fmaf(in[2 * p + kx], wv[ch], acc[p][ch]);
-            }
+        for (int i = 0; i < SM_NLD; ++i) {
+            const int rr = ld_rc[i] >> 8, cc = ld_rc[i] & 255;
+            const bool in = (unsigned)(iy0 + rr) < (unsigned)p.H && (unsigned)(ix0 + cc) < (unsigned)p.W;
+            const unsigned off = in ? (unsigned)((base + ld_rel[i]) * 4) : kStemOOB;
+            stg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, off, 0, 0));
         }
-    }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < SM_NLD; ++i)
+            if (i < SM_NLD - 1 || tid + 256 * i < SM_PATCH) patch[tid + 256 * i] = stg[i];
+    };
 
-    const int oy = oy0 + r;
-    if (oy >= OH) return;
-    float sc[16], sh[16];
+    // consumer role
+    const int oyl = 2 * wave + (l31 >> 4), oxl = l31 & 15;
+    const char* a0 = reinterpret_cast<const char*>(patch) + ((2 * oyl) * SM_PW + 2 * oxl) * 4;
+    const char* ab[3] = {a0 + hh * 4, a0 + hh * (SM_PW - 6) * 4, a0 + hh * (SM_CS - 6 * SM_PW - 6) * 4};
+    const char* bb = reinterpret_cast<const char*>(wl) + (hh * 32 + l31) * 8;
+    const float sc0 = p.scale[l31], sc1 = p.scale[32 + l31], sh0 = p.shift[l31], sh1 = p.shift[32 + l31];
+    const unsigned o_lane = (unsigned)((4 * hh) * 256 + l31 * 4);
+
+    int t = blockIdx.x;
+    if (t < p.ntiles) load_patch(t);
+    for (; t < p.ntiles; t += gridDim.x) {
+        __syncthreads();          // every wave is done with the previous tile's patch (and, first time, wl is written)
+        store_patch();
+        __syncthreads();
+        const int tn = t + gridDim.x;
+        if (tn < p.ntiles) load_patch(tn);   // in flight under this tile's MFMAs
+
+        f32x16 acc0, acc1;
 #pragma unroll
-    for (int ch = 0; ch < 16; ++ch) { sc[ch] = scale[cg * 16 + ch]; sh[ch] = shift[cg * 16 + ch]; }
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int ox = ox0 + 4 * q + p;
-        if (ox >= OW) continue;
-        float* o = out + ((size_t)(b * OH + oy) * OW + ox) * 64 + cg * 16;
+        for (int kk = 0; kk < SM_KK; ++kk) {
+            const int k0 = 2 * kk;
+            const int c = k0 / 49, ky = (k0 % 49) / 7, kx = k0 % 7;
+            const int off0 = (c * SM_CS + ky * SM_PW + kx) * 4;
+            // k0 = 146 pairs with the zero-weight k = 147: any finite in-patch value will do (delta 1)
+            const int sel = (kx < 6 || kk == SM_KK - 1) ? 0 : (ky < 6 ? 1 : 2);
+            const float a = *reinterpret_cast<const float*>(ab[sel] + off0);
+            const f32x2 bw = *reinterpret_cast<const f32x2*>(bb + kk * 512);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[1], acc1, 0, 0, 0);
+        }
+
+        // epilogue: accumulator r of a lane = pixel (row r >> 3, col (r & 3) + 8 ((r >> 2) & 1) + 4 hh) of the wave's
+        // two tile rows, channels l31 and 32 + l31
+        int b, oy0, ox0;
+        tile_coords(t, b, oy0, ox0);
+        const int oy = oy0 + 2 * wave;
+        const bool edge = ox0 + SM_TW > p.OW;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = fmaf(acc[p][4 * j + e], sc[4 * j + e], sh[4 * j + e]);
-                v[e] = relu ? fmaxf(t, 0.f) : t;
-            }
-            *reinterpret_cast<f32x4*>(o + 4 * j) = v;
+        for (int r = 0; r < 16; ++r) {
+            const int row = r >> 3, col = (r & 3) + 8 * ((r >> 2) & 1);
+            if (oy + row >= p.OH) continue;   // wave-uniform
+            const unsigned s_off = (unsigned)((((b * p.OH + oy + row) * p.OW + ox0 + col)) * 256);
+            unsigned v_off = o_lane;
+            if (edge && ox0 + col + 4 * hh >= p.OW) v_off = kStemOOB;
+            float v0 = fmaf(acc0[r], sc0, sh0), v1 = fmaf(acc1[r], sc1, sh1);
+            if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), ors, v_off, s_off, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), ors, v_off + 128, s_off, 0);
         }
     }
 }
 
+// OIHW (64, 3, 7, 7) -> [k pair kk][k half h][co & 31][co >> 5], k = 2 kk + h = 49 c + 7 ky + kx (k = 147: zero)
+void pack_stem_weights(const float* w, std::vector<float>& out) {
+    out.assign(SM_WF, 0.f);
+    for (int n = 0; n < 64; ++n)
+        for (int k = 0; k < 147; ++k) out[((k >> 1) * 2 + (k & 1)) * 64 + (n & 31) * 2 + (n >> 5)] = w[n * 147 + k];
+}
+
 int launch_stem(const float* x, const float* w, const float* scale, const float* shift, float* out, int B, int H,
                 int W, int OH, int OW, int relu, const LaunchCtx& ctx) {
-    constexpr size_t smem = ST_SMEM_FLOATS * sizeof(float);
+    constexpr size_t smem = (SM_WF + SM_PATCH) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_conv7x7_kernel),
@@ -117,13 +163,30 @@ int launch_stem(const float* x, const float* w, const float* scale, const float*
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    dim3 grid((OW + ST_TW - 1) / ST_TW, (OH + ST_TH - 1) / ST_TH, B);
+    // 32-bit buffer offsets on both sides: split the batch if a side reaches 2 GiB
+    const size_t in_img = (size_t)3 * H * W * 4, out_img = (size_t)OH * OW * 64 * 4;
+    const size_t limit = (size_t)1 << 31;
+    const size_t big = in_img > out_img ? in_img : out_img;
+    if (big >= limit) return (int)hipErrorInvalidValue;
+    const int max_b = (int)((limit - 1) / big);
     const double flops = 2.0 * B * OH * OW * 64.0 * 147.0;
     const double bytes = 4.0 * ((double)B * 3 * H * W + (double)B * OH * OW * 64 + 147.0 * 64);
     ProfScope ps(ctx, "stem_conv7x7_f32", flops, bytes);
-    hipLaunchKernelGGL(stem_conv7x7_kernel, grid, dim3(256), smem, ctx.stream, x, w, scale, shift, out, H, W, OH, OW,
-                       relu);
-    return (int)hipGetLastError();
+    for (int b0 = 0; b0 < B; b0 += max_b) {
+        StemArgs a;
+        a.B = (B - b0 < max_b) ? B - b0 : max_b;
+        a.x = x + (size_t)b0 * 3 * H * W; a.w = w; a.scale = scale; a.shift = shift;
+        a.out = out + (size_t)b0 * OH * OW * 64;
+        a.x_bytes = (unsigned)(in_img * a.B); a.out_bytes = (unsigned)(out_img * a.B);
+        a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.relu = relu;
+        a.tiles_x = (OW + SM_TW - 1) / SM_TW; a.tiles_y = (OH + SM_TH - 1) / SM_TH;
+        a.ntiles = a.B * a.tiles_x * a.tiles_y;
+        const int grid = a.ntiles < 768 ? a.ntiles : 768;   // 3 workgroups per CU (47 KB LDS each), persistent
+        hipLaunchKernelGGL(stem_conv7x7_kernel, dim3(grid), dim3(256), smem, ctx.stream, a);
+        const int rc = (int)hipGetLastError();
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------
