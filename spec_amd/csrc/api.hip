@@ -35,6 +35,10 @@ struct ConvW {
 struct Bneck {
     ConvW c1, c2, c3, ds;
     bool has_ds = false;
+    // conv3 + bn3 and downsample conv + bn folded into ONE 1x1 GEMM over [conv2 output | block input]:
+    // weights pre-multiplied by the BN scales (fp64), shift = shift3 + shift_ds, scale = 1
+    float *f_w = nullptr, *f_scale = nullptr, *f_shift = nullptr;
+    int f_Npad = 0;
 };
 
 struct FcW {  // Linear layers as H=W=1 convolutions
@@ -204,6 +208,39 @@ static int commit_conv(specmi_handle* h, const std::string& prefix, ConvW& c) {
         pack_wino_weights(w->f.data(), c.cout, c.cin, u);
         if ((rc = dev_upload(h, u.data(), u.size() * 4, (void**)&c.wino, h->param_allocs))) return rc;
     }
+    return SPECMI_OK;
+}
+
+static int commit_fused_ds(specmi_handle* h, const std::string& prefix, Bneck& b) {
+    const ConvW &c3 = b.c3, &ds = b.ds;
+    const HostTensor *w3, *wd, *g3, *b3, *m3, *v3, *gd, *bd, *md, *vd;
+    int rc;
+    if ((rc = need(h, prefix + c3.name + ".weight", {c3.cout, c3.cin, 1, 1}, false, &w3))) return rc;
+    if ((rc = need(h, prefix + ds.name + ".weight", {ds.cout, ds.cin, 1, 1}, false, &wd))) return rc;
+    if ((rc = need(h, prefix + c3.bn_name + ".weight", {c3.cout}, false, &g3))) return rc;
+    if ((rc = need(h, prefix + c3.bn_name + ".bias", {c3.cout}, false, &b3))) return rc;
+    if ((rc = need(h, prefix + c3.bn_name + ".running_mean", {c3.cout}, false, &m3))) return rc;
+    if ((rc = need(h, prefix + c3.bn_name + ".running_var", {c3.cout}, false, &v3))) return rc;
+    if ((rc = need(h, prefix + ds.bn_name + ".weight", {ds.cout}, false, &gd))) return rc;
+    if ((rc = need(h, prefix + ds.bn_name + ".bias", {ds.cout}, false, &bd))) return rc;
+    if ((rc = need(h, prefix + ds.bn_name + ".running_mean", {ds.cout}, false, &md))) return rc;
+    if ((rc = need(h, prefix + ds.bn_name + ".running_var", {ds.cout}, false, &vd))) return rc;
+    const int N = c3.cout, K1 = c3.cin, K2 = ds.cin, K = K1 + K2;
+    const int Npad = round_up(N, 64);
+    std::vector<float> s3, h3, sd, hd;
+    fold_bn(g3->f.data(), b3->f.data(), m3->f.data(), v3->f.data(), N, 1e-5f, Npad, s3, h3);
+    fold_bn(gd->f.data(), bd->f.data(), md->f.data(), vd->f.data(), N, 1e-5f, Npad, sd, hd);
+    std::vector<float> wcat((size_t)N * K), ones(Npad, 1.f), shift(Npad, 0.f), packed;
+    for (int n = 0; n < N; ++n) {
+        for (int k = 0; k < K1; ++k) wcat[(size_t)n * K + k] = (float)((double)w3->f[(size_t)n * K1 + k] * (double)s3[n]);
+        for (int k = 0; k < K2; ++k) wcat[(size_t)n * K + K1 + k] = (float)((double)wd->f[(size_t)n * K2 + k] * (double)sd[n]);
+        shift[n] = h3[n] + hd[n];
+    }
+    pack_gemm_weights(wcat.data(), N, K, 1, 1, K, Npad, packed);
+    b.f_Npad = Npad;
+    if ((rc = dev_upload(h, packed.data(), packed.size() * 4, (void**)&b.f_w, h->param_allocs))) return rc;
+    if ((rc = dev_upload(h, ones.data(), ones.size() * 4, (void**)&b.f_scale, h->param_allocs))) return rc;
+    if ((rc = dev_upload(h, shift.data(), shift.size() * 4, (void**)&b.f_shift, h->param_allocs))) return rc;
     return SPECMI_OK;
 }
 
@@ -397,6 +434,10 @@ struct TrunkOp {
     int relu;
     std::string label;
     size_t in_img, out_img;  // floats per image of input / output (and residual)
+    // fused downsample branch (conv3 ops only): the block input as a second A source
+    const Bneck* fused = nullptr;
+    int in2_buf = -1, H2 = 0, W2 = 0;
+    size_t in2_img = 0;
 };
 
 static int exec_op(specmi_handle* h, const TrunkOp& op, const float* images, float* feat_out, int b0, int nb,
@@ -422,6 +463,12 @@ static int exec_op(specmi_handle* h, const TrunkOp& op, const float* images, flo
     a.B = nb; a.H = op.H; a.W = op.W; a.Cin = c.cin; a.ldx = c.cin;
     a.OH = op.OH; a.OW = op.OW; a.Cout = c.cout; a.Npad = c.Npad; a.ldo = c.cout;
     a.KH = c.k; a.KW = c.k; a.stride = c.stride; a.pad = c.pad; a.relu = op.relu;
+    if (op.fused) {
+        const Bneck& bk = *op.fused;
+        a.w = bk.f_w; a.scale = bk.f_scale; a.shift = bk.f_shift; a.Npad = bk.f_Npad; a.res = nullptr;
+        a.x2 = buf(op.in2_buf) + (size_t)b0 * op.in2_img;
+        a.H2 = op.H2; a.W2 = op.W2; a.ldx2 = bk.ds.cin; a.Cin2 = bk.ds.cin; a.stride2 = bk.ds.stride;
+    }
     if (c.wino && opt_i(h, "winograd", 1) && conv_wino_supported(a)) {
         a.w = c.wino;
         LAUNCHCHK(h, launch_conv_wino(a, ctx), op.label.c_str());
@@ -467,12 +514,17 @@ static int run_trunk(specmi_handle* h, const float* images, int B, int H, int W,
         add(bk.c1, xi, t1, -1, ch, cw, ch, cw, 1, ".conv1");
         add(bk.c2, t1, t2, -1, ch, cw, oh, ow, 1, ".conv2");
         int identity = xi;
-        if (bk.has_ds) {
+        const bool fuse = bk.has_ds && bk.f_w && opt_i(h, "fuse_downsample", 1);
+        if (bk.has_ds && !fuse) {
             add(bk.ds, xi, idb, -1, ch, cw, oh, ow, 0, ".downsample");
             identity = idb;
         }
         const int out = (last && feat_out) ? -2 : t1;  // t1 is dead after conv2
-        add(bk.c3, t2, out, identity, oh, ow, oh, ow, 1, ".conv3");
+        add(bk.c3, t2, out, fuse ? -1 : identity, oh, ow, oh, ow, 1, fuse ? ".conv3+downsample" : ".conv3");
+        if (fuse) {
+            TrunkOp& o = ops.back();
+            o.fused = &bk; o.in2_buf = xi; o.H2 = ch; o.W2 = cw; o.in2_img = (size_t)ch * cw * bk.ds.cin;
+        }
         ch = oh; cw = ow;
         xi = t1;
         final_buf = out;
@@ -637,6 +689,7 @@ int specmi_commit(specmi_handle* h) {
         if ((rc = commit_conv(h, bp, b.c2))) return rc;
         if ((rc = commit_conv(h, bp, b.c3))) return rc;
         if (b.has_ds && (rc = commit_conv(h, bp, b.ds))) return rc;
+        if (b.has_ds && b.c3.cin % 32 == 0 && b.ds.cin % 32 == 0 && (rc = commit_fused_ds(h, bp, b))) return rc;
     }
     if (h->kind == SPECMI_MODEL_CAMCALIB) {
         const char* names[3] = {"fc_vfov", "fc_pitch", "fc_roll"};

@@ -51,6 +51,10 @@ struct KArgs {
     const float* res;
     float* out;
     unsigned x_bytes, w_bytes;  // buffer extents (< 2^31)
+    // optional second A source of a 1x1 layer (K = Cin + Cin2): the block input of a fused downsample branch
+    const float* x2;
+    unsigned x2_bytes;
+    int H2, W2, ldx2, stride2, cpc1;   // cpc1 = 32-channel chunks that come from x
     int H, W, ldx;
     int OW, OHW, Cout, Npad, ldo;
     int KH, KW, stride, pad;
@@ -74,8 +78,9 @@ struct KArgs {
 
 constexpr unsigned kOutOfRange = 0x80000000u;  // >= any buffer extent: the load returns zeros
 
-template <int BM, int BN, int WGM, int WGN, bool IS1X1, int BK>
+template <int BM, int BN, int WGM, int WGN, bool IS1X1, int BK, bool DUAL = false>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KArgs p) {
+    static_assert(!DUAL || IS1X1, "the second A source exists for 1x1 layers only");
     constexpr int LDA = BK + 4;
     constexpr int KQ = BK / 4;   // 16-byte k-quads per chunk row
     constexpr int NQ = BK / 8;   // 8-k sub-chunks per chunk
@@ -106,9 +111,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
     // ---- buffer descriptors (wave-uniform) and per-thread row offsets -----------------------
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t x2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DUAL ? p.x2 : p.x), 0, DUAL ? p.x2_bytes : p.x_bytes, 0x00020000);
     const int a_kq = tid % KQ, a_r = tid / KQ;
     unsigned a_voff[AI];   // byte offset of (row's tap-(0,0) pixel, quad a_kq); out-of-range when the row is past M (1x1)
     unsigned a_mask[AI];   // 3x3: bit t = filter tap t lies inside the image for this row
+    unsigned a_voff2[DUAL ? AI : 1];   // DUAL: the row's pixel in the second source (its own size / stride / channel count)
     // The tile prologue sits on every workgroup's critical path, so the pixel decode avoids the
     // ~40-instruction integer divide: 1x1/stride-1 rows address the input with m itself, other
     // shapes divide by OH*OW and OW with host-computed magic multipliers.
@@ -117,6 +124,18 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
         const int m = m0 + a_r + ARS * i;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
+        if (DUAL) {
+            if (p.stride2 == 1) {
+                a_voff2[i] = ok ? (unsigned)(mm * p.ldx2 * 4 + a_kq * 16) : kOutOfRange;
+            } else {
+                const int b2 = p.OHW == 1 ? mm : (int)(__umulhi((unsigned)mm, p.mg_ohw) >> p.sh_ohw);
+                const int rem2 = mm - b2 * p.OHW;
+                const int oy2 = p.OW == 1 ? rem2 : (int)(__umulhi((unsigned)rem2, p.mg_ow) >> p.sh_ow);
+                const int ox2 = rem2 - oy2 * p.OW;
+                const int pix2 = (b2 * p.H2 + oy2 * p.stride2) * p.W2 + ox2 * p.stride2;
+                a_voff2[i] = ok ? (unsigned)(pix2 * p.ldx2 * 4 + a_kq * 16) : kOutOfRange;
+            }
+        }
         if (IS1X1 && p.stride == 1) {
             a_voff[i] = ok ? (unsigned)(mm * p.ldx * 4 + a_kq * 16) : kOutOfRange;
             a_mask[i] = 0;
@@ -159,14 +178,19 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
             const int ky = tap / p.KW, kx = tap - ky * p.KW;
             tap_bytes = (unsigned)((ky * p.W + kx) * p.ldx * 4);
         }
-        const unsigned s_a = (unsigned)(c0 * BK * 4);
+        const bool second = DUAL && c >= p.cpc1;   // wave-uniform: chunks past cpc1 read the second source
+        const unsigned s_a = (unsigned)((second ? c0 - p.cpc1 : c0) * BK * 4);
         const unsigned s_b = (unsigned)(c * KQ * p.Npad * 16);
         if (!TUNE_ABLATE(16)) {
 #pragma unroll
             for (int i = 0; i < AI; ++i) {
                 unsigned voff = a_voff[i];
                 if (!IS1X1) voff = ((a_mask[i] >> tap) & 1u) ? voff + tap_bytes : kOutOfRange;
-                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, s_a, 0));
+                if (DUAL) {   // one load either way: descriptor picked with scalar selects, offset with one v_cndmask
+                    ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(second ? x2rs : xrs, second ? a_voff2[i] : voff, s_a, 0));
+                } else {
+                    ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, s_a, 0));
+                }
             }
         }
         if (!TUNE_ABLATE(32)) {
@@ -351,7 +375,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
 #endif
 }
 
-template <int BM, int BN, int WGM, int WGN, bool IS1X1, int BK = 32>
+template <int BM, int BN, int WGM, int WGN, bool IS1X1, int BK = 32, bool DUAL = false>
 static int launch_variant(const KArgs& k, int M, const LaunchCtx& ctx, const char* name, double flops,
                           double bytes) {
     constexpr size_t ab = (size_t)(2 * BM * (BK + 4) + 2 * (BK / 4) * BN * 4) * sizeof(float);
@@ -360,7 +384,7 @@ static int launch_variant(const KArgs& k, int M, const LaunchCtx& ctx, const cha
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&conv_igemm_f32_kernel<BM, BN, WGM, WGN, IS1X1, BK>),
+            reinterpret_cast<const void*>(&conv_igemm_f32_kernel<BM, BN, WGM, WGN, IS1X1, BK, DUAL>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -372,7 +396,7 @@ static int launch_variant(const KArgs& k, int M, const LaunchCtx& ctx, const cha
     ProfScope ps(ctx, name, flops, bytes);
     kk.cpc = k.cpc * 32 / BK;
     kk.nchunks = k.nchunks * 32 / BK;
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WGM, WGN, IS1X1, BK>), dim3(grid), dim3(64 * WGM * WGN), smem,
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WGM, WGN, IS1X1, BK, DUAL>), dim3(grid), dim3(64 * WGM * WGN), smem,
                        ctx.stream, kk);
     return (int)hipGetLastError();
 }
@@ -406,6 +430,11 @@ static int pick_variant(int M, int Npad, bool is1x1) {
 
 const char* conv_igemm_variant(const ConvArgs& a) {
     return kVariantNames[pick_variant(a.B * a.OH * a.OW, a.Npad, a.KH == 1 && a.KW == 1 && a.pad == 0)];
+}
+
+static int dispatch_dual(int v, const KArgs& k, int M, const LaunchCtx& ctx, double flops, double bytes) {
+    if (v == 4) return launch_variant<128, 128, 4, 2, true, 32, true>(k, M, ctx, "conv_igemm_f32<128x128,4x2,2src>", flops, bytes);
+    return launch_variant<64, 64, 2, 2, true, 32, true>(k, M, ctx, "conv_igemm_f32<64x64,2x2,2src>", flops, bytes);
 }
 
 template <bool IS1X1>
@@ -442,42 +471,51 @@ static int launch_one(const ConvArgs& a, const LaunchCtx& ctx) {
     k.KH = a.KH; k.KW = a.KW; k.stride = a.stride; k.pad = a.pad;
     const int M = a.B * a.OH * a.OW;
     k.M = M;
+    const bool dual = a.x2 != nullptr;
     k.cpc = a.Cin / 32;
-    k.nchunks = a.KH * a.KW * k.cpc;
+    k.nchunks = a.KH * a.KW * k.cpc + (dual ? a.Cin2 / 32 : 0);
+    k.x2 = a.x2; k.H2 = a.H2; k.W2 = a.W2; k.ldx2 = a.ldx2; k.stride2 = a.stride2; k.cpc1 = k.cpc;
+    k.x2_bytes = dual ? (unsigned)((size_t)a.B * a.H2 * a.W2 * a.ldx2 * 4) : 0u;
     k.nbn = 0;
     k.relu = a.relu;
     magic_u32((unsigned)k.OHW, &k.mg_ohw, &k.sh_ohw);
     magic_u32((unsigned)a.OW, &k.mg_ow, &k.sh_ow);
     k.x_bytes = (unsigned)((size_t)a.B * a.H * a.W * a.ldx * 4);
-    k.w_bytes = (unsigned)((size_t)a.KH * a.KW * a.Cin * a.Npad * 4);
+    k.w_bytes = (unsigned)(((size_t)a.KH * a.KW * a.Cin + (dual ? a.Cin2 : 0)) * a.Npad * 4);
 #ifdef SPECMI_TUNE
     k.ablate = g_ablate;
     k.tprof = g_tprof;
 #endif
     k.vec_ok = (a.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0) &&
                (!a.res || (reinterpret_cast<uintptr_t>(a.res) & 15) == 0);
-    const double Kd = (double)a.KH * a.KW * a.Cin;
+    const double Kd = (double)a.KH * a.KW * a.Cin + (dual ? a.Cin2 : 0);
     const double flops = 2.0 * (double)M * a.Cout * Kd;
-    const double bytes = 4.0 * ((double)a.B * a.H * a.W * a.Cin + (double)M * a.Cout * (a.res ? 2.0 : 1.0) +
-                                Kd * a.Cout);
+    const double bytes = 4.0 * ((double)a.B * a.H * a.W * a.Cin + (dual ? (double)M * a.Cin2 : 0.0) +
+                                (double)M * a.Cout * (a.res ? 2.0 : 1.0) + Kd * a.Cout);
     const bool is1x1 = (a.KH == 1 && a.KW == 1 && a.pad == 0);
     const int v = pick_variant(M, a.Npad, is1x1);
+    if (dual) return dispatch_dual(v, k, M, ctx, flops, bytes);
     return is1x1 ? dispatch<true>(v, k, M, ctx, flops, bytes) : dispatch<false>(v, k, M, ctx, flops, bytes);
 }
 
 int launch_conv_igemm(const ConvArgs& a, const LaunchCtx& ctx) {
     if (a.Cin % 32 != 0 || a.Npad % 64 != 0 || a.ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(a.x) & 15))
         return (int)hipErrorInvalidValue;
+    if (a.x2 && (a.KH != 1 || a.KW != 1 || a.pad != 0 || a.Cin2 % 32 != 0 || a.ldx2 % 4 != 0 ||
+                 (reinterpret_cast<uintptr_t>(a.x2) & 15)))
+        return (int)hipErrorInvalidValue;
     // buffer addressing is 32-bit: split the batch when the activation tensor reaches 2 GiB
-    const size_t img_bytes = (size_t)a.H * a.W * a.ldx * 4;
+    size_t img_bytes = (size_t)a.H * a.W * a.ldx * 4;
+    if (a.x2 && (size_t)a.H2 * a.W2 * a.ldx2 * 4 > img_bytes) img_bytes = (size_t)a.H2 * a.W2 * a.ldx2 * 4;
     const size_t limit = (size_t)1 << 31;
-    if (img_bytes >= limit || (size_t)a.KH * a.KW * a.Cin * a.Npad * 4 >= limit) return (int)hipErrorInvalidValue;
+    if (img_bytes >= limit || ((size_t)a.KH * a.KW * a.Cin + a.Cin2) * a.Npad * 4 >= limit) return (int)hipErrorInvalidValue;
     const int max_b = (int)((limit - 1) / img_bytes);
     if (a.B <= max_b) return launch_one(a, ctx);
     for (int b0 = 0; b0 < a.B; b0 += max_b) {
         ConvArgs s = a;
         s.B = (a.B - b0 < max_b) ? a.B - b0 : max_b;
         s.x = a.x + (size_t)b0 * a.H * a.W * a.ldx;
+        if (a.x2) s.x2 = a.x2 + (size_t)b0 * a.H2 * a.W2 * a.ldx2;
         const size_t orow = (size_t)b0 * a.OH * a.OW * a.ldo;
         s.out = a.out + orow;
         if (a.res) s.res = a.res + orow;

@@ -53,7 +53,7 @@ struct WArgs {
 #endif
 };
 
-#ifdef WINO_ABLATE   // compile-time perf ablation (wrong results): 1 no U loads, 2 no raw loads, 4 no transform, 8 no A reads, 16 no stage barrier
+#ifdef WINO_ABLATE   // compile-time perf ablation (wrong results): 1 no U loads, 2 no raw loads, 4 no transform, 8 no A reads, 16 no stage barrier, 32 no output stores, 64 no epilogue exchange
 #define WABL(bit) ((WINO_ABLATE) & (bit))
 #else
 #define WABL(bit) 0
@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
     auto emit = [&](float v, unsigned off) {
         v = fmaf(v, sc, sh);
         if (p.relu) v = fmaxf(v, 0.f);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ors, off + co_b, 0, 0);
+        if (!WABL(32)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ors, off + co_b, 0, 0);
     };
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 

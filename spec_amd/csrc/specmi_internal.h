@@ -70,6 +70,10 @@ struct ConvArgs {
     int OH, OW, Cout, Npad, ldo;
     int KH, KW, stride, pad;
     int relu;
+    // optional second A source of a 1x1 layer: out = [x | x2(strided)] * w, K = Cin + Cin2 (rows k >= Cin of w);
+    // used to fold a bottleneck's downsample branch into its conv3
+    const float* x2 = nullptr;
+    int H2 = 0, W2 = 0, ldx2 = 0, Cin2 = 0, stride2 = 1;
 };
 // Cin % 32 == 0, Npad % 64 == 0.  Returns hipError as int.
 int launch_conv_igemm(const ConvArgs& a, const LaunchCtx& ctx);

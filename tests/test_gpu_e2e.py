@@ -40,6 +40,33 @@ def test_trunk_vs_oracle(models):
     assert err < 2e-5, err
 
 
+@pytest.mark.parametrize('B,H,W', [(2, 224, 224), (3, 96, 160)])
+def test_trunk_execution_plans_agree(models, B, H, W):
+    """The trunk's layer plan is an optimisation choice, not a result: Winograd vs direct 3x3, and the
+    downsample branch folded into conv3 (one GEMM over two sources, BN scales folded into the weights)
+    vs separate launch + residual add must give the same features (fp32 rounding apart), also at a
+    non-square size where the stride-2 second source has odd geometry."""
+    _, hm = models
+    eng = hm.engine(torch.device(DEV))
+    x = t(synth.images(13, B))[:, :, :H, :W].contiguous().to(DEV)
+    feats = {}
+    for wino, fuse in ((1, 1), (0, 1), (1, 0), (0, 0)):
+        eng.set_option('winograd', wino)
+        eng.set_option('fuse_downsample', fuse)
+        feats[(wino, fuse)] = eng.trunk(x).cpu().numpy()
+    eng.set_option('winograd', 1)
+    eng.set_option('fuse_downsample', 1)
+    ref = feats[(0, 0)]
+    for k, v in feats.items():
+        assert v.shape == ref.shape
+        assert rel_err(v, ref) < 2e-5, (k, rel_err(v, ref))
+    eng.profile(True)
+    eng.trunk(x)
+    names = {e['label']: e['kernel'] for e in eng.profile_read()}
+    eng.profile(False)
+    assert '2src' in names['backbone.layer2.0.conv3+downsample'], names
+
+
 def test_camcalib_vs_reference_fixture(models):
     cc, _ = models
     g = golden('camcalib_e2e.npz')
