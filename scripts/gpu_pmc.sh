@@ -28,7 +28,7 @@ for d in $OUT/pmc_${TAG}_*/; do
   for db in $(find $d -name "*.db"); do python scripts/rocprof_summary.py pmc $db >> $OUT/pmc_${TAG}_summary.txt 2>&1; done
   rm -rf $d
 done
-grep -E "GUI_ACTIVE|MFMA|FETCH|WRITE|TCC|WAIT|conv_igemm|stem" $OUT/pmc_${TAG}_summary.txt | head -60
+grep -E "GUI_ACTIVE|MFMA|FETCH|WRITE|TCC|WAIT|conv_igemm|conv_wino|stem" $OUT/pmc_${TAG}_summary.txt | head -60
 tail -2 $OUT/pmc_$TAG.log | cut -c1-200
 rm -f $OUT/pmc_$TAG.log
 head -c 200000 $OUT/counters_avail.txt > $OUT/counters_avail_head.txt; rm -f $OUT/counters_avail.txt

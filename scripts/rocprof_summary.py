@@ -49,27 +49,42 @@ def pmc(dbs):
 
 
 def traffic(dbs):
-    """HBM traffic of the conv_igemm kernels from FETCH_SIZE / WRITE_SIZE passes (KB units).
+    """HBM traffic per kernel family from FETCH_SIZE / WRITE_SIZE passes (KB units).
     gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B request of a
-    wide coalesced stream, so the read side is doubled; WRITE_SIZE is taken as reported."""
+    wide coalesced stream, so the read side is doubled; WRITE_SIZE is taken as reported.
+    Top-level keys describe the dominant family (conv_igemm_f32, what bench.py reports as
+    roofline.traffic); 'families' holds the same numbers for the other conv kernels."""
     import json
-    tot = {}
-    for db in dbs:
-        c = sqlite3.connect(db)
-        cur = c.execute('select * from counters_collection limit 1')
-        cols = [d[0] for d in cur.description]
-        namec = 'kernel_name' if 'kernel_name' in cols else 'name'
-        q = (f"select counter_name, count(*), sum(value) from counters_collection where {namec} like '%conv_igemm%' "
-             f"and counter_name in ('FETCH_SIZE','WRITE_SIZE') group by counter_name")
-        for cn, n, sm in c.execute(q):
-            tot[cn] = (n, sm)
-    out = {'kernel': 'conv_igemm_f32 (all tile variants)'}
-    if 'FETCH_SIZE' in tot and 'WRITE_SIZE' in tot:
+
+    def family(pattern):
+        tot = {}
+        for db in dbs:
+            c = sqlite3.connect(db)
+            cur = c.execute('select * from counters_collection limit 1')
+            cols = [d[0] for d in cur.description]
+            namec = 'kernel_name' if 'kernel_name' in cols else 'name'
+            q = (f"select counter_name, count(*), sum(value) from counters_collection where {namec} like '%{pattern}%' "
+                 f"and counter_name in ('FETCH_SIZE','WRITE_SIZE') group by counter_name")
+            for cn, n, sm in c.execute(q):
+                tot[cn] = (n, sm)
+        if 'FETCH_SIZE' not in tot or 'WRITE_SIZE' not in tot:
+            return None
         nf, f = tot['FETCH_SIZE']; nw, w = tot['WRITE_SIZE']
-        out.update({'launches_fetch_pass': nf, 'launches_write_pass': nw, 'FETCH_SIZE_KB_sum': f, 'WRITE_SIZE_KB_sum': w,
-                    'read_bytes_per_launch': 2.0 * f * 1024 / nf, 'write_bytes_per_launch': w * 1024 / nw,
-                    'traffic_bytes_per_launch': 2.0 * f * 1024 / nf + w * 1024 / nw,
-                    'correction': 'read = 2 x FETCH_SIZE (gfx950 counts 64 B per 128-B request), write = WRITE_SIZE'})
+        return {'launches_fetch_pass': nf, 'launches_write_pass': nw, 'FETCH_SIZE_KB_sum': f, 'WRITE_SIZE_KB_sum': w,
+                'read_bytes_per_launch': 2.0 * f * 1024 / nf, 'write_bytes_per_launch': w * 1024 / nw,
+                'traffic_bytes_per_launch': 2.0 * f * 1024 / nf + w * 1024 / nw}
+
+    out = {'kernel': 'conv_igemm_f32 (all tile variants)'}
+    main = family('conv_igemm')
+    if main:
+        out.update(main)
+        out['correction'] = 'read = 2 x FETCH_SIZE (gfx950 counts 64 B per 128-B request), write = WRITE_SIZE'
+    fams = {}
+    for name, pat in (('conv_wino_f32', 'conv_wino'), ('stem_conv7x7', 'stem_conv7x7'), ('maxpool3x3s2', 'maxpool')):
+        r = family(pat)
+        if r:
+            fams[name] = r
+    out['families'] = fams
     print(json.dumps(out, indent=1))
 
 
