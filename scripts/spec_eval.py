@@ -9,7 +9,7 @@ metrics are computed on the device and the ``evaluation_results_<ds>.pkl`` dump 
 Real data (``--npz``: arrays img (N,3,224,224) fp32 normalised crops, cam_rotmat (N,3,3),
 cam_int (N,3,3), scale (N,), center (N,2), orig_shape (N,2)=[h,w], gt_vertices (N,6890,3))
 needs the licensed assets + checkpoint; ``--synthetic N`` builds a stand-in dataset whose ground
-truth is the CPU oracle's prediction plus noise, so the printed numbers exercise the full code path.
+truth is the model's own prediction plus noise, so the printed numbers exercise the full code path.
 """
 import argparse
 import os

@@ -2,7 +2,7 @@
 """Print the measured GPU-vs-reference-fixture / GPU-vs-oracle errors (run on the GPU box)."""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ -> repo root
 sys.path.insert(0, ROOT)
 from spec_amd import synth
 from tests.util import golden, gpu_models, oracle_models, rel_err, t, smpl_model
