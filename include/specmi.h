@@ -95,7 +95,8 @@ const char* specmi_version(void);
  * Any time: "winograd" (default 1: 3x3 / stride-1 convolutions with Cin % 16 == 0 and Cout % 64 == 0
  * run as fused Winograd F(2x2,3x3) on the fp32 matrix cores; 0: always the direct implicit GEMM);
  * "fuse_downsample" (default 1: a bottleneck's downsample conv + BN is folded into its conv3 as one 1x1
- * GEMM over [conv2 output | block input]; 0: separate launch + residual add, as torchvision writes it). */
+ * GEMM over [conv2 output | block input]; 0: separate launch + residual add, as torchvision writes it);
+ * "fc_splitk" (default 1: FC GEMMs with <= 1024 rows run as parallel K slices + a fixed-order reduction). */
 int specmi_set_option_i32(specmi_handle* h, const char* name, int value);
 int specmi_set_option_f32(specmi_handle* h, const char* name, float value);
 

@@ -72,6 +72,8 @@ struct specmi_handle {
     float *rot_ws = nullptr, *betas_ws = nullptr, *cam_ws = nullptr, *verts_ws = nullptr;
     float *pf_ws = nullptr, *A_ws = nullptr, *pj_ws = nullptr;
     int ws_B = 0;
+    float *splitk_ws = nullptr, *zeros = nullptr;   // split-K partial tiles (own allocations: hipMalloc here is graph-unsafe, so done in ensure_ws)
+    size_t splitk_floats = 0;
 
     Profiler prof;
 };
@@ -403,6 +405,11 @@ static int ensure_ws(specmi_handle* h, int B, int H, int W) {
     if ((rc = dev_alloc(h, (size_t)Bp * 72 * 4, (void**)&h->pj_ws, h->ws_allocs))) return rc;
     HIPCHK(h, hipMemset(h->pf_ws, 0, (size_t)Bp * (208 + 10) * 4));
     HIPCHK(h, hipMemset(h->A_ws, 0, (size_t)Bp * 288 * 4));
+    // split-K partial tiles of the FC GEMMs (<= 16 slices x 1024 rows x 1024 columns) and a row of zeros
+    h->splitk_floats = (size_t)16 * (Bp < 1024 ? Bp : 1024) * 1024;
+    if ((rc = dev_alloc(h, h->splitk_floats * 4, (void**)&h->splitk_ws, h->ws_allocs))) return rc;
+    if ((rc = dev_alloc(h, 4096 * 4, (void**)&h->zeros, h->ws_allocs))) return rc;
+    HIPCHK(h, hipMemset(h->zeros, 0, 4096 * 4));
     h->ws_B = Bw;
     return SPECMI_OK;
 }
@@ -418,6 +425,11 @@ static int run_fc(specmi_handle* h, const FcW& fc, const float* x, int ldx, int 
     a.OH = 1; a.OW = 1; a.Cout = fc.nout; a.Npad = fc.Npad; a.ldo = ldo;
     a.KH = 1; a.KW = 1; a.stride = 1; a.pad = 0; a.relu = 0;
     LaunchCtx ctx{s, &h->prof, label};
+    const int S = opt_i(h, "fc_splitk", 1) ? conv_igemm_splitk_plan(a) : 1;
+    if (S > 1 && h->splitk_ws && h->zeros && (size_t)S * B * fc.Npad <= h->splitk_floats && fc.Npad <= 4096) {
+        LAUNCHCHK(h, launch_conv_igemm_splitk(a, S, h->splitk_ws, fc.scale, h->zeros, ctx), label);   // fc.scale is all ones
+        return SPECMI_OK;
+    }
     LAUNCHCHK(h, launch_conv_igemm(a, ctx), label);
     return SPECMI_OK;
 }

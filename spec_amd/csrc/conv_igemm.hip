@@ -61,6 +61,7 @@ struct KArgs {
     int M, nbn, nchunks, cpc;  // cpc = chunks per filter tap = Cin / 32
     unsigned mg_ohw, sh_ohw, mg_ow, sh_ow;  // magic multipliers: n / OHW, n / OW for n < 2^31
     int relu;
+    long split_out_stride;   // SPLITK: blockIdx.y = K slice z of nchunks chunks; partial tile z goes to out + z * stride
     int vec_ok;  // out/res rows are 16-byte aligned: float4 epilogue traffic allowed
 #ifdef SPECMI_TUNE
     int ablate;  // perf ablation bits (wrong results!): 1 no global loads in loop, 2 no LDS restage, 4 no epilogue stores
@@ -78,8 +79,9 @@ struct KArgs {
 
 constexpr unsigned kOutOfRange = 0x80000000u;  // >= any buffer extent: the load returns zeros
 
-template <int BM, int BN, int WGM, int WGN, bool IS1X1, int BK, bool DUAL = false>
+template <int BM, int BN, int WGM, int WGN, bool IS1X1, int BK, bool DUAL = false, bool SPLITK = false>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KArgs p) {
+    static_assert(!SPLITK || (IS1X1 && !DUAL), "split-K serves the small-M FC GEMMs");
     static_assert(!DUAL || IS1X1, "the second A source exists for 1x1 layers only");
     constexpr int LDA = BK + 4;
     constexpr int KQ = BK / 4;   // 16-byte k-quads per chunk row
@@ -172,7 +174,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
     // chunk c = (tap, 32-channel slice); the per-chunk part of every address is scalar
     auto load_chunk = [&](int c) {
         const int tap = IS1X1 ? 0 : c / p.cpc;
-        const int c0 = IS1X1 ? c : c - tap * p.cpc;
+        const int c0 = IS1X1 ? (SPLITK ? c + (int)blockIdx.y * p.nchunks : c) : c - tap * p.cpc;
         unsigned tap_bytes = 0;
         if (!IS1X1) {
             const int ky = tap / p.KW, kx = tap - ky * p.KW;
@@ -180,7 +182,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
         }
         const bool second = DUAL && c >= p.cpc1;   // wave-uniform: chunks past cpc1 read the second source
         const unsigned s_a = (unsigned)((second ? c0 - p.cpc1 : c0) * BK * 4);
-        const unsigned s_b = (unsigned)(c * KQ * p.Npad * 16);
+        const unsigned s_b = (unsigned)((SPLITK ? c0 : c) * KQ * p.Npad * 16);
         if (!TUNE_ABLATE(16)) {
 #pragma unroll
             for (int i = 0; i < AI; ++i) {
@@ -311,6 +313,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
     // 4-byte stores at a row stride; after the transpose every lane moves 16 contiguous bytes.
     // All waves have passed the barrier above, so the A/B stages are free to reuse.
     float* Cs = smem;
+    float* const outp = SPLITK ? p.out + (size_t)blockIdx.y * p.split_out_stride : p.out;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -342,7 +345,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            if (m < p.M && !TUNE_ABLATE(4)) *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.ldo + n) = v;
+            if (m < p.M && !TUNE_ABLATE(4)) *reinterpret_cast<f32x4*>(outp + (size_t)m * p.ldo + n) = v;
         }
     } else {
         for (int ps = 0; ps < NP; ++ps) {
@@ -355,7 +358,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
                     float t = fmaf(Cs[row * LDC + cq * 4 + e], sc[e], sh[e]);
                     if (p.res) t += p.res[o + e];
                     if (p.relu) t = fmaxf(t, 0.f);
-                    p.out[o + e] = t;
+                    outp[o + e] = t;
                 }
             }
         }
@@ -375,16 +378,16 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
 #endif
 }
 
-template <int BM, int BN, int WGM, int WGN, bool IS1X1, int BK = 32, bool DUAL = false>
+template <int BM, int BN, int WGM, int WGN, bool IS1X1, int BK = 32, bool DUAL = false, bool SPLITK = false>
 static int launch_variant(const KArgs& k, int M, const LaunchCtx& ctx, const char* name, double flops,
-                          double bytes) {
+                          double bytes, int nsplit = 1) {
     constexpr size_t ab = (size_t)(2 * BM * (BK + 4) + 2 * (BK / 4) * BN * 4) * sizeof(float);
     constexpr size_t cb = (size_t)BM * (BN + 4) * sizeof(float);
     constexpr size_t smem = ab > cb ? ab : cb;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&conv_igemm_f32_kernel<BM, BN, WGM, WGN, IS1X1, BK, DUAL>),
+            reinterpret_cast<const void*>(&conv_igemm_f32_kernel<BM, BN, WGM, WGN, IS1X1, BK, DUAL, SPLITK>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -396,7 +399,7 @@ static int launch_variant(const KArgs& k, int M, const LaunchCtx& ctx, const cha
     ProfScope ps(ctx, name, flops, bytes);
     kk.cpc = k.cpc * 32 / BK;
     kk.nchunks = k.nchunks * 32 / BK;
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WGM, WGN, IS1X1, BK, DUAL>), dim3(grid), dim3(64 * WGM * WGN), smem,
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WGM, WGN, IS1X1, BK, DUAL, SPLITK>), dim3(grid, nsplit), dim3(64 * WGM * WGN), smem,
                        ctx.stream, kk);
     return (int)hipGetLastError();
 }
@@ -478,6 +481,7 @@ static int launch_one(const ConvArgs& a, const LaunchCtx& ctx) {
     k.x2_bytes = dual ? (unsigned)((size_t)a.B * a.H2 * a.W2 * a.ldx2 * 4) : 0u;
     k.nbn = 0;
     k.relu = a.relu;
+    k.split_out_stride = 0;
     magic_u32((unsigned)k.OHW, &k.mg_ohw, &k.sh_ohw);
     magic_u32((unsigned)a.OW, &k.mg_ow, &k.sh_ow);
     k.x_bytes = (unsigned)((size_t)a.B * a.H * a.W * a.ldx * 4);
@@ -496,6 +500,87 @@ static int launch_one(const ConvArgs& a, const LaunchCtx& ctx) {
     const int v = pick_variant(M, a.Npad, is1x1);
     if (dual) return dispatch_dual(v, k, M, ctx, flops, bytes);
     return is1x1 ? dispatch<true>(v, k, M, ctx, flops, bytes) : dispatch<false>(v, k, M, ctx, flops, bytes);
+}
+
+// ---- split-K for the small-M FC GEMMs (CamCalib heads, HMR regressor) ---------------------------------
+// M = batch rows only: a 64x64 tiling gives a few dozen workgroups that each walk the whole K (70 chunks for
+// fc1) - pure latency.  K is cut into S slices (blockIdx.y); slice z writes its raw partial tile to
+// ws[z][M][Npad]; a second launch adds the slices in fixed order (deterministic, batch-invariant) and applies
+// scale / shift / residual / ReLU.
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int S, long slice, int M, int Npad,
+                                                            int Cout, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const float* res, float* out,
+                                                            int ldo, int relu) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nq = Npad / 4;
+    if (i >= (long)M * nq) return;
+    const int m = (int)(i / nq), n = (int)(i % nq) * 4;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(ws + (size_t)m * Npad + n);
+    for (int z = 1; z < S; ++z) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ws + (size_t)z * slice + (size_t)m * Npad + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (n + e >= Cout) break;
+        float t = fmaf(acc[e], scale[n + e], shift[n + e]);
+        const size_t o = (size_t)m * ldo + n + e;
+        if (res) t += res[o];
+        if (relu) t = fmaxf(t, 0.f);
+        out[o] = t;
+    }
+}
+
+int conv_igemm_splitk_plan(const ConvArgs& a) {
+    const bool is1x1 = (a.KH == 1 && a.KW == 1 && a.pad == 0 && a.stride == 1);
+    const int M = a.B * a.OH * a.OW;
+    if (!is1x1 || a.x2 || M > 1024 || g_force_variant) return 1;
+    const int nch = a.Cin / 32;
+    int best = 1;
+    for (int s = 2; s <= 16; ++s)
+        if (nch % s == 0 && nch / s >= 8) best = s;
+    return best;
+}
+
+int launch_conv_igemm_splitk(const ConvArgs& a, int S, float* ws, const float* ones, const float* zeros,
+                             const LaunchCtx& ctx) {
+    if (a.Cin % (32 * S) != 0 || a.Npad % 64 != 0 || a.ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(a.x) & 15))
+        return (int)hipErrorInvalidValue;
+    KArgs k;
+    const int M = a.B * a.OH * a.OW;
+    k.x = a.x; k.w = a.w; k.scale = ones; k.shift = zeros; k.res = nullptr; k.out = ws;
+    k.H = a.H; k.W = a.W; k.ldx = a.ldx;
+    k.OW = a.OW; k.OHW = a.OH * a.OW; k.Cout = a.Npad; k.Npad = a.Npad; k.ldo = a.Npad;
+    k.KH = 1; k.KW = 1; k.stride = 1; k.pad = 0;
+    k.M = M;
+    k.cpc = a.Cin / 32;
+    k.nchunks = k.cpc / S;
+    k.nbn = 0;
+    k.relu = 0;
+    k.x2 = nullptr; k.x2_bytes = 0; k.H2 = k.W2 = k.ldx2 = 0; k.stride2 = 1; k.cpc1 = k.cpc;
+    k.split_out_stride = (long)M * a.Npad;
+    magic_u32((unsigned)k.OHW, &k.mg_ohw, &k.sh_ohw);
+    magic_u32((unsigned)a.OW, &k.mg_ow, &k.sh_ow);
+    k.x_bytes = (unsigned)((size_t)a.B * a.H * a.W * a.ldx * 4);
+    k.w_bytes = (unsigned)((size_t)a.Cin * a.Npad * 4);
+#ifdef SPECMI_TUNE
+    k.ablate = 0; k.tprof = nullptr;
+#endif
+    k.vec_ok = 1;
+    const double flops = 2.0 * (double)M * a.Cout * a.Cin;
+    const double bytes = 4.0 * ((double)M * a.Cin + (double)M * a.Cout * (a.res ? 2.0 : 1.0) + (double)a.Cin * a.Cout);
+    int rc;
+    {
+        ProfScope ps(ctx, "conv_igemm_f32<64x64,2x2,splitK>", flops, bytes);
+        rc = launch_variant<64, 64, 2, 2, true, 32, false, true>(k, M, LaunchCtx{ctx.stream, nullptr, nullptr}, "", 0, 0, S);
+        if (rc) return rc;
+        const long n = (long)M * (a.Npad / 4);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx.stream, ws, S,
+                           (long)M * a.Npad, M, a.Npad, a.Cout, a.scale, a.shift, a.res, a.out, a.ldo, a.relu);
+        rc = (int)hipGetLastError();
+    }
+    return rc;
 }
 
 int launch_conv_igemm(const ConvArgs& a, const LaunchCtx& ctx) {

@@ -77,6 +77,10 @@ struct ConvArgs {
 };
 // Cin % 32 == 0, Npad % 64 == 0.  Returns hipError as int.
 int launch_conv_igemm(const ConvArgs& a, const LaunchCtx& ctx);
+// small-M 1x1 / FC GEMMs: K slices in parallel + deterministic reduction.  plan() returns the slice count (1 = don't);
+// ws holds S * M * Npad floats, ones / zeros at least Npad floats each.
+int conv_igemm_splitk_plan(const ConvArgs& a);
+int launch_conv_igemm_splitk(const ConvArgs& a, int S, float* ws, const float* ones, const float* zeros, const LaunchCtx& ctx);
 // pick the tile the launcher would use (for tests / labels)
 const char* conv_igemm_variant(const ConvArgs& a);
 
