@@ -300,3 +300,34 @@ def test_conv_batch_split_beyond_2gib(eng):
     ref = _conv_ref(x[idx], w, sc, sh, 1, 0, None, False)
     assert rel_err(y[idx].numpy(), ref.numpy()) < 2e-5
     assert torch.isfinite(y).all()
+
+
+def test_winograd_and_stem_batch_split_beyond_2gib(eng):
+    """The Winograd kernel and the MFMA stem address both sides with 32-bit buffer offsets: an OUTPUT
+    tensor >= 2 GiB must be processed in batch slices too."""
+    # Winograd: 176 x 224 x 224 x 64 x 4 B = 2.10 GiB of output from a 0.53 GiB input
+    B, H, cin, cout = 176, 224, 16, 64
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(B, H, H, cin, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    sc, sh = torch.ones(cout), torch.zeros(cout)
+    y = eng.conv2d(x.to(DEV), w.numpy(), sc.numpy(), sh.numpy(), 1, 1, relu=False)
+    idx = [0, 1, 83, 84, 87, 88, 174, 175]
+    got = y[idx].cpu()
+    assert torch.isfinite(y).all()
+    del y
+    ref = _conv_ref(x[idx], w, sc, sh, 1, 1, None, False)
+    assert rel_err(got.numpy(), ref.numpy()) < 2e-5
+    del x
+    # stem: 700 x 112 x 112 x 64 x 4 B = 2.09 GiB of output
+    B = 700
+    xs = torch.randn(B, 3, 224, 224, generator=g)
+    ws = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    ys = eng.conv2d(xs.to(DEV), ws.numpy(), sc.numpy(), sh.numpy(), 2, 3, relu=True, nchw_input=True)
+    idx = [0, 1, 333, 334, 350, 351, 698, 699]
+    got = ys[idx].cpu()
+    assert torch.isfinite(ys).all()
+    del ys
+    ref = F.relu(F.conv2d(xs[idx], ws, stride=2, padding=3) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+    assert rel_err(got.numpy(), ref.numpy()) < 2e-5
