@@ -11,7 +11,7 @@ if [ "$MODE" = "tests" ]; then
   (timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -60) > $OUT/test_$TAG.log 2>&1
   tail -4 $OUT/test_$TAG.log
 fi
-timeout 300 python bench.py --steps 10 --warmup 3 --no-overlap --no-cpu-baseline > $OUT/bench_${TAG}_serial.json 2> $OUT/bench_${TAG}_serial.err
+timeout 300 python bench.py --steps 10 --warmup 3 --no-overlap --no-graph --no-cpu-baseline > $OUT/bench_${TAG}_serial.json 2> $OUT/bench_${TAG}_serial.err
 cp $OUT/bench_profile.json $OUT/bench_${TAG}_layers.json 2>/dev/null
 timeout 300 python bench.py --steps 10 --warmup 3 > $OUT/bench_${TAG}.json 2> $OUT/bench_${TAG}.err
 for v in 2 3; do
@@ -19,7 +19,7 @@ for v in 2 3; do
 done
 export TMPDIR=/tmp
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile --no-overlap > $OUT/rocprof_$TAG.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile --no-overlap --no-graph > $OUT/rocprof_$TAG.log 2>&1
 cd $R
 for db in $(find $OUT/prof_$TAG -name "*.db"); do python scripts/rocprof_summary.py stats $db > $OUT/rocprof_${TAG}_kernel_stats.txt; done
 rm -rf $OUT/prof_$TAG; head -8 $OUT/rocprof_${TAG}_kernel_stats.txt

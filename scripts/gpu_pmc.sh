@@ -7,7 +7,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 -L > $OUT/counters_avail.txt 2>&1
-BENCH="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-overlap"
+BENCH="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-overlap --no-graph"
 pass() { # name, counters...
   local name=$1; shift
   local ok=""
