@@ -79,9 +79,10 @@ struct KArgs {
 
 constexpr unsigned kOutOfRange = 0x80000000u;  // >= any buffer extent: the load returns zeros
 
-template <int BM, int BN, int WGM, int WGN, bool IS1X1, int BK, bool DUAL = false, bool SPLITK = false>
+template <int BM, int BN, int WGM, int WGN, bool IS1X1, int BK, bool DUAL = false, bool SPLITK = false, bool BDIR = false>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KArgs p) {
     static_assert(!SPLITK || (IS1X1 && !DUAL), "split-K serves the small-M FC GEMMs");
+    static_assert(!(DUAL && !IS1X1), "");
     static_assert(!DUAL || IS1X1, "the second A source exists for 1x1 layers only");
     constexpr int LDA = BK + 4;
     constexpr int KQ = BK / 4;   // 16-byte k-quads per chunk row
@@ -195,7 +196,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
                 }
             }
         }
-        if (!TUNE_ABLATE(32)) {
+        if (!BDIR && !TUNE_ABLATE(32)) {
 #pragma unroll
             for (int i = 0; i < BI; ++i)
                 rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, b_voff[i], s_b, 0));
@@ -205,9 +206,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
 #pragma unroll
         for (int i = 0; i < AI; ++i)
             *reinterpret_cast<f32x4*>(&As[buf * A_STAGE + (a_r + ARS * i) * LDA + a_kq * 4]) = ra[i];
+        if (!BDIR) {
 #pragma unroll
-        for (int i = 0; i < BI; ++i)
-            *reinterpret_cast<f32x4*>(&Bs[buf * B_STAGE + (tid + NT * i) * 4]) = rb[i];
+            for (int i = 0; i < BI; ++i)
+                *reinterpret_cast<f32x4*>(&Bs[buf * B_STAGE + (tid + NT * i) * 4]) = rb[i];
+        }
     };
 
     // ---- wave / lane coordinates -------------------------------------------------------------
@@ -223,6 +226,19 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // BDIR: the B (weight) fragments never touch LDS - every wave streams its own [32 k][32 n] blocks straight
+    // from L2 into rolling registers (the packed layout [K/4][Npad][4] is already the fragment layout:
+    // lane (n, k half) reads quad 2q + hh of column n), one chunk ahead
+    f32x4 fbq[BDIR ? NQ : 1][TN];
+    const unsigned fb_voff = (unsigned)((hh * p.Npad + n0 + wn * (BN / WGN) + l31) * 16);
+    auto load_bfrag = [&](int c, int q) {
+        const int ca = SPLITK ? c + (int)blockIdx.y * p.nchunks : c;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            fbq[BDIR ? q : 0][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                wrs, fb_voff + (unsigned)(j * 32 * 16), (unsigned)((ca * KQ + 2 * q) * p.Npad * 16), 0));
+    };
+
     // ---- epilogue coordinates (known up front so the residual can be prefetched) ------------
     constexpr int LDC = BN + 4;
     constexpr int QPR = BN / 4;         // float4 quads per tile row
@@ -234,6 +250,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
     f32x4 rr[NP];
 
     load_chunk(0);
+    if (BDIR) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) load_bfrag(0, q);
+    }
     store_chunk(0);
     __syncthreads();
 
@@ -247,8 +267,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
     auto read_frags = [&](const float* Ab, const float* Bb, int q, f32x4 (&fa)[TM], f32x4 (&fb)[TN]) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDA + q * 8);
+        if (!BDIR) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bb + (q * 2 * BN + j * 32) * 4);
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bb + (q * 2 * BN + j * 32) * 4);
+        }
     };
     auto chunk = [&](int c, auto prefetch) {
         constexpr bool PF = decltype(prefetch)::value;
@@ -267,8 +289,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1][i][s], fb[q & 1][j][s], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1][i][s], BDIR ? fbq[BDIR ? q : 0][j][s] : fb[q & 1][j][s], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                if (BDIR && PF && s == 3) load_bfrag(c + 1, q);   // rolling: these registers are next read one chunk from now
                 if (q == 0 && s == 0) {
                     if (PF) {
                         if (!TUNE_ABLATE(1)) load_chunk(c + 1);
@@ -284,7 +307,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
                 if (s == 1 && q < NQ - 1) read_frags(Ab, Bb, q + 1, fa[(q + 1) & 1], fb[(q + 1) & 1]);
                 if (PF && q == NQ - 1 && !TUNE_ABLATE(2)) {   // stage the next chunk: stores spread over the last 4 steps
 #pragma unroll
-                    for (int t = 0; t < AI + BI; ++t) {
+                    for (int t = 0; t < AI + (BDIR ? 0 : BI); ++t) {
                         if ((t & 3) != s) continue;
                         if (t < AI)
                             *reinterpret_cast<f32x4*>(&Asn[(a_r + ARS * t) * LDA + a_kq * 4]) = ra[t];
@@ -378,16 +401,17 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
 #endif
 }
 
-template <int BM, int BN, int WGM, int WGN, bool IS1X1, int BK = 32, bool DUAL = false, bool SPLITK = false>
+template <int BM, int BN, int WGM, int WGN, bool IS1X1, int BK = 32, bool DUAL = false, bool SPLITK = false, bool BDIR = false>
 static int launch_variant(const KArgs& k, int M, const LaunchCtx& ctx, const char* name, double flops,
                           double bytes, int nsplit = 1) {
-    constexpr size_t ab = (size_t)(2 * BM * (BK + 4) + 2 * (BK / 4) * BN * 4) * sizeof(float);
+    constexpr bool b_lds = !BDIR;   // BDIR kernels stage only A: 18 KB -> 7 workgroups per CU instead of 4
+    constexpr size_t ab = (size_t)(2 * BM * (BK + 4) + (b_lds ? 2 * (BK / 4) * BN * 4 : 0)) * sizeof(float);
     constexpr size_t cb = (size_t)BM * (BN + 4) * sizeof(float);
     constexpr size_t smem = ab > cb ? ab : cb;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&conv_igemm_f32_kernel<BM, BN, WGM, WGN, IS1X1, BK, DUAL, SPLITK>),
+            reinterpret_cast<const void*>(&conv_igemm_f32_kernel<BM, BN, WGM, WGN, IS1X1, BK, DUAL, SPLITK, BDIR>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -399,7 +423,7 @@ static int launch_variant(const KArgs& k, int M, const LaunchCtx& ctx, const cha
     ProfScope ps(ctx, name, flops, bytes);
     kk.cpc = k.cpc * 32 / BK;
     kk.nchunks = k.nchunks * 32 / BK;
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WGM, WGN, IS1X1, BK, DUAL, SPLITK>), dim3(grid, nsplit), dim3(64 * WGM * WGN), smem,
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WGM, WGN, IS1X1, BK, DUAL, SPLITK, BDIR>), dim3(grid, nsplit), dim3(64 * WGM * WGN), smem,
                        ctx.stream, kk);
     return (int)hipGetLastError();
 }
@@ -415,29 +439,29 @@ void conv_igemm_force_variant(int v) { g_force_variant = v; }
 
 static const char* kVariantNames[] = {"", "conv_igemm_f32<128x128,2x2>", "conv_igemm_f32<128x64,2x2>",
                                       "conv_igemm_f32<64x64,2x2>", "conv_igemm_f32<128x128,4x2>",
-                                      "conv_igemm_f32<128x64,4x2>", "conv_igemm_f32<64x128,2x4>", "conv_igemm_f32<64x64,2x2,bk16>"};
+                                      "conv_igemm_f32<128x64,4x2>", "conv_igemm_f32<64x128,2x4>", "conv_igemm_f32<64x64,2x2,bk16>",
+                                      "conv_igemm_f32<64x64,2x2,ldsB>", "conv_igemm_f32<128x128,4x2,bdir>"};
 
-static int pick_variant(int M, int Npad, bool is1x1) {
-    if (g_force_variant >= 1 && g_force_variant <= 7) {
-        const bool needs128 = (g_force_variant == 1 || g_force_variant == 4 || g_force_variant == 6);
+static int pick_variant(int M, int Npad, bool is1x1, int K) {
+    if (g_force_variant >= 1 && g_force_variant <= 9) {
+        const bool needs128 = (g_force_variant == 1 || g_force_variant == 4 || g_force_variant == 6 || g_force_variant == 9);
         if (!needs128 || Npad % 128 == 0) return g_force_variant;
     }
-    // Measured on MI355X at B=256 (tools/igemm_bench, profiles/): the 64x64 tile (4 workgroups =
-    // 16 waves per CU sharing the 64-cycle fp32 MFMA pipe) wins on the 3x3 and the small-M layers
-    // (finer work quantisation over 256 CUs); the 8-wave 128x128 tile halves the L2->LDS traffic
-    // and wins by 5-10 % on the large-M 1x1 layers that sit near the HBM roofline
-    // (layer1/layer2 expand convs with their residual, layer2.0 reduce/downsample).
-    if (is1x1 && Npad % 128 == 0 && M >= 131072) return 4;
+    // Measured on MI355X at B=256 (tools/igemm_bench, profiles/): the 64x64 tile with the B fragments
+    // streamed straight from L2 (A alone in LDS: 18 KB, 7 workgroups per CU) wins everywhere except on
+    // the large-M expand convs with K <= 128 (layer1/layer2 conv3 + residual) that sit on the HBM
+    // roofline - there the 8-wave 128x128 tile with both operands staged moves half the L2 traffic.
+    if (is1x1 && Npad % 128 == 0 && M >= 131072 && K <= 128) return 4;
     return 3;
 }
 
 const char* conv_igemm_variant(const ConvArgs& a) {
-    return kVariantNames[pick_variant(a.B * a.OH * a.OW, a.Npad, a.KH == 1 && a.KW == 1 && a.pad == 0)];
+    return kVariantNames[pick_variant(a.B * a.OH * a.OW, a.Npad, a.KH == 1 && a.KW == 1 && a.pad == 0, a.Cin + a.Cin2)];
 }
 
 static int dispatch_dual(int v, const KArgs& k, int M, const LaunchCtx& ctx, double flops, double bytes) {
     if (v == 4) return launch_variant<128, 128, 4, 2, true, 32, true>(k, M, ctx, "conv_igemm_f32<128x128,4x2,2src>", flops, bytes);
-    return launch_variant<64, 64, 2, 2, true, 32, true>(k, M, ctx, "conv_igemm_f32<64x64,2x2,2src>", flops, bytes);
+    return launch_variant<64, 64, 2, 2, true, 32, true, false, true>(k, M, ctx, "conv_igemm_f32<64x64,2x2,2src>", flops, bytes);
 }
 
 template <bool IS1X1>
@@ -450,8 +474,10 @@ static int dispatch(int v, const KArgs& k, int M, const LaunchCtx& ctx, double f
         case 5: return launch_variant<128, 64, 4, 2, IS1X1>(k, M, ctx, kVariantNames[v], flops, bytes);
         case 6: return launch_variant<64, 128, 2, 4, IS1X1>(k, M, ctx, kVariantNames[v], flops, bytes);
         case 7: return launch_variant<64, 64, 2, 2, IS1X1, 16>(k, M, ctx, kVariantNames[v], flops, bytes);
+        case 8: return launch_variant<64, 64, 2, 2, IS1X1, 32, false, false, false>(k, M, ctx, kVariantNames[v], flops, bytes);
+        case 9: return launch_variant<128, 128, 4, 2, IS1X1, 32, false, false, true>(k, M, ctx, kVariantNames[v], flops, bytes);
 #endif
-        default: return launch_variant<64, 64, 2, 2, IS1X1>(k, M, ctx, kVariantNames[3], flops, bytes);
+        default: return launch_variant<64, 64, 2, 2, IS1X1, 32, false, false, true>(k, M, ctx, kVariantNames[3], flops, bytes);
     }
 }
 
@@ -497,7 +523,7 @@ static int launch_one(const ConvArgs& a, const LaunchCtx& ctx) {
     const double bytes = 4.0 * ((double)a.B * a.H * a.W * a.Cin + (dual ? (double)M * a.Cin2 : 0.0) +
                                 (double)M * a.Cout * (a.res ? 2.0 : 1.0) + Kd * a.Cout);
     const bool is1x1 = (a.KH == 1 && a.KW == 1 && a.pad == 0);
-    const int v = pick_variant(M, a.Npad, is1x1);
+    const int v = pick_variant(M, a.Npad, is1x1, a.Cin + (dual ? a.Cin2 : 0));
     if (dual) return dispatch_dual(v, k, M, ctx, flops, bytes);
     return is1x1 ? dispatch<true>(v, k, M, ctx, flops, bytes) : dispatch<false>(v, k, M, ctx, flops, bytes);
 }
@@ -573,7 +599,7 @@ int launch_conv_igemm_splitk(const ConvArgs& a, int S, float* ws, const float* o
     int rc;
     {
         ProfScope ps(ctx, "conv_igemm_f32<64x64,2x2,splitK>", flops, bytes);
-        rc = launch_variant<64, 64, 2, 2, true, 32, false, true>(k, M, LaunchCtx{ctx.stream, nullptr, nullptr}, "", 0, 0, S);
+        rc = launch_variant<64, 64, 2, 2, true, 32, false, true, true>(k, M, LaunchCtx{ctx.stream, nullptr, nullptr}, "", 0, 0, S);
         if (rc) return rc;
         const long n = (long)M * (a.Npad / 4);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx.stream, ws, S,
