@@ -441,10 +441,10 @@ static const char* kVariantNames[] = {"", "conv_igemm_f32<128x128,2x2>", "conv_i
                                       "conv_igemm_f32<64x64,2x2>", "conv_igemm_f32<128x128,4x2>",
                                       "conv_igemm_f32<128x64,4x2>", "conv_igemm_f32<64x128,2x4>", "conv_igemm_f32<64x64,2x2,bk16>",
                                       "conv_igemm_f32<64x64,2x2,ldsB>", "conv_igemm_f32<128x128,4x2,bdir>",
-                                      "conv_igemm_f32<64x128,2x2,bdir>", "conv_igemm_f32<128x64,2x2,bdir>"};
+                                      "conv_igemm_f32<64x128,2x2,bdir>", "conv_igemm_f32<128x64,2x2,bdir>", "conv_igemm_f32<64x64,2x2,bdir,bk64>"};
 
 static int pick_variant(int M, int Npad, bool is1x1, int K) {
-    if (g_force_variant >= 1 && g_force_variant <= 11) {
+    if (g_force_variant >= 1 && g_force_variant <= 12) {
         const bool needs128 = (g_force_variant == 1 || g_force_variant == 4 || g_force_variant == 6 || g_force_variant == 9 || g_force_variant == 10);
         if (!needs128 || Npad % 128 == 0) return g_force_variant;
     }
@@ -479,6 +479,7 @@ static int dispatch(int v, const KArgs& k, int M, const LaunchCtx& ctx, double f
         case 9: return launch_variant<128, 128, 4, 2, IS1X1, 32, false, false, true>(k, M, ctx, kVariantNames[v], flops, bytes);
         case 10: return launch_variant<64, 128, 2, 2, IS1X1, 32, false, false, true>(k, M, ctx, kVariantNames[v], flops, bytes);
         case 11: return launch_variant<128, 64, 2, 2, IS1X1, 32, false, false, true>(k, M, ctx, kVariantNames[v], flops, bytes);
+        case 12: return launch_variant<64, 64, 2, 2, IS1X1, 64, false, false, true>(k, M, ctx, kVariantNames[v], flops, bytes);
 #endif
         default: return launch_variant<64, 64, 2, 2, IS1X1, 32, false, false, true>(k, M, ctx, kVariantNames[3], flops, bytes);
     }
