@@ -12,20 +12,27 @@
 //
 // Work decomposition (CDNA4, wave64):
 //   * GEMM view per frequency f in 0..15:  D_f[t][co] = sum_ci V_f[t][ci] * U_f[ci][co] with
-//     t = 2x2 output tile index in [0, B*TH*TW).  A workgroup (4 waves) owns 32 tiles x 128
-//     output channels; wave w owns co block w (32 channels) for ALL 16 frequencies: 16
-//     accumulator tiles of v_mfma_f32_32x32x2_f32 = 256 accumulator registers per lane, so the
-//     output transform is lane-local (no cross-wave exchange) and one wave per SIMD runs.
+//     t = 2x2 output tile index in [0, B*TH*TW).  Two wave layouts (template NF = frequencies per wave):
+//       NF = 16: workgroup = 32 tiles x 128 co, wave w = co block w for ALL 16 frequencies: 16 accumulator
+//                tiles of v_mfma_f32_32x32x2_f32 = 256 accumulator registers per lane, lane-local output
+//                transform, one wave per SIMD, V triple buffered (picked from Cin = 512);
+//       NF = 8 : workgroup = 32 tiles x 64 co, wave = (co block, frequency columns {2fh, 2fh+1}): 128
+//                accumulators, two workgroups per CU cover each other's epilogues; the two halves of a co
+//                block meet in the output transform through 32 floats per lane of LDS.
 //   * A operand (transformed input V): the 256 threads each own one (tile, channel pair) per
 //     16-channel stage: 16 buffer_load_b64 of the raw 4x4 patch (image border = hardware range
-//     check -> 0.0), B^T d B on packed fp32 adds, 16 ds_write_b64 into the stage buffer laid out
+//     check -> 0.0), B^T d B in registers, 16 ds_write_b64 into the stage buffer laid out
 //     [f][c2][tile][2] exactly as the MFMA A fragments are read back (ds_read_b64, conflict free).
 //   * B operand (transformed filters U = G g G^T, computed in fp64 at commit): never staged -
-//     every wave streams its own fragments straight from L2 with coalesced buffer_load_b64
-//     ([co block][ci/4][f][lane][2] in HBM), one 4-channel micro-chunk ahead, rolling registers.
-//   * K loop: stage = 16 input channels = 4 micro-chunks of 32 MFMAs; V is double buffered, one
-//     barrier per stage; the loads / transform / LDS writes of stage s+1 are slotted between the
-//     MFMAs of stage s.
+//     every wave streams its own fragments straight from L2 with coalesced 16-byte loads
+//     ([co block][ci/4][f/2][lane][(f&1)*2 + jj] in HBM: one load = a frequency pair), 1-2 micro-chunks
+//     ahead, rolling registers.
+//   * K loop: stage = 16 input channels = 4 micro-chunks of NF MFMA pairs, one barrier per stage; the
+//     loads / transform / LDS writes of the next stage are slotted between the MFMAs of this one.
+//   * Persistent workgroups: the (tile, stage) sequence of a workgroup is ONE software pipeline, so the
+//     next tile's patch loads and transform run under the current tile's last stages.
+//   * Epilogue: store addresses come from a 16-byte-per-tile LDS table written by the loader threads;
+//     BatchNorm scale/shift + ReLU fused; buffer stores (out-of-range offset = masked).
 #include "specmi_internal.h"
 
 namespace specmi {
