@@ -18,9 +18,14 @@
 //     sub-chunk q (8 k's), lane half h, step s  ->  k = 8q + 4h + s.  A and B use the same
 //     permutation, so the sum over k is unchanged.
 //   * LDS: A tile [BM][32+4] fp32 (row pad 4 floats => ds_read_b128 of 16 rows hits 64
-//     distinct banks, ds_write_b128 of one row's 8 quads hits 32 distinct banks);
-//     B tile [8][BN][4] fp32 - exactly the HBM layout of the packed weights [K/4][Npad][4],
-//     so the copy is linear and the fragment read (consecutive n per lane) is conflict-free.
+//     distinct banks, ds_write_b128 of one row's 8 quads hits 32 distinct banks).
+//   * B (weights), 64x64 kernel (BDIR): never staged.  The packed HBM layout [K/4][Npad][4] IS the
+//     MFMA fragment layout (lane (n, k half) reads quad 2q + hh of column n), so every wave streams
+//     its own [32 k][32 n] blocks from L2 with 1-KiB coalesced buffer loads into rolling registers,
+//     one chunk ahead: no B traffic through LDS, A-only LDS = 18 KB -> 7 workgroups per CU (+6 %).
+//     The 8-wave 128x128 kernel (HBM-bound expand convs) keeps B staged in LDS as [8][BN][4].
+//   * Variants: two A sources (K = Cin + Cin2: a bottleneck's downsample conv folded into conv3),
+//     split-K over blockIdx.y for the small-M FC GEMMs (fixed-order second-pass reduction).
 //   * The fp32 MFMA holds a SIMD's matrix pipe for 64 cycles but the SIMD has only ~16 issue
 //     slots in that time, shared by all its waves - so everything that is not an MFMA is kept
 //     off the VALU: tile rows are addressed with buffer loads (32-bit per-row offset computed
