@@ -197,6 +197,14 @@ int specmi_crop_normalize(specmi_handle* h, const uint8_t* frame_rgb_hwc, int H,
                           const float* bboxes, int n, float scale, int crop_size, float* out_nchw,
                           uint8_t* raw_hwc, float* bbox_scale, float* bbox_center, void* stream);
 
+/* The CamCalib frame transform (camcalib/pano_dataset.py:156-162, scripts/camcalib_demo.py:100): torchvision
+ * Resize(600) on a PIL image = Pillow's antialiased bilinear resample (Image.resize((OW, OH), BILINEAR): separable
+ * triangle filter, 22-bit fixed-point coefficients, uint8 between the passes) + ToTensor + ImageNet Normalize, from a
+ * uint8 RGB HWC frame in device memory to (3,OH,OW) fp32; bit-identical to Pillow.  The caller picks (OH, OW)
+ * (shorter side 600, longer int(600*long/short)).  Optional raw_hwc: the resized uint8 image (OH,OW,3). */
+int specmi_resize_normalize(specmi_handle* h, const uint8_t* frame_rgb_hwc, int H, int W, int OH, int OW,
+                            float* out_chw, uint8_t* raw_hwc, void* stream);
+
 /* ---- evaluation metrics on the path's outputs ---------------------------------- */
 
 /* eval_single (spec/utils/compute_error.py:52-86, spec/trainer.py:272-316): joints =

@@ -127,3 +127,102 @@ def crop_detections(image, dets, scale=1.0, crop_size=224):
         sc.append(np.float32(bbox[2] / 200.))
         ce.append([np.float32(bbox[0]), np.float32(bbox[1])])
     return np.stack(imgs), np.stack(raws), np.array(sc, np.float32), np.array(ce, np.float32)
+
+
+# ------------------------------------------------------------------------------------------------
+# CamCalib frame transform (camcalib/pano_dataset.py:156-162: torchvision Resize(600) on a PIL image
+# -> ToTensor -> Normalize).  torchvision's Resize(int) on a PIL image calls
+# ``img.resize((ow, oh), Image.BILINEAR)`` with the shorter side set to ``size`` and the longer to
+# ``int(size * long / short)``; Pillow's resize is a separable two-pass convolution (horizontal, then
+# vertical, uint8 in between) with a triangle filter whose support grows with the down-scale factor
+# and 22-bit fixed-point coefficients.  Restated from Pillow's published algorithm
+# (src/libImaging/Resample.c: precompute_coeffs, normalize_coeffs_8bpc, ImagingResampleHorizontal_8bpc /
+# Vertical_8bpc) and PINNED against the installed Pillow binary (tests/test_preprocess.py, bit-exact).
+# ------------------------------------------------------------------------------------------------
+PIL_PRECISION_BITS = 32 - 8 - 2
+
+
+def resize_output_size(w, h, min_size=600):
+    """torchvision.transforms.Resize(int) -> (ow, oh): shorter side = min_size, longer = int(min_size*long/short)."""
+    if w <= h:
+        return min_size, int(min_size * h / w)
+    return int(min_size * w / h), min_size
+
+
+def pil_bilinear_coeffs(in_size, out_size):
+    """precompute_coeffs + normalize_coeffs_8bpc for the triangle filter over the box [0, in_size):
+    -> bounds (out_size, 2) int32 [xmin, count], kk (out_size, ksize) int32 fixed-point weights."""
+    scale = float(in_size) / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(np.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = 0.0 + (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        k = np.zeros(ksize, np.float64)
+        ww = 0.0
+        for x in range(xmax):
+            a = abs((x + xmin - center + 0.5) * ss)
+            w = 1.0 - a if a < 1.0 else 0.0
+            k[x] = w
+            ww += w
+        if ww != 0.0:
+            k[:xmax] = k[:xmax] / ww
+        for x in range(ksize):   # (int)(+-0.5 + k * 2^22): C truncation toward zero
+            v = k[x] * (1 << PIL_PRECISION_BITS)
+            kk[xx, x] = int(-0.5 + v) if k[x] < 0 else int(0.5 + v)
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk
+
+
+def _pil_pass(img, bounds, kk, axis):
+    """One 8bpc resample pass along ``axis`` (1 = horizontal, 0 = vertical) of an (H, W, C) uint8 image."""
+    src = img.astype(np.int64)
+    n = bounds.shape[0]
+    shape = list(img.shape)
+    shape[axis] = n
+    out = np.empty(shape, np.uint8)
+    for i in range(n):
+        lo, cnt = int(bounds[i, 0]), int(bounds[i, 1])
+        w = kk[i, :cnt].astype(np.int64)
+        if axis == 1:
+            acc = (src[:, lo:lo + cnt, :] * w[None, :, None]).sum(axis=1)
+        else:
+            acc = (src[lo:lo + cnt, :, :] * w[:, None, None]).sum(axis=0)
+        acc = (acc + (1 << (PIL_PRECISION_BITS - 1))) >> PIL_PRECISION_BITS
+        v = np.clip(acc, 0, 255).astype(np.uint8)
+        if axis == 1:
+            out[:, i, :] = v
+        else:
+            out[i, :, :] = v
+    return out
+
+
+def pil_resize_bilinear_u8(img, ow, oh):
+    """Image.resize((ow, oh), BILINEAR) of an (H, W, 3) uint8 array: horizontal pass (if the width changes),
+    then vertical pass (if the height changes), uint8 intermediate."""
+    H, W = img.shape[:2]
+    out = img
+    if ow != W:
+        b, k = pil_bilinear_coeffs(W, ow)
+        out = _pil_pass(out, b, k, axis=1)
+    if oh != H:
+        b, k = pil_bilinear_coeffs(H, oh)
+        out = _pil_pass(out, b, k, axis=0)
+    return np.ascontiguousarray(out)
+
+
+def camcalib_transform(frame_u8, min_size=600):
+    """ImageFolder.__getitem__ of camcalib/pano_dataset.py:156-179 -> (3, oh, ow) float32."""
+    H, W = frame_u8.shape[:2]
+    ow, oh = resize_output_size(W, H, min_size)
+    return to_tensor_normalize(pil_resize_bilinear_u8(frame_u8, ow, oh))

@@ -25,22 +25,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def camcalib_input(frame_u8, min_size=600):
-    """ImageFolder transform of camcalib/pano_dataset.py:156-162: Resize(min side 600, PIL bilinear),
-    ToTensor, ImageNet Normalize - done on the host like the reference's dataloader."""
-    from PIL import Image
-    from spec_amd import constants as C
-    img = Image.fromarray(frame_u8)
-    w, h = img.size
-    if w <= h:
-        ow, oh = min_size, int(min_size * h / w)
-    else:
-        oh, ow = min_size, int(min_size * w / h)
-    img = img.resize((ow, oh), Image.BILINEAR)
-    x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255)
-    mean = torch.tensor(C.IMG_NORM_MEAN).view(3, 1, 1)
-    std = torch.tensor(C.IMG_NORM_STD).view(3, 1, 1)
-    return ((x - mean) / std).unsqueeze(0)
+def camcalib_input(frame_u8, min_size=600, device='cuda'):
+    """ImageFolder transform of camcalib/pano_dataset.py:156-162 (Resize(min side 600) of the PIL image,
+    ToTensor, ImageNet Normalize) on the device: the uint8 frame goes to HBM once and
+    ``specmi_resize_normalize`` reproduces Pillow's resample bit for bit."""
+    from spec_amd.preprocess import camcalib_transform
+    return camcalib_transform(torch.from_numpy(np.ascontiguousarray(frame_u8)).to(device), min_size)
 
 
 def main():

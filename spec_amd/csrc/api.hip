@@ -72,6 +72,10 @@ struct specmi_handle {
     float *rot_ws = nullptr, *betas_ws = nullptr, *cam_ws = nullptr, *verts_ws = nullptr;
     float *pf_ws = nullptr, *A_ws = nullptr, *pj_ws = nullptr;
     int ws_B = 0;
+    int* resize_tab = nullptr;          // device copy of the Pillow coefficient tables of the last resize geometry
+    size_t resize_tab_ints = 0;
+    std::vector<int> resize_host;       // host image of the same (kept alive for the async copy)
+    int resize_geom[4] = {0, 0, 0, 0};  // H, W, OH, OW the tables were built for
     float *splitk_ws = nullptr, *zeros = nullptr;   // split-K partial tiles (own allocations: hipMalloc here is graph-unsafe, so done in ensure_ws)
     size_t splitk_floats = 0;
 
@@ -644,6 +648,7 @@ int specmi_destroy(specmi_handle* h) {
     for (auto& r : h->prof.log) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     free_pool(h->ws_allocs);
     free_pool(h->param_allocs);
+    if (h->resize_tab) (void)hipFree(h->resize_tab);
     delete h;
     return SPECMI_OK;
 }
@@ -889,6 +894,38 @@ int specmi_avgpool(specmi_handle* h, const float* x, int B, int HW, int C, float
     if (!x || !out || B <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
     LaunchCtx ctx{(hipStream_t)stream, &h->prof, "avgpool"};
     LAUNCHCHK(h, launch_avgpool(x, out, B, HW, C, C, ctx), "avgpool");
+    return SPECMI_OK;
+}
+
+int specmi_resize_normalize(specmi_handle* h, const uint8_t* frame, int H, int W, int OH, int OW, float* out, uint8_t* raw,
+                            void* stream) {
+    ENTER(h);
+    if (!frame || !out || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    // tables: [hb (2 OW) | hk (OW ksh) | vb (2 OH) | vk (OH ksv)], rebuilt only when the geometry changes
+    std::vector<int> hb, hk, vb, vk;
+    const int ksh = pillow_coeffs(W, OW, hb, hk), ksv = pillow_coeffs(H, OH, vb, vk);
+    const size_t o_hk = hb.size(), o_vb = o_hk + hk.size(), o_vk = o_vb + vb.size(), total = o_vk + vk.size();
+    if (h->resize_geom[0] != H || h->resize_geom[1] != W || h->resize_geom[2] != OH || h->resize_geom[3] != OW || !h->resize_tab) {
+        if (total > h->resize_tab_ints) {
+            HIPCHK(h, hipStreamSynchronize(s));
+            if (h->resize_tab) (void)hipFree(h->resize_tab);
+            h->resize_tab = nullptr;
+            HIPCHK(h, hipMalloc((void**)&h->resize_tab, total * 4));
+            h->resize_tab_ints = total;
+        }
+        HIPCHK(h, hipStreamSynchronize(s));   // a previous launch may still read the old tables
+        h->resize_host.resize(total);
+        std::memcpy(h->resize_host.data(), hb.data(), hb.size() * 4);
+        std::memcpy(h->resize_host.data() + o_hk, hk.data(), hk.size() * 4);
+        std::memcpy(h->resize_host.data() + o_vb, vb.data(), vb.size() * 4);
+        std::memcpy(h->resize_host.data() + o_vk, vk.data(), vk.size() * 4);
+        HIPCHK(h, hipMemcpyAsync(h->resize_tab, h->resize_host.data(), total * 4, hipMemcpyHostToDevice, s));
+        h->resize_geom[0] = H; h->resize_geom[1] = W; h->resize_geom[2] = OH; h->resize_geom[3] = OW;
+    }
+    LaunchCtx ctx{s, &h->prof, "resize_normalize"};
+    LAUNCHCHK(h, launch_resize_normalize(frame, H, W, OH, OW, h->resize_tab, h->resize_tab + o_hk, ksh, h->resize_tab + o_vb,
+                                         h->resize_tab + o_vk, ksv, out, raw, ctx), "resize_normalize");
     return SPECMI_OK;
 }
 

@@ -12,6 +12,8 @@
 // (32-fx)(32-fy)*32 ... summing to 2^15, result (sum + 2^14) >> 15; then (u8/255 - mean)/std
 // in fp32 like ToTensor + Normalize.  Lanes map to consecutive x of one output row, so the
 // NCHW stores are coalesced; the 4 taps x 3 channels come through L2 (a frame is a few MB).
+#include <cmath>
+
 #include "specmi_internal.h"
 
 namespace specmi {
@@ -68,6 +70,95 @@ int launch_crop_normalize(const unsigned char* frame, int H, int W, const float*
     ProfScope ps(ctx, "crop_normalize", 0.0, (double)n * S * S * (12.0 + 12.0 + (raw ? 3.0 : 0.0)));
     hipLaunchKernelGGL(crop_normalize_kernel, dim3((S * S + 255) / 256, n), dim3(256), 0, ctx.stream, frame, H, W, bboxes,
                        scale, S, out, raw, bbox_scale, bbox_center);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// CamCalib frame transform (camcalib/pano_dataset.py:156-162): torchvision Resize(600) on a PIL image =
+// Pillow's separable triangle-filter resample (support grows with the down-scale factor, 22-bit fixed-point
+// coefficients, horizontal pass -> uint8 -> vertical pass -> uint8), then ToTensor + Normalize.
+// The coefficient tables are built on the host exactly like Pillow's precompute_coeffs /
+// normalize_coeffs_8bpc (double precision, C truncation) - pillow_coeffs() - and the kernel evaluates
+// both passes per output pixel in integer arithmetic, so the result is bit-identical to Pillow's.
+// ------------------------------------------------------------------------------------------------
+constexpr int PIL_BITS = 32 - 8 - 2;
+
+// -> ksize; bounds[2*i] = first tap, bounds[2*i+1] = tap count, kk[i*ksize + t] = fixed-point weight
+int pillow_coeffs(int in_size, int out_size, std::vector<int>& bounds, std::vector<int>& kk) {
+    const double scale = (double)in_size / out_size;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = 1.0 * filterscale;
+    const int ksize = (int)std::ceil(support) * 2 + 1;
+    bounds.assign((size_t)out_size * 2, 0);
+    kk.assign((size_t)out_size * ksize, 0);
+    std::vector<double> k(ksize);
+    const double ss = 1.0 / filterscale;
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = 0.0 + (xx + 0.5) * scale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        double ww = 0.0;
+        for (int x = 0; x < ksize; ++x) k[x] = 0.0;
+        for (int x = 0; x < xmax; ++x) {
+            double a = (x + xmin - center + 0.5) * ss;
+            if (a < 0.0) a = -a;
+            const double w = a < 1.0 ? 1.0 - a : 0.0;
+            k[x] = w;
+            ww += w;
+        }
+        for (int x = 0; x < xmax; ++x)
+            if (ww != 0.0) k[x] /= ww;
+        for (int x = 0; x < ksize; ++x)
+            kk[(size_t)xx * ksize + x] = k[x] < 0 ? (int)(-0.5 + k[x] * (1 << PIL_BITS)) : (int)(0.5 + k[x] * (1 << PIL_BITS));
+        bounds[2 * xx] = xmin;
+        bounds[2 * xx + 1] = xmax;
+    }
+    return ksize;
+}
+
+__global__ void __launch_bounds__(256) resize_normalize_kernel(const unsigned char* __restrict__ frame, int H, int W, int OH,
+                                                                int OW, const int* __restrict__ hb, const int* __restrict__ hk,
+                                                                int ksh, const int* __restrict__ vb,
+                                                                const int* __restrict__ vk, int ksv,
+                                                                float* __restrict__ out, unsigned char* __restrict__ raw) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= OH * OW) return;
+    const int oy = idx / OW, ox = idx - oy * OW;
+    const int xmin = hb[2 * ox], xcnt = hb[2 * ox + 1], ymin = vb[2 * oy], ycnt = vb[2 * oy + 1];
+    int acc[3] = {1 << (PIL_BITS - 1), 1 << (PIL_BITS - 1), 1 << (PIL_BITS - 1)};
+    for (int y = 0; y < ycnt; ++y) {
+        const unsigned char* row = frame + ((size_t)(ymin + y) * W + xmin) * 3;
+        int h[3] = {1 << (PIL_BITS - 1), 1 << (PIL_BITS - 1), 1 << (PIL_BITS - 1)};
+        for (int x = 0; x < xcnt; ++x) {
+            const int w = hk[(size_t)ox * ksh + x];
+            h[0] += row[3 * x + 0] * w; h[1] += row[3 * x + 1] * w; h[2] += row[3 * x + 2] * w;
+        }
+        const int wv = vk[(size_t)oy * ksv + y];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int v = h[c] >> PIL_BITS;                     // the uint8 image between the two passes
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+            acc[c] += v * wv;
+        }
+    }
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        int v = acc[c] >> PIL_BITS;
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        if (raw) raw[(size_t)idx * 3 + c] = (unsigned char)v;
+        out[((size_t)c * OH + oy) * OW + ox] = ((float)v / 255.0f - mean[c]) / stdv[c];
+    }
+}
+
+int launch_resize_normalize(const unsigned char* frame, int H, int W, int OH, int OW, const int* hb, const int* hk, int ksh,
+                            const int* vb, const int* vk, int ksv, float* out, unsigned char* raw, const LaunchCtx& ctx) {
+    ProfScope ps(ctx, "resize_normalize", 0.0, (double)H * W * 3 + (double)OH * OW * (12.0 + (raw ? 3.0 : 0.0)));
+    hipLaunchKernelGGL(resize_normalize_kernel, dim3((OH * OW + 255) / 256), dim3(256), 0, ctx.stream, frame, H, W, OH, OW, hb,
+                       hk, ksh, vb, vk, ksv, out, raw);
     return (int)hipGetLastError();
 }
 

@@ -179,4 +179,9 @@ int launch_eval_joints(const float* pred, const float* gt, int B, int J, float* 
 int launch_crop_normalize(const unsigned char* frame, int H, int W, const float* bboxes, int n, float scale, int S,
                           float* out, unsigned char* raw, float* bbox_scale, float* bbox_center, const LaunchCtx& ctx);
 
+// Pillow-exact bilinear resize + ToTensor + Normalize (CamCalib frame transform)
+int pillow_coeffs(int in_size, int out_size, std::vector<int>& bounds, std::vector<int>& kk);
+int launch_resize_normalize(const unsigned char* frame, int H, int W, int OH, int OW, const int* hb, const int* hk, int ksh,
+                            const int* vb, const int* vk, int ksv, float* out, unsigned char* raw, const LaunchCtx& ctx);
+
 }  // namespace specmi

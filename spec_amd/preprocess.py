@@ -1,4 +1,6 @@
-"""Crop + normalise on the device: the detection loop of ``spec/tester.py:116-128``
+"""Pre-processing on the device.
+
+Crop + normalise: the detection loop of ``spec/tester.py:116-128``
 (``get_single_image_crop_demo`` per bbox, ``bbox_scale = bbox[2]/200``, ``bbox_center``) as one
 HIP launch (``specmi_crop_normalize``) from a uint8 RGB frame that already sits in HBM."""
 from __future__ import annotations
@@ -35,3 +37,31 @@ def crop_detections(frame_rgb_u8, dets, scale: float = 1.0, crop_size: int = 224
     if return_raw:
         res['raw'] = raw
     return res
+
+
+def resize_output_size(w: int, h: int, min_size: int = 600):
+    """``torchvision.transforms.Resize(min_size)`` geometry: shorter side -> min_size, longer ->
+    ``int(min_size * long / short)``.  Returns (ow, oh)."""
+    if w <= h:
+        return min_size, int(min_size * h / w)
+    return int(min_size * w / h), min_size
+
+
+@torch.no_grad()
+def camcalib_transform(frame_rgb_u8, min_size: int = 600, return_raw: bool = False):
+    """The CamCalib demo's ``ImageFolder`` transform (``camcalib/pano_dataset.py:156-162``): Resize(600) of
+    the PIL image (Pillow's antialiased bilinear), ToTensor, ImageNet Normalize - one HIP launch
+    (``specmi_resize_normalize``), bit-identical to Pillow + torchvision.  frame (H,W,3) uint8 device tensor ->
+    (1,3,oh,ow) fp32 [, (oh,ow,3) uint8]."""
+    if not isinstance(frame_rgb_u8, torch.Tensor) or frame_rgb_u8.device.type != 'cuda':
+        raise RuntimeError('camcalib_transform needs a device tensor (no CPU path in spec_amd)')
+    if frame_rgb_u8.dtype != torch.uint8 or frame_rgb_u8.dim() != 3 or frame_rgb_u8.shape[2] != 3:
+        raise ValueError('frame must be (H,W,3) uint8 RGB')
+    eng = _engine(frame_rgb_u8.device)
+    frame = frame_rgb_u8.contiguous()
+    H, W = frame.shape[:2]
+    ow, oh = resize_output_size(W, H, min_size)
+    out = torch.empty(1, 3, oh, ow, device=eng.device, dtype=torch.float32)
+    raw = torch.empty(oh, ow, 3, device=eng.device, dtype=torch.uint8) if return_raw else None
+    _lib.check(eng.h, eng.lib.specmi_resize_normalize(eng.h, _ptr(frame), H, W, oh, ow, _ptr(out), _ptr(raw), eng._stream()))
+    return (out, raw) if return_raw else out

@@ -8,6 +8,10 @@ from oracle import preprocess as P
 from tests.util import t
 
 
+# (seed, H, W, min_size) of the CamCalib Resize cases: down-scale by 1.6-5.4x (wide filter), up-scale, odd sizes, portrait
+RESIZE_CASES = [(21, 97, 130, 48), (22, 120, 80, 64), (23, 40, 60, 64), (24, 161, 87, 30), (25, 64, 64, 64), (26, 75, 203, 33)]
+
+
 def _frame(seed, H=180, W=260):
     rng = np.random.default_rng(seed)
     img = rng.random((H, W, 3)) * 255
@@ -77,3 +81,70 @@ def test_gpu_crop_feeds_hmr():
     x = out['inp_images']
     assert x.shape == (1, 3, 224, 224) and x.dtype == torch.float32 and x.is_contiguous()
     assert float(x.max()) <= (1 - 0.406) / 0.225 + 1e-5 and float(x.min()) >= -0.485 / 0.229 - 1e-5
+
+
+# ---- CamCalib frame transform: Pillow's antialiased bilinear resize + ToTensor + Normalize -----------------
+
+def _resize_golden():
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'camcalib_transform.npz'))
+    return [g[f'case{i}'] for i in range(len(RESIZE_CASES))]
+
+
+def test_oracle_resize_matches_pillow_fixture():
+    """The NumPy restatement of Pillow's ImagingResample is bit-exact against vectors produced by the real
+    Pillow binary (tests/golden/make_pillow_fixture.py)."""
+    for (seed, H, W, ms), ref in zip(RESIZE_CASES, _resize_golden()):
+        ow, oh = P.resize_output_size(W, H, ms)
+        got = P.pil_resize_bilinear_u8(_frame(seed, H, W), ow, oh)
+        assert got.shape == ref.shape and np.array_equal(got, ref), (H, W, ms)
+
+
+def test_oracle_resize_matches_installed_pillow():
+    """Same check against whatever Pillow is importable (skipped without it), on sizes the demo sees."""
+    Image = pytest.importorskip('PIL.Image')
+    for seed, (H, W) in enumerate([(480, 640), (720, 1280), (600, 450), (97, 130)]):
+        img = _frame(40 + seed, H, W)
+        ow, oh = P.resize_output_size(W, H, 600)
+        ref = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
+        assert np.array_equal(P.pil_resize_bilinear_u8(img, ow, oh), ref)
+
+
+def test_resize_geometry_and_identity():
+    assert P.resize_output_size(1920, 1080) == (1066, 600)      # int(600 * 1920 / 1080)
+    assert P.resize_output_size(450, 600) == (600, 800)
+    img = _frame(3, 64, 64)
+    assert np.array_equal(P.pil_resize_bilinear_u8(img, 64, 64), img)
+    x = P.camcalib_transform(img, 64)
+    assert x.shape == (3, 64, 64) and x.dtype == np.float32
+    np.testing.assert_array_equal(x, P.to_tensor_normalize(img))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', range(len(RESIZE_CASES)))
+def test_gpu_resize_bit_exact(case):
+    """specmi_resize_normalize vs the Pillow fixture (uint8 image) and vs the oracle (normalised tensor): bit-exact."""
+    from spec_amd.preprocess import camcalib_transform
+    seed, H, W, ms = RESIZE_CASES[case]
+    img = _frame(seed, H, W)
+    out, raw = camcalib_transform(t(img).to('cuda:0'), ms, return_raw=True)
+    ref_u8 = _resize_golden()[case]
+    assert np.array_equal(raw.cpu().numpy(), ref_u8)
+    ref = P.camcalib_transform(img, ms)
+    assert out.shape == (1,) + ref.shape
+    np.testing.assert_array_equal(out[0].cpu().numpy(), ref)
+
+
+@pytest.mark.gpu
+def test_gpu_resize_demo_sizes_and_camcalib():
+    """Full-size frames (the demo's Resize(600)), geometry changes between calls (the coefficient tables are
+    rebuilt), and the result feeds the CamCalib network at its native variable resolution."""
+    from spec_amd.preprocess import camcalib_transform
+    from tests.util import gpu_models
+    cc, _ = gpu_models(True, True, 'cuda:0')
+    for seed, (H, W) in enumerate([(480, 640), (720, 1280), (450, 600), (480, 640)]):
+        img = _frame(50 + seed, H, W)
+        x = camcalib_transform(t(img).to('cuda:0'), 600)
+        np.testing.assert_array_equal(x[0].cpu().numpy(), P.camcalib_transform(img, 600))
+        lg = cc(x)
+        assert all(torch.isfinite(l).all() and l.shape == (1, 256) for l in lg)
