@@ -90,7 +90,8 @@ const char* specmi_version(void);
 /* ---- parameters (replaces load_state_dict / load_pretrained_model,
  *      spec/tester.py:63-71, scripts/camcalib_demo.py:80-81) ---------------------------- */
 
-/* Integer options before commit.  HMR: "use_cam" (SMPLCamHead vs SMPLHead, hmr.py:66-74),
+/* Integer options before commit.  CamCalib (camcalib/model.py:25-70): "backbone" (50 default | 34),
+ * "num_fc_layers" (1..3), "num_fc_channels" (<= 1024, multiple of 32).  HMR: "use_cam" (SMPLCamHead vs SMPLHead, hmr.py:66-74),
  * "use_cam_feats" (hmr.py:55,94-98), "img_res" (hmr.py:69).  Float option: "focal_length".
  * Any time: "winograd" (default 1: 3x3 / stride-1 convolutions with Cin % 16 == 0 and Cout % 64 == 0
  * run as fused Winograd F(2x2,3x3) on the fp32 matrix cores; 0: always the direct implicit GEMM);

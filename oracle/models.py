@@ -12,7 +12,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .resnet import ResNet50Trunk, get_backbone_info
+from .resnet import ResNet50Trunk, ResNet34Trunk, get_backbone_info
 from .heads import HMRHead, SMPLCamHead, SMPLHead, set_assets  # noqa: F401
 from .geometry import softargmax1d, batch_euler2matrix
 
@@ -22,18 +22,36 @@ ROLL_RANGE = (-0.6, 0.6)       # literal, camcalib/cam_utils.py:133
 
 
 class CamCalibOracle(nn.Module):
-    """camcalib/model.py:25-57 (num_fc_layers == 1 branch) and forward :72-81."""
+    """camcalib/model.py:25-70 (single Linear per angle or the activation-free Linear chain of
+    ``_get_fc_layers``) and forward :72-81; resnet50 or resnet34 trunk (``test_model``, :84-101)."""
 
     def __init__(self, backbone='resnet50', num_fc_layers=1, num_fc_channels=1024,
                  num_out_channels=256):
         super().__init__()
-        assert num_fc_layers == 1
-        self.backbone = ResNet50Trunk()
+        assert num_fc_layers > 0
+        self.backbone = ResNet50Trunk() if backbone == 'resnet50' else ResNet34Trunk()
+        self.num_out_channels = num_out_channels
         self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
         c = get_backbone_info(backbone)['n_output_channels']
-        self.fc_vfov = nn.Linear(c, num_out_channels)
-        self.fc_pitch = nn.Linear(c, num_out_channels)
-        self.fc_roll = nn.Linear(c, num_out_channels)
+        if num_fc_layers == 1:
+            self.fc_vfov = nn.Linear(c, num_out_channels)
+            self.fc_pitch = nn.Linear(c, num_out_channels)
+            self.fc_roll = nn.Linear(c, num_out_channels)
+        else:
+            self.fc_vfov = self._get_fc_layers(num_fc_layers, num_fc_channels, c)
+            self.fc_pitch = self._get_fc_layers(num_fc_layers, num_fc_channels, c)
+            self.fc_roll = self._get_fc_layers(num_fc_layers, num_fc_channels, c)
+
+    def _get_fc_layers(self, num_layers, num_channels, inp_channels):
+        modules = []
+        for i in range(num_layers):
+            if i == 0:
+                modules.append(nn.Linear(inp_channels, num_channels))
+            elif i == num_layers - 1:
+                modules.append(nn.Linear(num_channels, self.num_out_channels))
+            else:
+                modules.append(nn.Linear(num_channels, num_channels))
+        return nn.Sequential(*modules)
 
     def forward(self, images):
         x = torch.flatten(self.avgpool(self.backbone(images)), 1)

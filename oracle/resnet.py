@@ -73,6 +73,49 @@ class ResNet50Trunk(nn.Module):
         return (x, stages) if return_stages else x
 
 
+class BasicBlock(nn.Module):
+    """torchvision BasicBlock (ResNet-18/34)."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        out += identity
+        return self.relu(out)
+
+
+class ResNet34Trunk(ResNet50Trunk):
+    """``pare.models.backbone.resnet34`` = torchvision ``ResNet(BasicBlock, [3,4,6,3])`` without avgpool / fc
+    (camcalib/model.py:85, camcalib/config.py:81); 512 output channels."""
+
+    def _make_layer(self, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes, kernel_size=1, stride=stride, bias=False),
+                                       nn.BatchNorm2d(planes))
+        layers = [BasicBlock(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes
+        for _ in range(1, blocks):
+            layers.append(BasicBlock(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+
+def resnet34(pretrained=False, **kwargs):
+    return ResNet34Trunk()
+
+
 def resnet50(pretrained=False, **kwargs):
     """``pretrained`` is accepted and ignored: no network, weights come from a state_dict."""
     return ResNet50Trunk()

@@ -35,6 +35,7 @@ struct ConvW {
 struct Bneck {
     ConvW c1, c2, c3, ds;
     bool has_ds = false;
+    bool basic = false;   // torchvision BasicBlock (ResNet-18/34): c1 = 3x3 (stride), c2 = 3x3, no c3
     // conv3 + bn3 and downsample conv + bn folded into ONE 1x1 GEMM over [conv2 output | block input]:
     // weights pre-multiplied by the BN scales (fp64), shift = shift3 + shift_ds, scale = 1
     float *f_w = nullptr, *f_scale = nullptr, *f_shift = nullptr;
@@ -58,7 +59,8 @@ struct specmi_handle {
     // packed parameters (device)
     ConvW stem;
     std::vector<Bneck> blocks;
-    FcW fc_cam[3];             // CamCalib: vfov, pitch, roll
+    FcW fc_cam[3][3];          // CamCalib: vfov, pitch, roll x up to 3 stacked Linear layers (camcalib/model.py:59-70: no activation between them)
+    int fc_layers = 1, feat_ch = 2048;
     FcW fc1, fc2, dec;         // HMR head (dec = decpose|decshape|deccam)
     float *init_pose = nullptr, *init_shape = nullptr, *init_cam = nullptr;
     SmplDev smpl;
@@ -277,32 +279,42 @@ static int commit_fc(specmi_handle* h, const std::vector<std::string>& names, co
     return SPECMI_OK;
 }
 
-static void build_resnet50(specmi_handle* h) {
+// torchvision ResNet-50 (Bottleneck [3,4,6,3], v1.5: stride on the 3x3) or ResNet-34 (BasicBlock [3,4,6,3]) trunk
+static void build_resnet(specmi_handle* h, int depth) {
     h->stem = ConvW();
     h->stem.name = "conv1"; h->stem.bn_name = "bn1";
     h->stem.cin = 3; h->stem.cout = 64; h->stem.k = 7; h->stem.stride = 2; h->stem.pad = 3;
     h->blocks.clear();
+    const bool basic = depth == 34;
     const int nblocks[4] = {3, 4, 6, 3}, planes[4] = {64, 128, 256, 512};
+    const int expansion = basic ? 1 : 4;
     int inplanes = 64;
     for (int li = 0; li < 4; ++li) {
         for (int b = 0; b < nblocks[li]; ++b) {
             const int stride = (b == 0 && li > 0) ? 2 : 1;
             const std::string p = "layer" + std::to_string(li + 1) + "." + std::to_string(b);
             Bneck bn;
+            bn.basic = basic;
             auto mk = [&](ConvW& c, const std::string& cn, const std::string& bnn, int cin, int cout, int k, int s,
                           int pad) {
                 c.name = p + "." + cn; c.bn_name = p + "." + bnn;
                 c.cin = cin; c.cout = cout; c.k = k; c.stride = s; c.pad = pad;
             };
-            mk(bn.c1, "conv1", "bn1", inplanes, planes[li], 1, 1, 0);
-            mk(bn.c2, "conv2", "bn2", planes[li], planes[li], 3, stride, 1);
-            mk(bn.c3, "conv3", "bn3", planes[li], planes[li] * 4, 1, 1, 0);
-            bn.has_ds = (b == 0);
-            if (bn.has_ds) mk(bn.ds, "downsample.0", "downsample.1", inplanes, planes[li] * 4, 1, stride, 0);
-            inplanes = planes[li] * 4;
+            if (basic) {
+                mk(bn.c1, "conv1", "bn1", inplanes, planes[li], 3, stride, 1);
+                mk(bn.c2, "conv2", "bn2", planes[li], planes[li], 3, 1, 1);
+            } else {
+                mk(bn.c1, "conv1", "bn1", inplanes, planes[li], 1, 1, 0);
+                mk(bn.c2, "conv2", "bn2", planes[li], planes[li], 3, stride, 1);
+                mk(bn.c3, "conv3", "bn3", planes[li], planes[li] * 4, 1, 1, 0);
+            }
+            bn.has_ds = (stride != 1 || inplanes != planes[li] * expansion);
+            if (bn.has_ds) mk(bn.ds, "downsample.0", "downsample.1", inplanes, planes[li] * expansion, 1, stride, 0);
+            inplanes = planes[li] * expansion;
             h->blocks.push_back(bn);
         }
     }
+    h->feat_ch = inplanes;
 }
 
 static int opt_i(specmi_handle* h, const char* name, int dflt) {
@@ -522,11 +534,27 @@ static int run_trunk(specmi_handle* h, const float* images, int B, int H, int W,
         const int t1 = free_idx[0], t2 = free_idx[1], idb = free_idx[2];
         const int stage = bk.c1.name[5] - '0';   // "layerN.b.conv1"
         const std::string p = "backbone." + bk.c1.name.substr(0, bk.c1.name.rfind('.'));
-        const int oh = conv_out(ch, 3, bk.c2.stride, 1), ow = conv_out(cw, 3, bk.c2.stride, 1);
+        const int bstride = bk.basic ? bk.c1.stride : bk.c2.stride;
+        const int oh = conv_out(ch, 3, bstride, 1), ow = conv_out(cw, 3, bstride, 1);
         auto add = [&](const ConvW& c, int in, int out, int res, int ih, int iw, int ooh, int oow, int relu, const char* nm) {
             ops.push_back({2, &c, in, out, res, ih, iw, ooh, oow, relu, p + nm, (size_t)ih * iw * c.cin, (size_t)ooh * oow * c.cout});
             stage_of.push_back(stage);
         };
+        if (bk.basic) {
+            // BasicBlock: relu(bn1(conv3x3_s(x))) -> relu(bn2(conv3x3(.)) + identity | downsample(x))
+            add(bk.c1, xi, t1, -1, ch, cw, oh, ow, 1, ".conv1");
+            int identity = xi;
+            if (bk.has_ds) {
+                add(bk.ds, xi, idb, -1, ch, cw, oh, ow, 0, ".downsample");
+                identity = idb;
+            }
+            const int out = (last && feat_out) ? -2 : t2;
+            add(bk.c2, t1, out, identity, oh, ow, oh, ow, 1, ".conv2");
+            ch = oh; cw = ow;
+            xi = out;
+            final_buf = out;
+            continue;
+        }
         add(bk.c1, xi, t1, -1, ch, cw, ch, cw, 1, ".conv1");
         add(bk.c2, t1, t2, -1, ch, cw, oh, ow, 1, ".conv2");
         int identity = xi;
@@ -636,7 +664,7 @@ int specmi_create(specmi_handle** out, int device_id, int model_kind) {
     specmi_handle* h = new specmi_handle();
     h->device = device_id;
     h->kind = model_kind;
-    build_resnet50(h);
+    build_resnet(h, 50);
     *out = h;
     return SPECMI_OK;
 }
@@ -700,22 +728,37 @@ int specmi_commit(specmi_handle* h) {
     h->committed = false;
     int rc;
     const std::string bp = "backbone.";
+    const int depth = opt_i(h, "backbone", 50);
+    if (depth != 50 && depth != 34) return fail(h, SPECMI_ERR_ARG, "backbone %d: resnet50 and resnet34 are built", depth);
+    if (depth != 50 && h->kind != SPECMI_MODEL_CAMCALIB)
+        return fail(h, SPECMI_ERR_ARG, "the HMR regressor is built for the resnet50 trunk (2048 features) only");
+    build_resnet(h, depth);
     if ((rc = commit_conv(h, bp, h->stem))) return rc;
     for (Bneck& b : h->blocks) {
         if ((rc = commit_conv(h, bp, b.c1))) return rc;
         if ((rc = commit_conv(h, bp, b.c2))) return rc;
-        if ((rc = commit_conv(h, bp, b.c3))) return rc;
+        if (!b.basic && (rc = commit_conv(h, bp, b.c3))) return rc;
         if (b.has_ds && (rc = commit_conv(h, bp, b.ds))) return rc;
-        if (b.has_ds && b.c3.cin % 32 == 0 && b.ds.cin % 32 == 0 && (rc = commit_fused_ds(h, bp, b))) return rc;
+        if (!b.basic && b.has_ds && b.c3.cin % 32 == 0 && b.ds.cin % 32 == 0 && (rc = commit_fused_ds(h, bp, b))) return rc;
     }
     if (h->kind == SPECMI_MODEL_CAMCALIB) {
+        // camcalib/model.py:39-57: one Linear per angle, or Sequential(Linear x num_fc_layers) WITHOUT activations
         const char* names[3] = {"fc_vfov", "fc_pitch", "fc_roll"};
-        const HostTensor* w0 = find(h, "fc_vfov.weight");
-        if (!w0) return fail(h, SPECMI_ERR_MISSING, "missing tensor 'fc_vfov.weight'");
-        const int nb = (int)(w0->numel() / 2048);
+        const int L = opt_i(h, "num_fc_layers", 1), hc = opt_i(h, "num_fc_channels", 1024);
+        if (L < 1 || L > 3 || hc < 1 || hc > 1024) return fail(h, SPECMI_ERR_ARG, "num_fc_layers in 1..3 and num_fc_channels <= 1024 are built");
+        h->fc_layers = L;
+        const std::string lastw = L == 1 ? std::string("fc_vfov.weight") : "fc_vfov." + std::to_string(L - 1) + ".weight";
+        const HostTensor* w0 = find(h, lastw);
+        if (!w0) return fail(h, SPECMI_ERR_MISSING, "missing tensor '%s'", lastw.c_str());
+        const int last_in = L == 1 ? h->feat_ch : hc;
+        const int nb = (int)(w0->numel() / last_in);
         h->opt_i["nbins"] = nb;
         for (int i = 0; i < 3; ++i)
-            if ((rc = commit_fc(h, {names[i]}, {nb}, 2048, h->fc_cam[i]))) return rc;
+            for (int l = 0; l < L; ++l) {
+                const std::string nm = L == 1 ? std::string(names[i]) : std::string(names[i]) + "." + std::to_string(l);
+                const int nin = l == 0 ? h->feat_ch : hc, nout = l == L - 1 ? nb : hc;
+                if ((rc = commit_fc(h, {nm}, {nout}, nin, h->fc_cam[i][l]))) return rc;
+            }
     } else {
         const int ucf = opt_i(h, "use_cam_feats", 0);
         const int nin = 2048 + 144 + 13 + (ucf ? 7 : 0);
@@ -762,12 +805,23 @@ int specmi_camcalib_forward(specmi_handle* h, const float* images, int B, int H,
     if ((rc = run_trunk(h, images, B, H, W, nullptr, &f, &fh, &fw, s))) return rc;
     {
         LaunchCtx ctx{s, &h->prof, "avgpool"};
-        LAUNCHCHK(h, launch_avgpool(f, h->xf, B, fh * fw, 2048, 2048, ctx), "avgpool");
+        LAUNCHCHK(h, launch_avgpool(f, h->xf, B, fh * fw, h->feat_ch, 2048, ctx), "avgpool");
     }
     float* outs[3] = {lv, lp, lr};
     const char* labels[3] = {"fc_vfov", "fc_pitch", "fc_roll"};
-    for (int i = 0; i < 3; ++i)
-        if ((rc = run_fc(h, h->fc_cam[i], h->xf, 2048, B, nullptr, outs[i], h->fc_cam[i].nout, s, labels[i]))) return rc;
+    for (int i = 0; i < 3; ++i) {
+        // Linear chain (no activation in between, camcalib/model.py:59-70); hidden rows live in h1 / h2 (1024 wide)
+        const float* x = h->xf;
+        int ldx = 2048;
+        for (int l = 0; l < h->fc_layers; ++l) {
+            const FcW& fc = h->fc_cam[i][l];
+            const bool lastl = (l + 1 == h->fc_layers);
+            float* y = lastl ? outs[i] : (l == 0 ? h->h1 : h->h2);
+            const int ldy = lastl ? fc.nout : 1024;
+            if ((rc = run_fc(h, fc, x, ldx, B, nullptr, y, ldy, s, labels[i]))) return rc;
+            x = y; ldx = ldy;
+        }
+    }
     return SPECMI_OK;
 }
 

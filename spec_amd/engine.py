@@ -42,6 +42,7 @@ class Engine:
             raise _lib.SpecmiError(rc, (self.lib.specmi_last_error(None) or b'?').decode())
         self.h = h
         self.nbins = 256
+        self.feat_channels = 2048
         self.num_verts = 0
 
     def close(self):
@@ -90,6 +91,11 @@ class Engine:
                 smpl['v_template'], torch.Tensor) else int(smpl['v_template'].shape[0])
         if 'fc_vfov.weight' in tensors:
             self.nbins = int(tensors['fc_vfov.weight'].shape[0])
+        else:   # Sequential heads (num_fc_layers > 1): the last Linear of the chain has the bins
+            last = [k for k in tensors if k.startswith('fc_vfov.') and k.endswith('.weight')]
+            if last:
+                self.nbins = int(tensors[sorted(last)[-1]].shape[0])
+        self.feat_channels = 512 if int(options.get('backbone', 50)) == 34 else 2048
         _lib.check(self.h, self.lib.specmi_commit(self.h))
 
     # ---- forward ---------------------------------------------------------------------------
@@ -114,7 +120,7 @@ class Engine:
         fh, fw = o(fh, 3, 2, 1), o(fw, 3, 2, 1)
         for _ in range(3):
             fh, fw = o(fh, 3, 2, 1), o(fw, 3, 2, 1)
-        feat = torch.empty(B, fh, fw, 2048, device=self.device, dtype=torch.float32)
+        feat = torch.empty(B, fh, fw, self.feat_channels, device=self.device, dtype=torch.float32)
         _lib.check(self.h, self.lib.specmi_trunk_forward(self.h, _ptr(x), B, H, W, _ptr(feat), self._stream()))
         return feat
 

@@ -60,6 +60,43 @@ class ResNet50Params(nn.Module):
         raise RuntimeError('ResNet50Params only holds parameters; the trunk runs inside libspecmi')
 
 
+class _BasicBlockParams(nn.Module):
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        if downsample:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes, 1, stride=stride, bias=False),
+                                            nn.BatchNorm2d(planes))
+
+
+class ResNet34Params(nn.Module):
+    """torchvision-layout ResNet-34 trunk parameters (BasicBlock [3,4,6,3], no avgpool / fc) - the CamCalib
+    config default (camcalib/config.py:81) and one of the two trunks of camcalib/model.py:85."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        inplanes = 64
+        for li, (nb, planes) in enumerate(zip((3, 4, 6, 3), (64, 128, 256, 512)), start=1):
+            blocks = []
+            for b in range(nb):
+                stride = 2 if (b == 0 and li > 1) else 1
+                blocks.append(_BasicBlockParams(inplanes, planes, stride, downsample=(stride != 1 or inplanes != planes)))
+                inplanes = planes
+            setattr(self, f'layer{li}', nn.Sequential(*blocks))
+
+    def forward(self, *a, **k):
+        raise RuntimeError('ResNet34Params only holds parameters; the trunk runs inside libspecmi')
+
+
+def resnet34(pretrained=False, **kwargs):
+    return ResNet34Params()
+
+
 def resnet50(pretrained=False, **kwargs):
     """Name looked up by the reference via ``eval(backbone)`` (hmr.py:53, camcalib/model.py:33).
     ``pretrained`` never touches the network here; weights come from a checkpoint."""
@@ -67,7 +104,7 @@ def resnet50(pretrained=False, **kwargs):
 
 
 def get_backbone_info(backbone):
-    return {'resnet50': {'n_output_channels': 2048}}[backbone]
+    return {'resnet50': {'n_output_channels': 2048}, 'resnet34': {'n_output_channels': 512}}[backbone]
 
 
 class HMRHeadParams(nn.Module):
@@ -172,21 +209,44 @@ class CameraRegressorNetwork(_EngineModule):
 
     def __init__(self, backbone='resnet50', num_fc_layers=1, num_fc_channels=1024, num_out_channels=256):
         super().__init__()
-        if backbone != 'resnet50':
-            raise NotImplementedError(f'backbone {backbone!r}: only resnet50 (the released model) is built')
+        if backbone not in ('resnet50', 'resnet34'):
+            raise NotImplementedError(f'backbone {backbone!r}: resnet50 (the released model) and resnet34 are built')
         assert num_fc_layers > 0, 'Number of FC layers should be more than 0'
-        if num_fc_layers != 1:
-            raise NotImplementedError('only num_fc_layers=1 (the released CamCalib model) is built')
-        self.backbone = resnet50(pretrained=True)
+        if num_fc_layers > 3 or num_fc_channels > 1024 or num_fc_channels % 32:
+            raise NotImplementedError('num_fc_layers <= 3 and num_fc_channels <= 1024 (multiple of 32) are built')
+        self.backbone = resnet50(pretrained=True) if backbone == 'resnet50' else resnet34(pretrained=True)
+        self._backbone_depth = 50 if backbone == 'resnet50' else 34
+        self.num_fc_layers, self.num_fc_channels = num_fc_layers, num_fc_channels
         self.num_out_channels = num_out_channels
         out_channels = get_backbone_info(backbone)['n_output_channels']
-        self.fc_vfov = nn.Linear(out_channels, num_out_channels)
-        self.fc_pitch = nn.Linear(out_channels, num_out_channels)
-        self.fc_roll = nn.Linear(out_channels, num_out_channels)
-        for fc in (self.fc_vfov, self.fc_pitch, self.fc_roll):
-            nn.init.normal_(fc.weight, mean=0, std=0.01)
-            nn.init.constant_(fc.bias, 0)
+        if num_fc_layers == 1:
+            self.fc_vfov = nn.Linear(out_channels, num_out_channels)
+            self.fc_pitch = nn.Linear(out_channels, num_out_channels)
+            self.fc_roll = nn.Linear(out_channels, num_out_channels)
+            for fc in (self.fc_vfov, self.fc_pitch, self.fc_roll):
+                nn.init.normal_(fc.weight, mean=0, std=0.01)
+                nn.init.constant_(fc.bias, 0)
+        else:
+            self.fc_vfov = self._get_fc_layers(num_fc_layers, num_fc_channels, out_channels)
+            self.fc_pitch = self._get_fc_layers(num_fc_layers, num_fc_channels, out_channels)
+            self.fc_roll = self._get_fc_layers(num_fc_layers, num_fc_channels, out_channels)
         super().train(False)
+
+    def _get_fc_layers(self, num_layers, num_channels, inp_channels):
+        """camcalib/model.py:59-70: Linear layers back to back, no activation in between."""
+        modules = []
+        for i in range(num_layers):
+            if i == 0:
+                modules.append(nn.Linear(inp_channels, num_channels))
+            elif i == num_layers - 1:
+                modules.append(nn.Linear(num_channels, self.num_out_channels))
+            else:
+                modules.append(nn.Linear(num_channels, num_channels))
+        return nn.Sequential(*modules)
+
+    def _options(self):
+        return {'backbone': self._backbone_depth, 'num_fc_layers': int(self.num_fc_layers),
+                'num_fc_channels': int(self.num_fc_channels)}
 
     @torch.no_grad()
     def forward(self, images):

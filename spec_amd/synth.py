@@ -113,12 +113,52 @@ def resnet50_state(seed: int, prefix: str = '') -> 'OrderedDict[str, np.ndarray]
     return sd
 
 
-def camcalib_state(seed: int = 1001, fc_std: float = 0.05, nbins: int = C.NUM_CAMCALIB_BINS):
-    """CameraRegressorNetwork(num_fc_layers=1) parameters (camcalib/model.py:40-52 layout)."""
-    sd = resnet50_state(seed, 'backbone.')
+def resnet34_conv_specs():
+    """(name, cin, cout, k, stride, pad, bn_name) of the torchvision ResNet-34 trunk in state-dict order."""
+    specs = [('conv1', 3, 64, 7, 2, 3, 'bn1')]
+    inplanes = 64
+    for li, (nb, planes) in enumerate(zip(RESNET50_BLOCKS, RESNET50_PLANES), start=1):
+        for b in range(nb):
+            stride = 2 if (b == 0 and li > 1) else 1
+            p = f'layer{li}.{b}'
+            specs.append((f'{p}.conv1', inplanes, planes, 3, stride, 1, f'{p}.bn1'))
+            specs.append((f'{p}.conv2', planes, planes, 3, 1, 1, f'{p}.bn2'))
+            if stride != 1 or inplanes != planes:
+                specs.append((f'{p}.downsample.0', inplanes, planes, 1, stride, 0, f'{p}.downsample.1'))
+            inplanes = planes
+    return specs
+
+
+def resnet34_state(seed: int, prefix: str = '') -> 'OrderedDict[str, np.ndarray]':
+    """Random ResNet-34 trunk parameters, activations O(1) through the 16 blocks (bn2 damps the residual branch)."""
+    sd = OrderedDict()
+    for (name, cin, cout, k, _s, _p, bn) in resnet34_conv_specs():
+        sd[f'{prefix}{name}.weight'] = normal(seed, name + '.weight', (cout, cin, k, k), std=math.sqrt(2.0 / (cin * k * k)))
+        g0 = 0.25 if bn.endswith('bn2') else (0.7 if bn.endswith('downsample.1') else 1.0)
+        sd[f'{prefix}{bn}.weight'] = (g0 * (1.0 + 0.1 * normal(seed, bn + '.weight', (cout,)))).astype(np.float32)
+        sd[f'{prefix}{bn}.bias'] = normal(seed, bn + '.bias', (cout,), std=0.05)
+        sd[f'{prefix}{bn}.running_mean'] = normal(seed, bn + '.running_mean', (cout,), std=0.1)
+        sd[f'{prefix}{bn}.running_var'] = uniform(seed, bn + '.running_var', (cout,), 0.8, 1.2)
+        sd[f'{prefix}{bn}.num_batches_tracked'] = np.array(0, dtype=np.int64)
+    return sd
+
+
+def camcalib_state(seed: int = 1001, fc_std: float = 0.05, nbins: int = C.NUM_CAMCALIB_BINS, backbone: str = 'resnet50',
+                   num_fc_layers: int = 1, num_fc_channels: int = 1024):
+    """CameraRegressorNetwork parameters (camcalib/model.py:40-70 layout): one Linear per angle, or the
+    ``fc_*.{0..L-1}`` Linear chain of ``_get_fc_layers``."""
+    sd = resnet50_state(seed, 'backbone.') if backbone == 'resnet50' else resnet34_state(seed, 'backbone.')
+    feat = 2048 if backbone == 'resnet50' else 512
     for head in ('fc_vfov', 'fc_pitch', 'fc_roll'):
-        sd[f'{head}.weight'] = normal(seed, head + '.weight', (nbins, 2048), std=fc_std)
-        sd[f'{head}.bias'] = normal(seed, head + '.bias', (nbins,), std=0.1)
+        if num_fc_layers == 1:
+            sd[f'{head}.weight'] = normal(seed, head + '.weight', (nbins, feat), std=fc_std)
+            sd[f'{head}.bias'] = normal(seed, head + '.bias', (nbins,), std=0.1)
+            continue
+        for l in range(num_fc_layers):
+            nin = feat if l == 0 else num_fc_channels
+            nout = nbins if l == num_fc_layers - 1 else num_fc_channels
+            sd[f'{head}.{l}.weight'] = normal(seed, f'{head}.{l}.weight', (nout, nin), std=fc_std if l == num_fc_layers - 1 else math.sqrt(1.0 / nin))
+            sd[f'{head}.{l}.bias'] = normal(seed, f'{head}.{l}.bias', (nout,), std=0.1)
     return sd
 
 

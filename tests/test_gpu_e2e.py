@@ -246,3 +246,47 @@ def test_eval_flow_synthetic(tmp_path):
     assert 14.0 < float(lines['W-V2V']) < 18.0
     ev = joblib.load(os.path.join(str(tmp_path), 'evaluation_results_spec-syn.pkl'))
     assert ev['pred_vertices'].shape == (96, 6890, 3) and ev['pred_pose'].shape == (96, 24, 3, 3)
+
+
+# camcalib/model.py:84-101 (the reference's own ``test_model``): both trunks x {1,2,3} FC layers x {256,512,1024} hidden
+# channels x three input sizes - here with a parity check against the CPU oracle instead of a breakpoint
+_CC_SIZES = [(224, 224), (480, 640), (500, 450)]
+_CC_MATRIX = [(b, nl, nc, _CC_SIZES[(i + j + k) % 3])
+              for i, b in enumerate(('resnet50', 'resnet34')) for j, nl in enumerate((1, 2, 3))
+              for k, nc in enumerate((256, 512, 1024)) if nl > 1 or nc == 1024]
+
+
+@pytest.mark.parametrize('backbone,num_fc_layers,num_fc_channels,size', _CC_MATRIX,
+                         ids=lambda v: str(v).replace(' ', ''))
+def test_camcalib_model_matrix(backbone, num_fc_layers, num_fc_channels, size):
+    from oracle.models import CamCalibOracle, load_numpy_state
+    from spec_amd.modules import CameraRegressorNetwork
+    sd = synth.camcalib_state(1500 + num_fc_layers, backbone=backbone, num_fc_layers=num_fc_layers,
+                              num_fc_channels=num_fc_channels)
+    ref_m = load_numpy_state(CamCalibOracle(backbone, num_fc_layers, num_fc_channels).eval(), sd)
+    m = CameraRegressorNetwork(backbone=backbone, num_fc_layers=num_fc_layers, num_fc_channels=num_fc_channels)
+    missing, unexpected = m.load_state_dict({k: t(v) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).eval()
+    x = t(synth.images(77, 1, size[0], size[1]))
+    out = m(x.to(DEV))
+    ref = ref_m(x)
+    assert len(out) == 3
+    for o, r in zip(out, ref):
+        assert o.shape == r.shape == (1, 256)
+        assert rel_err(o.cpu().numpy(), r.numpy()) < 1e-4, (backbone, num_fc_layers, num_fc_channels, size)
+
+
+def test_resnet34_trunk_vs_oracle_batch():
+    """ResNet-34 trunk (BasicBlocks: Winograd conv1, direct conv2 with the residual fused) against the oracle, B=3."""
+    from oracle.models import CamCalibOracle, load_numpy_state
+    from spec_amd.modules import CameraRegressorNetwork
+    sd = synth.camcalib_state(1600, backbone='resnet34')
+    ref_m = load_numpy_state(CamCalibOracle('resnet34').eval(), sd)
+    m = CameraRegressorNetwork(backbone='resnet34')
+    m.load_state_dict({k: t(v) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).eval()
+    x = t(synth.images(78, 3))
+    feat = m.engine(torch.device(DEV)).trunk(x.to(DEV)).cpu()
+    ref = ref_m.backbone(x).permute(0, 2, 3, 1)
+    assert feat.shape == ref.shape == (3, 7, 7, 512)
+    assert rel_err(feat.numpy(), ref.numpy()) < 2e-5

@@ -121,3 +121,29 @@ def test_smpl_file_loader_without_chumpy(tmp_path):
     assert m['shapedirs'].shape == (nv, 3, 10) and m['posedirs'].shape == (207, nv * 3)
     assert np.allclose(m['posedirs'][5].reshape(nv, 3), raw['posedirs'][:, :, 5])
     assert m['parents'][0] == -1 and m['J_regressor'].shape == (24, nv) and m['J_regressor'].dtype == np.float32
+
+
+@pytest.mark.parametrize('backbone,nl,nc', [('resnet34', 1, 1024), ('resnet34', 3, 256), ('resnet50', 2, 512)])
+def test_camcalib_variants_state_dict_layout(backbone, nl, nc):
+    """camcalib/model.py:25-70 variants (the reference's test_model matrix): parameter names, order and shapes are
+    the torchvision / nn.Sequential ones, so a checkpoint trained with the reference loads strictly."""
+    from oracle.models import CamCalibOracle
+    from spec_amd.modules import CameraRegressorNetwork
+    own = CameraRegressorNetwork(backbone=backbone, num_fc_layers=nl, num_fc_channels=nc).state_dict()
+    ref = CamCalibOracle(backbone, nl, nc).state_dict()
+    assert list(own.keys()) == list(ref.keys())
+    assert all(tuple(own[k].shape) == tuple(ref[k].shape) for k in ref)
+    sd = synth.camcalib_state(5, backbone=backbone, num_fc_layers=nl, num_fc_channels=nc)
+    assert sorted(sd.keys()) == sorted(ref.keys())
+    n_backbone = len([k for k in ref if k.startswith('backbone.')])
+    assert n_backbone == (318 if backbone == 'resnet50' else 216)   # (53 | 36) conv + bn pairs x 6 tensors
+
+
+def test_unsupported_variants_raise():
+    from spec_amd.modules import CameraRegressorNetwork, HMR
+    with pytest.raises(NotImplementedError):
+        CameraRegressorNetwork(backbone='hrnet_w32')
+    with pytest.raises(NotImplementedError):
+        CameraRegressorNetwork(num_fc_layers=4)
+    with pytest.raises(NotImplementedError):
+        HMR(backbone='resnet34')
