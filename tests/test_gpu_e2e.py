@@ -185,6 +185,25 @@ def test_full_batch_256_properties(models):
     assert ((p2 - big['smpl_joints2d'].double()).abs().max() / big['smpl_joints2d'].abs().max()) < 1e-5
 
 
+def test_batch_700_crosses_the_2gib_slices(models):
+    """B=700: the stem output and the layer-1 tensors exceed 2 GiB, so every kernel family (stem, direct, two-source,
+    Winograd) runs in batch slices; images on both sides of the slice boundaries still match a small batch bit for bit."""
+    from spec_amd.pipeline import SpecPipeline
+    cc, hm = models
+    pipe = SpecPipeline(cc, hm, overlap=False)
+    B = 700
+    x = t(synth.images(79, 8)).to(DEV).repeat(88, 1, 1, 1)[:B].contiguous()      # 8 distinct crops, tiled
+    sc, ce, iw, ih = [t(a).to(DEV).repeat(*([88] + [1] * (a.ndim - 1)))[:B].contiguous() for a in synth.bbox_inputs(79, 8)]
+    big = pipe(x, sc, ce, iw, ih)
+    idx = torch.tensor([0, 1, 325, 326, 333, 334, 652, 653, 698, 699], device=DEV)
+    small = pipe(x[idx], sc[idx], ce[idx], iw[idx], ih[idx])
+    for k in ('smpl_vertices', 'smpl_joints2d', 'pred_pose_6d', 'cam_pitch'):
+        assert torch.isfinite(big[k]).all(), k
+        assert torch.equal(big[k][idx], small[k]), k
+    # every 8th image is the same crop: identical results across the whole batch
+    assert torch.equal(big['smpl_vertices'][0::8][:80], big['smpl_vertices'][0:1].expand(80, -1, -1))
+
+
 def test_reload_after_parameter_change(models):
     """In-place parameter edits are picked up (version counters) - checkpoint loading after construction."""
     cc, _ = models
