@@ -173,7 +173,7 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=device)
 
-    from spec_amd.pipeline import SpecPipeline, gather_outputs
+    from spec_amd.pipeline import SpecPipeline, AsyncGather
     torch.set_grad_enabled(False)
     cc, hm, cs, hs = build_models(device)
     pipe = SpecPipeline(cc, hm, overlap=not args.no_overlap)
@@ -201,14 +201,20 @@ def main():
             log('[bench] hipGraph capture failed, launching eagerly:', repr(e))
             run = pipe
 
+    # N > 1: one all-gather of the packed records per step, started asynchronously so that RCCL moves step s over xGMI
+    # while the kernels of step s+1 run (at most 2 in flight; everything is drained inside the timed region)
+    gather = AsyncGather(depth=2) if world > 1 else None
+
     def step():
         out = run(x, scale, center, img_w, img_h)
-        if world > 1:
-            return gather_outputs(out)
+        if gather is not None:
+            return gather.submit(out)
         return out
 
     for _ in range(args.warmup):
         step()
+    if gather is not None:
+        gather.drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -216,6 +222,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
+    if gather is not None:
+        gather.drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

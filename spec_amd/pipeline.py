@@ -125,6 +125,42 @@ def unpack_outputs(packed: torch.Tensor, num_verts: int) -> Dict[str, torch.Tens
     return res
 
 
+class AsyncGather:
+    """The per-step all-gather taken off the critical path: ``submit(out)`` packs the step's outputs and starts
+    the collective with ``async_op=True`` (RCCL runs it on its own stream once the packing kernel is done), so it
+    overlaps the NEXT step's kernels; at most ``depth`` collectives are in flight (the oldest is waited for before
+    a new one is queued, which also bounds memory), ``drain()`` waits for the rest.  Results come back in
+    submission order."""
+
+    def __init__(self, depth: int = 2, group=None, keep_results: bool = False):
+        self.depth, self.group, self.keep = max(1, depth), group, keep_results
+        self.pending = []
+        self.results = []
+
+    def _retire(self):
+        work, full = self.pending.pop(0)
+        work.wait()
+        if self.keep:
+            self.results.append(full)
+        self.last = full
+
+    def submit(self, out: Dict[str, torch.Tensor]):
+        import torch.distributed as dist
+        while len(self.pending) >= self.depth:
+            self._retire()
+        packed = pack_outputs(out)
+        world = dist.get_world_size(self.group)
+        full = torch.empty(world * packed.shape[0], packed.shape[1], device=packed.device, dtype=packed.dtype)
+        work = dist.all_gather_into_tensor(full, packed, group=self.group, async_op=True)
+        self.pending.append((work, full))
+        return full
+
+    def drain(self):
+        while self.pending:
+            self._retire()
+        return self.results if self.keep else getattr(self, 'last', None)
+
+
 def gather_outputs(out: Dict[str, torch.Tensor], group=None) -> torch.Tensor:
     """One all-gather (RCCL over xGMI with backend 'nccl'; gloo on CPU tests) of the packed
     per-image records: returns (world*B, record) on every rank, rank-major."""

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from spec_amd.pipeline import PACKED_KEYS, gather_outputs, pack_outputs, shard_range, unpack_outputs
+from spec_amd.pipeline import PACKED_KEYS, AsyncGather, gather_outputs, pack_outputs, shard_range, unpack_outputs
 
 V = 37  # small synthetic vertex count
 
@@ -34,7 +34,13 @@ def _worker(rank, world, port, total, q):
         lo, hi = shard_range(total, rank, world)
         out = _fake_forward(torch.arange(lo, hi))
         full = gather_outputs(out)
-        q.put((rank, full.numpy()))
+        # the bench's overlapped variant: 5 "steps" with at most 2 collectives in flight, results in order
+        ag = AsyncGather(depth=2, keep_results=True)
+        for step in range(5):
+            ag.submit({k: v + 100.0 * step for k, v in out.items()})
+        steps = ag.drain()
+        ok = len(steps) == 5 and all(torch.equal(s_, full + 100.0 * i) for i, s_ in enumerate(steps))
+        q.put((rank, full.numpy() if ok else None))
     finally:
         dist.destroy_process_group()
 
