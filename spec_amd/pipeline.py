@@ -87,7 +87,9 @@ class GraphedPipeline:
             pipeline(*self.static_in)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread-local error mode: another thread's runtime calls (e.g. the RCCL watchdog's event queries in a
+        # multi-GPU job) must not invalidate this capture
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             self.static_out = pipeline(*self.static_in)
 
     @torch.no_grad()
