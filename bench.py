@@ -3,18 +3,25 @@
 (BASELINE.json config 3; config 4 = the same per-GPU work on N GPUs + one RCCL all-gather).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 256]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+``--gpus N`` with N > 1 launches the N ranks itself (re-exec under ``torch.distributed.run``, one process per
+GPU, rendezvous on 127.0.0.1) unless it already runs under a launcher (WORLD_SIZE set); it REFUSES to run
+when fewer than N devices are visible - it never falls back to fewer GPUs silently.
 
 A step = one pass of the whole hot path over one synthetic batch that is already resident in
-HBM: CamCalib trunk + 3 FC heads -> soft-argmax decode -> (R, K) -> SPEC trunk -> 3-iteration
-regressor -> SMPL LBS (6890 vertices) -> 49 joints -> perspective projection (+ for N > 1 the
-all-gather of the packed per-image records).  Rank 0 prints ONE JSON line.
+HBM: CamCalib trunk + 3 FC heads -> soft-argmax decode -> (R, K) -> SPEC trunk -> regressor
+-> SMPL LBS (6890 vertices) -> 49 joints -> perspective projection (+ for N > 1 the
+all-gather of the packed per-image records, which the kernels write in place).  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
+import re
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,12 +34,38 @@ if ROOT not in sys.path:
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 PEAK_HBM_TBS = 8.0
+TRUNK_GFLOP_PER_IMAGE = 8.174272512   # 4.087136256 GMAC per ResNet-50 trunk at 224x224
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+# ------------------------------------------------------------------------------------------------
+# multi-GPU self-launch
+# ------------------------------------------------------------------------------------------------
+def self_launch(n: int) -> int:
+    """Re-exec this script as n ranks under torch.distributed.run (one process per GPU, RCCL)."""
+    have = torch.cuda.device_count()
+    if have < n:
+        log(f'[bench] ERROR: --gpus {n} requested but only {have} GPU(s) are visible; refusing to run on fewer '
+            f'devices (use --gpus {max(have, 1)})')
+        return 2
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log('[bench] launching', n, 'ranks:', ' '.join(cmd))
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------------
+# models / inputs
+# ------------------------------------------------------------------------------------------------
 def build_models(device):
     from spec_amd import synth, assets
     from spec_amd.modules import HMR, CameraRegressorNetwork
@@ -64,6 +97,9 @@ def make_inputs(B, device, seed):
     return x, scale, center, img_w, img_h
 
 
+# ------------------------------------------------------------------------------------------------
+# roofline bookkeeping
+# ------------------------------------------------------------------------------------------------
 def pmc_traffic():
     """HBM bytes per conv launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs,
     gfx950-corrected by scripts/rocprof_summary.py); None when no summary is committed."""
@@ -73,6 +109,57 @@ def pmc_traffic():
             return json.load(f).get('traffic_bytes_per_launch')
     except Exception:
         return None
+
+
+def executed_flops(e):
+    """FLOPs the matrix cores execute for a profiler entry: the Winograd F(2x2,3x3) kernels run 16/36 of the
+    algorithmic (direct-convolution) count their entries carry."""
+    return e['flops'] * (16.0 / 36.0 if e['kernel'].startswith('conv_wino') else 1.0)
+
+
+_LAYER_RE = re.compile(r'backbone\.(layer\d)\.\d+\.(conv\d(?:\+downsample)?|downsample)')
+
+
+def stage_name(e):
+    """Group the ~130 launches of a step into the stages of SURVEY.md App. B (both trunks together)."""
+    lab = e['label']
+    m = _LAYER_RE.search(lab)
+    if m:
+        return f'{m.group(1)}.{m.group(2)}'
+    if lab.endswith('backbone.conv1'):
+        return 'stem.conv7x7+bn+relu'
+    if lab.endswith('maxpool'):
+        return 'stem.maxpool'
+    if lab.startswith('fc_') or lab == 'avgpool':
+        return 'camcalib.avgpool+fc'
+    if lab.startswith('head.'):
+        return 'hmr.regressor'
+    if lab == 'smpl':
+        return 'smpl.' + e['kernel'].replace('smpl_', '')
+    return lab or e['kernel']
+
+
+def stage_table(entries):
+    """per stage, frac = max(bytes_alg / BW_peak, flops / FLOP_peak) / t_measured, naming the
+    resource that binds.  flops = executed MFMA FLOPs (Winograd: 16/36 of the direct count)."""
+    agg = {}
+    for e in entries:
+        a = agg.setdefault(stage_name(e), {'ms': 0.0, 'flops': 0.0, 'alg_flops': 0.0, 'bytes': 0.0, 'launches': 0, 'kernels': set()})
+        a['ms'] += e['ms']; a['flops'] += executed_flops(e); a['alg_flops'] += e['flops']
+        a['bytes'] += e['bytes']; a['launches'] += e['launches']; a['kernels'].add(e['kernel'])
+    rows = []
+    for name, a in agg.items():
+        t = a['ms'] * 1e-3
+        if t <= 0:
+            continue
+        t_hbm = a['bytes'] / (PEAK_HBM_TBS * 1e12)
+        t_mfma = a['flops'] / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+        rows.append({'stage': name, 'kernel': '|'.join(sorted(a['kernels'])), 'launches': a['launches'],
+                     'ms': round(a['ms'], 4), 'bound': 'hbm' if t_hbm >= t_mfma else 'mfma',
+                     'frac': round(max(t_hbm, t_mfma) / t, 4),
+                     'TFLOPs': round(a['flops'] / t / 1e12, 2), 'alg_TBps': round(a['bytes'] / t / 1e12, 3)})
+    rows.sort(key=lambda r: -r['ms'])
+    return rows
 
 
 def roofline_from_profile(entries):
@@ -100,6 +187,9 @@ def roofline_from_profile(entries):
             'frac_executed_of_peak': round(walg * 16.0 / 36.0 / PEAK_FP32_MFMA_TFLOPS, 4),
             'share_of_step_kernel_time': round(wms / total_ms, 4) if total_ms > 0 else None,
         }
+    # whole step against both roofs (every kernel of the step, executed FLOPs, algorithmic bytes)
+    all_fl = sum(executed_flops(e) for e in entries)
+    all_by = sum(e['bytes'] for e in entries)
     return {
         'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
         'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(),
@@ -115,11 +205,20 @@ def roofline_from_profile(entries):
         'algorithmic_hbm_GBps': round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0,
         'share_of_step_kernel_time': round(ms / total_ms, 4) if total_ms > 0 else None,
         'second_kernel': wino_info,
+        'whole_step': {'kernel_ms': round(total_ms, 3),
+                       'executed_mfma_TFLOPs': round(all_fl / (total_ms * 1e-3) / 1e12, 2) if total_ms > 0 else None,
+                       'frac_of_mfma_peak': round(all_fl / (total_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if total_ms > 0 else None,
+                       'algorithmic_TBps': round(all_by / (total_ms * 1e-3) / 1e12, 3) if total_ms > 0 else None},
     }
 
 
-def cpu_baseline(cs, hs, budget_s=12.0, batch=16):
-    """The CPU oracle (PyTorch-CPU fp32 restatement of the reference forward) on the host cores."""
+# ------------------------------------------------------------------------------------------------
+# CPU baseline (oracle = test infrastructure; imported here and nowhere in the product path)
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline(cs, hs, budget_s=22.0, batch=16):
+    """The CPU oracle (PyTorch-CPU fp32 restatement of the reference forward) on the host cores: thread sweep
+    (oversubscribing SMT siblings costs 2x on this path), best setting timed longer, plus batch-1 latency and the
+    single-thread rate."""
     from spec_amd import synth
     from oracle import heads
     from oracle.models import CamCalibOracle, HMROracle, load_numpy_state, full_pipeline
@@ -130,19 +229,50 @@ def cpu_baseline(cs, hs, budget_s=12.0, batch=16):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
     x = t(synth.images(3, batch))
     sc, ce, iw, ih = [t(a) for a in synth.bbox_inputs(3, batch, jitter=False)]
-    full_pipeline(occ, ohm, x[:2], sc[:2], ce[:2], iw[:2], ih[:2])     # warm-up
+    logical = os.cpu_count() or 1
+    try:
+        import psutil
+        physical = psutil.cpu_count(logical=False) or logical
+    except Exception:
+        physical = logical
+    t_start = time.perf_counter()
+
+    def rate(nthreads, nimg, reps=1):
+        torch.set_num_threads(nthreads)
+        full_pipeline(occ, ohm, x[:2], sc[:2], ce[:2], iw[:2], ih[:2])     # warm-up at this thread count
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            full_pipeline(occ, ohm, x[:nimg], sc[:nimg], ce[:nimg], iw[:nimg], ih[:nimg])
+        return nimg * reps / (time.perf_counter() - t0)
+
+    sweep = {}
+    for nt in sorted({n for n in (8, 16, 32, 64, physical, logical) if 1 <= n <= logical}):
+        if time.perf_counter() - t_start > budget_s * 0.55:
+            break
+        sweep[nt] = round(rate(nt, batch), 2)
+    best_nt = max(sweep, key=sweep.get)
+    torch.set_num_threads(best_nt)
     n, t0 = 0, time.perf_counter()
     while True:
         full_pipeline(occ, ohm, x, sc, ce, iw, ih)
         n += batch
         el = time.perf_counter() - t0
-        if el >= budget_s or n >= 20 * batch:
+        if time.perf_counter() - t_start >= budget_s * 0.85 or n >= 10 * batch:
             break
-    return {'value': round(n / el, 2), 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+    best = n / el
+    b1 = rate(best_nt, 1, reps=3)
+    single = rate(1, 1, reps=1)
+    torch.set_num_threads(best_nt)
+    return {'value': round(best, 2), 'unit': 'images/s', 'cores': best_nt, 'kind': 'port',
             'sample': f'{n} synthetic 224x224 images in batches of {batch}, full CamCalib+SPEC+SMPL forward, '
-                      f'PyTorch-CPU fp32 oracle, {el:.1f}s'}
+                      f'PyTorch-CPU fp32 oracle, {el:.1f}s at the best thread count of the sweep',
+            'thread_sweep_images_per_s': {str(k): v for k, v in sweep.items()},
+            'host': {'logical_cpus': logical, 'physical_cores': physical},
+            'batch1_images_per_s': round(b1, 2), 'batch1_threads': best_nt,
+            'single_thread_images_per_s': round(single, 3)}
 
 
+# ------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -151,19 +281,31 @@ def main():
     ap.add_argument('--batch', type=int, default=256, help='images per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--no-sustained', action='store_true', help='skip the >= 5 s sustained region')
+    ap.add_argument('--sustained-seconds', type=float, default=5.0)
+    ap.add_argument('--no-c2', action='store_true', help='skip the config-2 line (CamCalib trunk only, batch 64)')
     ap.add_argument('--no-overlap', action='store_true', help='run CamCalib and SPEC back to back on one stream')
     ap.add_argument('--force-variant', type=int, default=0, help='debug: force a conv tile (1:128x128 2:128x64 3:64x64)')
     ap.add_argument('--graph', action='store_true', help='(default) capture the step in a hipGraph and replay it')
-    ap.add_argument('--no-graph', action='store_true', help='launch the ~130 kernels of a step eagerly')
+    ap.add_argument('--no-graph', action='store_true', help='launch the ~120 kernels of a step eagerly')
     ap.add_argument('--subbatch', type=int, default=-1, help='trunk sub-batch for the early stages (0 = off, -1 = library default)')
     ap.add_argument('--subbatch-layers', type=int, default=-1)
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        log('[bench] ERROR: --gpus must be >= 1')
+        sys.exit(2)
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus > 1 and world == 1:
-        log('[bench] --gpus > 1 needs a torch.distributed.run launch; running 1 GPU')
+    if world != args.gpus:
+        log(f'[bench] ERROR: launched with WORLD_SIZE={world} but --gpus {args.gpus}; they must agree')
+        sys.exit(2)
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        log(f'[bench] ERROR: rank {rank} needs GPU {local_rank}, {torch.cuda.device_count()} visible (no CPU path)')
+        sys.exit(2)
     n_gpus = world
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
@@ -173,7 +315,7 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=device)
 
-    from spec_amd.pipeline import SpecPipeline, AsyncGather
+    from spec_amd.pipeline import SpecPipeline, AsyncGather, gather_outputs
     torch.set_grad_enabled(False)
     cc, hm, cs, hs = build_models(device)
     pipe = SpecPipeline(cc, hm, overlap=not args.no_overlap)
@@ -183,60 +325,103 @@ def main():
             m._engine.set_option('trunk_subbatch', args.subbatch)
         if args.subbatch_layers >= 0:
             m._engine.set_option('trunk_subbatch_layers', args.subbatch_layers)
-    if args.force_variant:
-        cc._engine.set_option('force_conv_variant', args.force_variant)
+        if args.force_variant:
+            m._engine.set_option('force_conv_variant', args.force_variant)
     B = args.batch
     x, scale, center, img_w, img_h = make_inputs(B, device, 20210001 + rank)
+
+    # N > 1: one all-gather of the packed records per step, started asynchronously so that RCCL moves step s over xGMI
+    # while the kernels of step s+1 run (at most 2 in flight; everything is drained inside the timed region).  The
+    # kernels write the record in place; under graph replay two record buffers alternate so that step s+1 never
+    # writes the buffer the collective of step s still reads.
+    gather = AsyncGather(depth=2) if world > 1 else None
 
     run = pipe
     launch_mode = 'eager launches'
     if not args.no_graph:
-        # the step is ~130 dependent launches: replaying them as one hipGraph removes the inter-launch gaps
+        # the step is ~120 dependent launches: replaying them as one hipGraph removes the inter-launch gaps
         # (+1 % at B=256).  Same kernels, same work; falls back to eager launches if capture is unavailable.
         try:
             from spec_amd.pipeline import GraphedPipeline
-            run = GraphedPipeline(pipe, x, scale, center, img_w, img_h)
+            run = GraphedPipeline(pipe, x, scale, center, img_w, img_h, buffers=2 if world > 1 else 1)
             launch_mode = 'hipGraph replay'
         except Exception as e:
             log('[bench] hipGraph capture failed, launching eagerly:', repr(e))
             run = pipe
 
-    # N > 1: one all-gather of the packed records per step, started asynchronously so that RCCL moves step s over xGMI
-    # while the kernels of step s+1 run (at most 2 in flight; everything is drained inside the timed region)
-    gather = AsyncGather(depth=2) if world > 1 else None
-
     def step():
+        if gather is not None:
+            gather.reserve()        # the buffer this step writes must not be read by a pending collective
         out = run(x, scale, center, img_w, img_h)
         if gather is not None:
             return gather.submit(out)
         return out
 
+    def timed(nsteps):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step()
+        if gather is not None:
+            gather.drain()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
     for _ in range(args.warmup):
         step()
     if gather is not None:
         gather.drain()
-    torch.cuda.synchronize()
+    local_elapsed = timed(args.steps)
+    elapsed = local_elapsed
+    per_rank = None
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    if gather is not None:
-        gather.drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        tt = torch.tensor([local_elapsed], device=device, dtype=torch.float64)
+        allt = torch.empty(world, device=device, dtype=torch.float64)
+        dist.all_gather_into_tensor(allt, tt)
+        elapsed = float(allt.max().item())
+        per_rank = [round(B * args.steps / float(v), 1) for v in allt.tolist()]
     ms_per_step = elapsed / args.steps * 1e3
     value = B * n_gpus * args.steps / elapsed
 
-    roof, stages = None, None
+    # ---- sustained region: the same step for >= 5 s (clock / thermal steady state) -------------------------
+    sustained = None
+    if not args.no_sustained:
+        n_sus = max(args.steps, int(math.ceil(args.sustained_seconds / (ms_per_step * 1e-3))))
+        el = timed(n_sus)
+        if world > 1:
+            tt = torch.tensor([el], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        sustained = {'steps': n_sus, 'seconds': round(el, 3), 'ms_per_step': round(el / n_sus * 1e3, 3),
+                     'images_per_s': round(B * n_gpus * n_sus / el, 2)}
+
+    # ---- N > 1: the collective alone ------------------------------------------------------------------------
+    comm = None
+    if world > 1:
+        out = pipe(x, scale, center, img_w, img_h)
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        gather_outputs(out)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            full = gather_outputs(out)
+        e1.record()
+        torch.cuda.synchronize()
+        ag_ms = e0.elapsed_time(e1) / 5
+        comm = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
+                'record_bytes_per_image': int(out['record'].shape[1] * 4),
+                'all_gather_ms_blocking': round(ag_ms, 3), 'gathered_MB_per_rank': round(full.numel() * 4 / 1e6, 1),
+                'per_rank_images_per_s': per_rank}
+
+    roof, stages, c2 = None, None, None
     if rank == 0 and not args.no_profile:
         for m in (cc, hm):
             m._engine.profile(True)
@@ -271,22 +456,35 @@ def main():
         roof = roofline_from_profile(entries)
         roof['region'] = {'steps': nprof, 'ms_per_step': round(prof_ms_per_step, 3), 'streams': 1, 'launch': 'eager launches',
                           'images_per_s': round(B * 1e3 / prof_ms_per_step, 1)}
-        agg = {}
-        for r in entries:
-            a = agg.setdefault(r['kernel'], {'ms': 0.0, 'flops': 0.0, 'bytes': 0.0, 'launches': 0})
-            for k in ('ms', 'flops', 'bytes', 'launches'):
-                a[k] += r[k]
-        stages = {k: {'ms': round(v['ms'], 3), 'launches': v['launches'],
-                      'TFLOPs': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 else 0,
-                      'GBps': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) if v['ms'] > 0 else 0}
-                  for k, v in agg.items()}
-        log('[bench] per-kernel (HIP events, one step):')
-        for k, v in sorted(stages.items(), key=lambda kv: -kv[1]['ms']):
-            log(f'    {k:34s} {v["ms"]:9.3f} ms  x{v["launches"]:<4d} {v["TFLOPs"]:7.2f} TF/s {v["GBps"]:9.1f} GB/s(alg)')
+        stages = stage_table(entries)
+        log('[bench] per-stage (HIP events, one step, both trunks):')
+        for r in stages:
+            log(f'    {r["stage"]:28s} {r["ms"]:8.3f} ms x{r["launches"]:<3d} {r["bound"]:4s} frac {r["frac"]:.3f} '
+                f'{r["TFLOPs"]:7.2f} TF/s {r["alg_TBps"]:6.3f} TB/s(alg)  {r["kernel"]}')
         outdir = os.path.join(ROOT, 'gpurun_out')
         if os.path.isdir(outdir):
             with open(os.path.join(outdir, 'bench_profile.json'), 'w') as f:
                 json.dump({'entries': entries, 'stages': stages, 'ms_per_step': ms_per_step}, f, indent=1)
+
+    # ---- config 2: CamCalib ResNet-50 trunk only, batch 64 -----------------------------------
+    if rank == 0 and not args.no_c2:
+        x64 = x[:64].contiguous() if B >= 64 else make_inputs(64, device, 20210001)[0]
+        eng = cc._engine
+        for _ in range(3):
+            eng.trunk(x64)
+        torch.cuda.synchronize()
+        n2 = max(20, args.steps)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n2):
+            eng.trunk(x64)
+        e1.record()
+        torch.cuda.synchronize()
+        ms2 = e0.elapsed_time(e1) / n2
+        tf2 = 64 * TRUNK_GFLOP_PER_IMAGE / ms2                     # GFLOP / ms = TFLOP/s (algorithmic, direct-conv count)
+        c2 = {'workload': 'C2: CamCalib ResNet-50 trunk only, synthetic 224x224, batch 64, 1 stream, eager launches',
+              'batch': 64, 'steps': n2, 'ms_per_step': round(ms2, 3), 'images_per_s': round(64e3 / ms2, 1),
+              'algorithmic_TFLOPs': round(tf2, 2), 'frac_of_mfma_peak_algorithmic': round(tf2 / PEAK_FP32_MFMA_TFLOPS, 4)}
 
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
@@ -306,11 +504,11 @@ def main():
                                    'synthetic 224x224 crops resident in HBM',
                        'batch_per_gpu': B, 'global_batch': B * n_gpus,
                        'streams': 1 if args.no_overlap else 2, 'launch': launch_mode,
-                       'parallelism': f'images sharded over {n_gpus} GPU(s), 1 all-gather' if n_gpus > 1 else 'single GPU'},
-            'roofline': roof, 'cpu_baseline': cpu,
+                       'parallelism': (f'images sharded over {n_gpus} GPUs (one process per GPU), 1 asynchronous RCCL '
+                                       f'all-gather of the packed records per step') if n_gpus > 1 else 'single GPU'},
+            'roofline': roof, 'cpu_baseline': cpu, 'sustained': sustained, 'c2': c2, 'comm': comm,
+            'stages': stages,
         }
-        if stages is not None:
-            line['stages_ms'] = {k: v['ms'] for k, v in stages.items()}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()          # rank 0 may still be in its profiling pass

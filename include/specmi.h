@@ -53,7 +53,10 @@ enum {
 
 enum {
     SPECMI_MODEL_CAMCALIB = 0, /* camcalib/model.py CameraRegressorNetwork(resnet50, 1 FC) */
-    SPECMI_MODEL_HMR = 1       /* spec/models/hmr.py HMR(resnet50)                         */
+    SPECMI_MODEL_HMR = 1,      /* spec/models/hmr.py HMR(resnet50)                         */
+    SPECMI_MODEL_SMPL = 2      /* the SMPL body model alone ("smpl.*" tensors only): specmi_smpl_native /
+                                  specmi_smpl_forward for ground-truth meshes in the evaluation code
+                                  (spec/utils/compute_error.py:118-160, spec/trainer.py:71-86)             */
 };
 
 /* Output dict of HMR.forward (spec/models/hmr.py:113,122): device pointers, fp32. */
@@ -97,7 +100,15 @@ const char* specmi_version(void);
  * run as fused Winograd F(2x2,3x3) on the fp32 matrix cores; 0: always the direct implicit GEMM);
  * "fuse_downsample" (default 1: a bottleneck's downsample conv + BN is folded into its conv3 as one 1x1
  * GEMM over [conv2 output | block input]; 0: separate launch + residual add, as torchvision writes it);
- * "fc_splitk" (default 1: FC GEMMs with <= 1024 rows run as parallel K slices + a fixed-order reduction). */
+ * "fc_splitk" (default 1: FC GEMMs with <= 1024 rows run as parallel K slices + a fixed-order reduction);
+ * "head_collapse" (default 1; HMR, read at commit and at forward: the three IEF iterations of HMRHead - an affine map in
+ * eval mode, no activation between fc1 / fc2 / dec* and dropout = identity - run as ONE (features + camera features) -> 157
+ * GEMM whose matrix is composed in float64 at commit; 0: the nine GEMMs of the reference loop);
+ * "output_ld" (HMR, default 0 = dense outputs; n > 0: every per-image output pointer of specmi_hmr_forward /
+ * specmi_hmr_head_forward / specmi_smpl_forward addresses image 0 and image b lives at pointer + b*n floats, i.e. the outputs
+ * are columns of ONE caller-owned (B, n) record - the packed all-gather record of SURVEY.md 8e - written by the kernels
+ * directly); "angle_ld" (the same for vfov / pitch / roll of specmi_camcalib_decode);
+ * "force_conv_variant" / "force_wino_variant" (tests and tuning: pin the tile variant of this handle's launches, 0 = auto). */
 int specmi_set_option_i32(specmi_handle* h, const char* name, int value);
 int specmi_set_option_f32(specmi_handle* h, const char* name, float value);
 
@@ -132,6 +143,15 @@ int specmi_camcalib_decode(specmi_handle* h, const float* logits_vfov, const flo
                            const float* img_w, float* vfov, float* pitch, float* roll,
                            float* f_pix, float* cam_rotmat, float* cam_intrinsics, void* stream);
 
+/* The two per-row reductions of camcalib/cam_utils.py on a (rows, nbins) device logit tensor:
+ *   argmax_idx[row] = np.argmax(row) - bins2vfov / bins2pitch / bins2roll / bins2horizon (cam_utils.py:66-91), the 'kl' / 'ce'
+ *                     and legacy branches of convert_preds_to_angles (:123-133); first maximum, NaN counts as maximum;
+ *                     the caller gathers the bin-centre table (host float64, as the reference returns it);
+ *   soft_idx[row]   = get_softargmax (cam_utils.py:110-118): softmax expectation of the index, normalised to [-1, 1].
+ * Either output may be NULL (not both). */
+int specmi_camcalib_bins(specmi_handle* h, const float* logits, int rows, int nbins, int32_t* argmax_idx,
+                         float* soft_idx, void* stream);
+
 /* read_cam_params (spec/utils/cam_params.py:24-50) for angles that were decoded earlier, e.g.
  * read back from the CamCalib result pickle: (pitch, roll, f_pix, img_w, img_h) (B,) device ->
  * cam_rotmat (B,3,3), cam_intrinsics (B,3,3) (K[2,2] = 0).  Either output may be NULL. */
@@ -147,6 +167,14 @@ int specmi_hmr_forward(specmi_handle* h, const float* images_nchw, int B, int H,
                        const float* cam_rotmat, const float* cam_intrinsics,
                        const float* bbox_scale, const float* bbox_center, const float* img_w,
                        const float* img_h, const specmi_hmr_outputs* out, void* stream);
+
+/* Everything of HMR.forward after `features = self.backbone(images)` (spec/models/hmr.py:94-122): regressor head +
+ * SMPL head from an NHWC layer-4 map (B, fh, fw, C).  Lets a caller run the SPEC trunk beside the CamCalib network
+ * (whose output the head needs) on another stream and join afterwards. */
+int specmi_hmr_regress(specmi_handle* h, const float* feat_nhwc, int B, int fh, int fw,
+                       const float* cam_rotmat, const float* cam_intrinsics, const float* bbox_scale,
+                       const float* bbox_center, const float* img_w, const float* img_h,
+                       const specmi_hmr_outputs* out, void* stream);
 
 /* ---- stage-level entry points (parity tests, profiling, reuse) ------------------------- */
 
@@ -170,6 +198,14 @@ int specmi_smpl_forward(specmi_handle* h, const float* rotmat, const float* beta
                         const float* bbox_center, const float* img_w, const float* img_h,
                         float* vertices, float* joints3d, float* joints2d, float* cam_t,
                         void* stream);
+
+/* The body model WITHOUT the 49-joint wrapper - smplx.SMPL.forward as the evaluation code calls it (`smpl_native` /
+ * `body_model` / `body_model_orig`, spec/trainer.py:71-86,249-254, spec/utils/compute_error.py:118-160): `pose` is
+ * (B,24,3,3) rotation matrices (pose2rot=False) or, with pose_is_axis_angle != 0, (B,72) axis-angle vectors
+ * (global_orient | body_pose; smplx batch_rodrigues); outputs vertices (B,V,3) and / or joints24 (B,24,3) =
+ * `.joints[:, :24]`, the posed kinematic-chain joints.  Either output may be NULL (not both). */
+int specmi_smpl_native(specmi_handle* h, const float* pose, int pose_is_axis_angle, const float* betas, int B,
+                       float* vertices, float* joints24, void* stream);
 
 /* A single fused conv+BN(+residual)(+ReLU) layer, y = act(conv(x)*scale + shift [+ res]).
  * x (B,H,W,Cin) NHWC device; w (Cout,Cin,KH,KW) OIHW HOST; scale/shift (Cout) HOST;
@@ -221,6 +257,15 @@ int specmi_eval_mesh(specmi_handle* h, const float* pred_vertices, const float* 
  * (B,J,3) joint sets. */
 int specmi_eval_joints(specmi_handle* h, const float* pred_joints, const float* gt_joints, int B,
                        int J, float* mpjpe_mm, float* pampjpe_mm, void* stream);
+
+/* pred_joints = einsum('bik,ji->bjk', vertices, J_regressor) (spec/utils/compute_error.py:184,187): vertices (B,V,3),
+ * J_regressor (J,V) device -> joints (B,J,3). */
+int specmi_regress_joints(specmi_handle* h, const float* vertices, int B, int V, const float* J_regressor, int J,
+                          float* joints, void* stream);
+
+/* torch.bmm(R, x.transpose(2,1)).transpose(2,1) (spec/utils/compute_error.py:164-165,186): R (B,3,3), points (B,N,3)
+ * -> out (B,N,3), out[b,n] = R[b] points[b,n]. */
+int specmi_rotate_points(specmi_handle* h, const float* R, const float* points, int B, int N, float* out, void* stream);
 
 /* ---- profiling -------------------------------------------------------------------------- */
 

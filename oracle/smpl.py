@@ -45,6 +45,21 @@ def batch_rigid_transform(rot_mats, joints, parents):
     return posed_joints, rel_transforms
 
 
+def batch_rodrigues(rot_vecs, epsilon=1e-8):
+    """smplx.lbs.batch_rodrigues (0.1.28): (N,3) axis-angle -> (N,3,3)."""
+    batch_size = rot_vecs.shape[0]
+    dtype = rot_vecs.dtype
+    angle = torch.norm(rot_vecs + epsilon, dim=1, keepdim=True)
+    rot_dir = rot_vecs / angle
+    cos = torch.unsqueeze(torch.cos(angle), dim=1)
+    sin = torch.unsqueeze(torch.sin(angle), dim=1)
+    rx, ry, rz = torch.split(rot_dir, 1, dim=1)
+    zeros = torch.zeros((batch_size, 1), dtype=dtype)
+    K = torch.cat([zeros, -rz, ry, rz, zeros, -rx, -ry, rx, zeros], dim=1).view((batch_size, 3, 3))
+    ident = torch.eye(3, dtype=dtype).unsqueeze(dim=0)
+    return ident + sin * K + (1 - cos) * torch.bmm(K, K)
+
+
 def lbs_rotmat(betas, rot_mats, v_template, shapedirs, posedirs, J_regressor, parents, lbs_weights):
     """``smplx.lbs.lbs(..., pose2rot=False)``: rot_mats (B,24,3,3) -> verts (B,V,3), joints (B,24,3)."""
     batch_size = max(betas.shape[0], rot_mats.shape[0])
@@ -95,6 +110,11 @@ class SMPLOracle(nn.Module):
                                       self.lbs_weights)
         extra = torch.index_select(vertices, 1, self.extra_joints_idxs)
         return vertices, torch.cat([joints, extra], dim=1)
+
+    def native_axis_angle(self, betas, pose_aa):
+        """smplx.SMPL.forward(global_orient=pose[:, :3], body_pose=pose[:, 3:], betas) with pose2rot=True."""
+        B = pose_aa.shape[0]
+        return self.native(betas, batch_rodrigues(pose_aa.reshape(-1, 3)).view(B, 24, 3, 3))
 
     def forward(self, betas, rot_mats):
         vertices, joints45 = self.native(betas, rot_mats)

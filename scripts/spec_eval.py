@@ -1,15 +1,16 @@
 #!/usr/bin/env python
-"""Build-owned counterpart of the reference's evaluation flow (``scripts/spec_eval.py`` ->
-``SPECTrainer.validation_step`` spec/trainer.py:230-364 -> ``compute_error``
-spec/utils/compute_error.py:89-223) on MI355X: batches of 64 (``DATASET.BATCH_SIZE``,
-spec/config.py:85) go through the hot path with the *precomputed* CamCalib predictions of the
-dataset (``pred_cam_rotmat`` / ``pred_cam_int``, spec/dataset/cam_dataset.py:617-653), the
-metrics are computed on the device and the ``evaluation_results_<ds>.pkl`` dump is written.
+"""Config 5 in one command - the MI355X counterpart of the reference's ``scripts/spec_eval.py``:
 
-Real data (``--npz``: arrays img (N,3,224,224) fp32 normalised crops, cam_rotmat (N,3,3),
-cam_int (N,3,3), scale (N,), center (N,2), orig_shape (N,2)=[h,w], gt_vertices (N,6890,3))
-needs the licensed assets + checkpoint; ``--synthetic N`` builds a stand-in dataset whose ground
-truth is the model's own prediction plus noise, so the printed numbers exercise the full code path.
+    python scripts/spec_eval.py --cfg data/spec/checkpoints/spec_config.yaml --opts DATASET.VAL_DS spec-syn
+
+With the reference's ``data/`` tree present (README.md:127-147: licensed SMPL model, checkpoints, datasets) this loads
+the Lightning checkpoint + SMPL pickle + annotations, runs every image through the hot path on the GPU in batches of
+``DATASET.BATCH_SIZE`` with the dataset's precomputed CamCalib camera (or the GT camera with TESTING.USE_GT_CAM
+True), writes ``evaluation_results_<ds>.pkl`` in the reference's format, scores it on the device like
+``spec/utils/compute_error.py`` and prints W-MPJPE / PA-MPJPE / W-PVE beside the README table (README.md:155-159).
+
+``--standin DIR`` first writes a small synthetic ``data/`` tree in the REAL container formats under DIR and evaluates
+that (a dry run of the whole flow; the numbers are meaningless).  ``--synthetic N`` is the quick in-memory variant.
 """
 import argparse
 import os
@@ -22,68 +23,78 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--npz', type=str, default=None)
-    ap.add_argument('--ckpt', type=str, default=None)
-    ap.add_argument('--synthetic', type=int, default=0)
-    ap.add_argument('--batch_size', type=int, default=64)
-    ap.add_argument('--log_dir', type=str, default='logs/eval')
-    ap.add_argument('--dataset_name', type=str, default='spec-syn')
-    args = ap.parse_args()
-
+def synthetic(args):
+    """In-memory stand-in: ground truth = the model's own prediction + noise, scored with the device metrics."""
     from spec_amd import assets, synth, metrics, io_formats
-    from spec_amd.checkpoint import load_pretrained_model, read_checkpoint
+    from spec_amd.cam_utils import cam_params_from_angles
     from spec_amd.modules import HMR
-    torch.set_grad_enabled(False)
     dev = torch.device('cuda')
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
-
-    if args.synthetic:
-        N = args.synthetic
-        smpl = assets.use_synthetic_assets(1003)
-        hm = HMR(use_cam=True, use_cam_feats=True)
-        hm.load_state_dict({k: t(v) for k, v in synth.hmr_state(1002, True).items()}, strict=False)
-        scale, center, img_w, img_h = synth.bbox_inputs(5, N, 640., 480.)
-        rng = np.random.default_rng(0)
-        ang = rng.uniform(-0.4, 0.4, (N, 2)).astype(np.float32)
-        from spec_amd.cam_utils import cam_params_from_angles
-        R, K = cam_params_from_angles(ang[:, 0], ang[:, 1], rng.uniform(300, 900, N).astype(np.float32), img_w, img_h)
-        data = {'img': synth.images(123, N), 'cam_rotmat': R.cpu().numpy(), 'cam_int': K.cpu().numpy(), 'scale': scale,
-                'center': center, 'orig_shape': np.stack([img_h, img_w], 1), 'gt_vertices': None}
-        J24 = t(smpl['J_regressor']).to(dev)
-    else:
-        assets.load_assets()
-        smpl = assets.smpl_model()
-        hm = HMR(backbone='resnet50', img_res=224, pretrained=None, use_cam_feats=True, use_cam=True)
-        load_pretrained_model(hm, read_checkpoint(args.ckpt)['state_dict'], overwrite_shape_mismatch=True, remove_lightning=True)
-        data = dict(np.load(args.npz))
-        J24 = t(smpl['J_regressor']).to(dev)
+    N = args.synthetic
+    smpl = assets.use_synthetic_assets(1003)
+    hm = HMR(use_cam=True, use_cam_feats=True)
+    hm.load_state_dict({k: t(v) for k, v in synth.hmr_state(1002, True).items()}, strict=False)
     hm.to(dev).eval().commit(dev, freeze=True)
-
-    N = data['img'].shape[0]
+    scale, center, img_w, img_h = synth.bbox_inputs(5, N, 640., 480.)
+    rng = np.random.default_rng(0)
+    ang = rng.uniform(-0.4, 0.4, (N, 2)).astype(np.float32)
+    R, K = cam_params_from_angles(ang[:, 0], ang[:, 1], rng.uniform(300, 900, N).astype(np.float32), img_w, img_h)
+    img = synth.images(123, N)
+    J24 = t(smpl['J_regressor']).to(dev)
+    Jh = t(synth.h36m_regressor(1003)).to(dev)
     dump = io_formats.EvalDump()
     acc = {'w_mpjpe_24': [], 'pa_mpjpe_24': [], 'w_v2v': []}
     for b0 in range(0, N, args.batch_size):
         sl = slice(b0, min(N, b0 + args.batch_size))
-        x = t(data['img'][sl]).to(dev)
-        shp = t(data['orig_shape'][sl]).float().to(dev)
-        # positional call order of spec/trainer.py:139
-        pred = hm(x, t(data['cam_rotmat'][sl]).to(dev), t(data['cam_int'][sl]).to(dev), t(data['scale'][sl]).to(dev),
-                  t(data['center'][sl]).to(dev), shp[:, 1].contiguous(), shp[:, 0].contiguous())
+        pred = hm(t(img[sl]).to(dev), R[sl], K[sl], t(scale[sl]).to(dev), t(center[sl]).to(dev), t(img_w[sl]).to(dev),
+                  t(img_h[sl]).to(dev))                         # positional call order of spec/trainer.py:139
         dump.add(pred)
-        if data['gt_vertices'] is None:          # synthetic ground truth: prediction + 1 cm noise + a global offset
-            g = torch.Generator(device=dev).manual_seed(b0)
-            gt = pred['smpl_vertices'] + 0.01 * torch.randn(pred['smpl_vertices'].shape, device=dev, generator=g) + 0.05
-        else:
-            gt = t(data['gt_vertices'][sl]).to(dev)
-        mp, pa, v2v = metrics.eval_single(pred['smpl_vertices'], gt, J24, joint_sel=range(24))
+        g = torch.Generator(device=dev).manual_seed(b0)        # synthetic ground truth: prediction + 1 cm noise + offset
+        gt = pred['smpl_vertices'] + 0.01 * torch.randn(pred['smpl_vertices'].shape, device=dev, generator=g) + 0.05
+        gt_j24 = metrics.regress_joints(gt, J24)               # stands for the GT kinematic-chain joints
+        mp, pa = metrics.w_mpjpe_24(pred['smpl_vertices'], gt_j24, J24)
+        _, _, v2v = metrics.eval_single(pred['smpl_vertices'], gt, Jh)
         acc['w_mpjpe_24'].append(mp); acc['pa_mpjpe_24'].append(pa); acc['w_v2v'].append(v2v)
     path = dump.write(args.log_dir, args.dataset_name)
     res = {k: float(torch.cat(v).mean()) for k, v in acc.items()}
     print(f'***** RESULTS ON {args.dataset_name.upper()} ({N} samples) *****')
     print(f"W-MPJPE-24: {res['w_mpjpe_24']:.3f}\nPA-MPJPE-24: {res['pa_mpjpe_24']:.3f}\nW-V2V: {res['w_v2v']:.3f}")
     print('dump:', path)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--cfg', type=str, default=None, help='cfg file path (reference: data/spec/checkpoints/spec_config.yaml)')
+    ap.add_argument('--opts', default=[], nargs='*', help='additional options to update config')
+    ap.add_argument('--data-root', type=str, default='.', help='directory that holds data/ (the reference runs from its repo root)')
+    ap.add_argument('--ckpt', type=str, default=None, help='checkpoint (default: TRAINING.PRETRAINED_LIT of the config, '
+                                                            'else data/spec/checkpoints/spec_checkpoint.ckpt)')
+    ap.add_argument('--limit', type=int, default=None, help='evaluate only the first N samples of each dataset')
+    ap.add_argument('--standin', type=str, default=None, help='write a synthetic data/ tree in the real formats here and evaluate it')
+    ap.add_argument('--synthetic', type=int, default=0)
+    ap.add_argument('--batch_size', type=int, default=64)
+    ap.add_argument('--log_dir', type=str, default='logs/eval')
+    ap.add_argument('--dataset_name', type=str, default='spec-syn')
+    args = ap.parse_args()
+    torch.set_grad_enabled(False)
+    if args.synthetic:
+        return synthetic(args)
+    from spec_amd import evaluation
+    root = args.data_root
+    cfg = args.cfg
+    if args.standin:
+        evaluation.write_standin_data_tree(args.standin, dataset=args.dataset_name)
+        root = args.standin
+        cfg = cfg or os.path.join(root, 'data/spec/checkpoints/spec_config.yaml')
+    if cfg is None and os.path.exists(os.path.join(root, 'data/spec/checkpoints/spec_config.yaml')):
+        cfg = os.path.join(root, 'data/spec/checkpoints/spec_config.yaml')
+    hp = evaluation.load_config(cfg, args.opts)
+    ckpt = args.ckpt
+    if ckpt is None and hp['TRAINING']['PRETRAINED_LIT'] is None:
+        ckpt = 'data/spec/checkpoints/spec_checkpoint.ckpt'          # scripts/spec_demo.py:31
+    if not os.path.isdir(os.path.join(root, 'data')):
+        sys.exit(f'{os.path.join(root, "data")} not found: download the reference data (README.md:127-147) or use --standin DIR')
+    evaluation.run_evaluation(hp, data_root=root, ckpt=ckpt, limit=args.limit)
 
 
 if __name__ == '__main__':

@@ -74,7 +74,11 @@ def load_smpl_file(path: str, j_regressor_extra: Optional[np.ndarray] = None) ->
                 path = os.path.join(path, cand)
                 break
     if path.endswith('.npz'):
-        raw = dict(np.load(path, allow_pickle=True))
+        try:
+            raw = dict(np.load(path, allow_pickle=False))     # plain arrays only: no pickle execution
+        except ValueError as e:
+            raise ValueError(f'{path}: object (pickled) members are not loaded from .npz files; convert the model to '
+                             f'plain arrays or use the .pkl (read through a restricted unpickler)') from e
     else:
         with open(path, 'rb') as f:
             raw = _RestrictedUnpickler(f, encoding='latin1').load()

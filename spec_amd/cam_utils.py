@@ -1,12 +1,16 @@
 """CamCalib decode + CamCalib->SPEC hand-off on the GPU.
 
-Mirrors the call surface of ``camcalib/cam_utils.py:110-145`` (``convert_preds_to_angles``,
-soft-argmax branch) and ``spec/utils/cam_params.py:24-50`` (R, K construction) but runs as one
-fused HIP launch (``specmi_camcalib_decode``) on the logits that are already in HBM, instead
-of the reference's per-image subprocess + pickle hand-off (``spec/tester.py:86-88``).
+Mirrors the whole call surface of ``camcalib/cam_utils.py`` (bin tables :23-63, ``bins2*`` :66-91,
+``*2soft_idx`` / ``angle_to_soft_idx`` / ``soft_idx_to_angle`` :94-107, ``get_softargmax`` :110-118,
+``convert_preds_to_angles`` :121-145 with the reference's defaults) and ``spec/utils/cam_params.py:24-50``
+(R, K construction).  The reductions over the 256 bins (arg-max, soft-arg-max) run on the logits that are
+already in HBM (``specmi_camcalib_bins`` / ``specmi_camcalib_decode``); bin tables are host float64 NumPy
+arrays and ``bins2*`` return float64 NumPy arrays exactly like the reference.  Host (CPU) logits are moved
+to the GPU first - there is no CPU arithmetic path.
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 from . import constants as C
@@ -22,6 +26,84 @@ def _engine(device) -> Engine:
     return _engines[dev]
 
 
+# ---- bin tables (camcalib/cam_utils.py:23-63) -------------------------------------------------------------
+def get_bins(minval, maxval, sigma, alpha, beta, kappa):
+    """Remember, bin 0 = below value! last bin mean >= maxval  (camcalib/cam_utils.py:23-37; scipy.stats.norm(0,
+    sigma).pdf written out: exp(-(x/sigma)^2 / 2) / sqrt(2 pi) / sigma)."""
+    x = np.linspace(minval, maxval, 255)
+    y = x / sigma
+    pdf = np.exp(-y ** 2 / 2.0) / np.sqrt(2 * np.pi) / sigma
+    pdf /= (pdf.max())
+    pdf *= alpha
+    pdf = pdf.max() * beta - pdf
+    cumsum = np.cumsum(pdf)
+    cumsum = cumsum / cumsum.max() * kappa
+    cumsum -= cumsum[pdf.size // 2]
+    return cumsum
+
+
+def _centers(bins):
+    c = bins.copy()
+    c[:-1] += np.diff(c) / 2
+    return np.append(c, bins[-1])
+
+
+pitch_bins = np.linspace(-0.6, 0.6, 255)
+pitch_bins_centers = _centers(pitch_bins)
+horizon_bins = np.linspace(-0.5, 1.5, 255)
+horizon_bins_centers = _centers(horizon_bins)
+roll_bins = get_bins(-np.pi / 6, np.pi / 6, 0.5, 0.04, 1.1, np.pi)
+roll_bins_centers = _centers(roll_bins)
+vfov_bins = np.linspace(0.2617, 2.1, 255)
+vfov_bins_centers = _centers(vfov_bins)
+roll_new_bins = np.linspace(-0.6, 0.6, 255)
+roll_new_bins_centers = _centers(roll_new_bins)
+
+
+def _argmax_idx(bins) -> np.ndarray:
+    """np.argmax over the last axis, reduced on the GPU (first maximum; index work, bit-exact)."""
+    if not isinstance(bins, torch.Tensor):
+        bins = torch.as_tensor(np.asarray(bins))
+    if not torch.cuda.is_available():
+        raise RuntimeError('spec_amd.cam_utils needs an AMD GPU (no CPU path)')
+    dev = bins.device if bins.device.type == 'cuda' else torch.device('cuda')
+    if bins.dtype == torch.float64:
+        # float64 input: order-preserving only if no two distinct doubles collapse to one float; the reference's
+        # logits are network outputs (fp32), so refuse instead of silently changing ties
+        if not torch.equal(bins.float().double(), bins):
+            raise NotImplementedError('bins2*: float64 logits that are not exactly representable in fp32')
+    idx, _ = _engine(dev).camcalib_bins(bins.to(dev), argmax=True, soft=False)
+    return idx.cpu().numpy().astype(np.int64)
+
+
+def bins2horizon(bins):
+    return horizon_bins_centers[_argmax_idx(bins)]
+
+
+def bins2pitch(bins):
+    return pitch_bins_centers[_argmax_idx(bins)]
+
+
+def bins2roll(bins):
+    return roll_bins_centers[_argmax_idx(bins)]
+
+
+def bins2vfov(bins):
+    return vfov_bins_centers[_argmax_idx(bins)]
+
+
+def vfov2soft_idx(angle):
+    return angle_to_soft_idx(angle, min=np.min(vfov_bins), max=np.max(vfov_bins))
+
+
+def pitch2soft_idx(angle):
+    return angle_to_soft_idx(angle, min=np.min(pitch_bins), max=np.max(pitch_bins))
+
+
+def roll2soft_idx(angle):
+    return angle_to_soft_idx(angle, min=-0.6, max=0.6)
+
+
 def soft_idx_to_angle(soft_idx, min, max):
     return (max - min) * ((soft_idx + 1) / 2) + min
 
@@ -31,26 +113,48 @@ def angle_to_soft_idx(angle, min, max):
 
 
 @torch.no_grad()
-def decode_camera(pred_vfov, pred_pitch, pred_roll, img_h=None, img_w=None):
-    """Logits (B,256)x3 [+ full-image sizes] -> dict(vfov, pitch, roll, f_pix, cam_rotmat,
-    cam_intrinsics) as device tensors (one kernel launch)."""
-    if pred_vfov.device.type != 'cuda':
-        raise RuntimeError('decode_camera needs device tensors (no CPU path in spec_amd)')
-    return _engine(pred_vfov.device).camcalib_decode(pred_vfov, pred_pitch, pred_roll, img_h, img_w)
+def get_softargmax(pred):
+    """(N, 256) logits -> (N,) soft-arg-max in [-1, 1] (camcalib/cam_utils.py:110-118), device tensor."""
+    dev = pred.device if pred.device.type == 'cuda' else torch.device('cuda')
+    _, soft = _engine(dev).camcalib_bins(pred.to(dev), argmax=False, soft=True)
+    return soft.reshape(-1)
 
 
 @torch.no_grad()
-def convert_preds_to_angles(pred_vfov, pred_pitch, pred_roll, loss_type='softargmax_l2',
-                            return_type='torch', legacy=False):
-    """Reference signature (camcalib/cam_utils.py:121).  Only the soft-argmax, non-legacy branch
-    used by the released model (scripts/camcalib_demo.py:74-78,227) is built."""
-    if loss_type not in ('softargmax_l2', 'softargmax_biased_l2') or legacy:
-        raise NotImplementedError('only the soft-argmax (non-legacy) decode of the released CamCalib model')
-    d = decode_camera(pred_vfov, pred_pitch, pred_roll)
-    out = (d['vfov'], d['pitch'], d['roll'])
-    if return_type == 'np':
-        return tuple(t.cpu().numpy() for t in out)
-    return out
+def decode_camera(pred_vfov, pred_pitch, pred_roll, img_h=None, img_w=None, angles_out=None):
+    """Logits (B,256)x3 [+ full-image sizes] -> dict(vfov, pitch, roll, f_pix, cam_rotmat,
+    cam_intrinsics) as device tensors (one kernel launch).  ``angles_out``: optional (vfov, pitch, roll)
+    destination tensors with a common stride (columns of a packed record)."""
+    if pred_vfov.device.type != 'cuda':
+        raise RuntimeError('decode_camera needs device tensors (no CPU path in spec_amd)')
+    return _engine(pred_vfov.device).camcalib_decode(pred_vfov, pred_pitch, pred_roll, img_h, img_w, angles_out)
+
+
+@torch.no_grad()
+def convert_preds_to_angles(pred_vfov, pred_pitch, pred_roll, loss_type='kl', return_type='torch', legacy=False):
+    """Reference signature, defaults and return types (camcalib/cam_utils.py:121-145): 'kl' / 'ce' -> arg-max bin
+    centres (float64 NumPy, converted with torch.from_numpy for return_type='torch'); 'softargmax_l2' /
+    'softargmax_biased_l2' -> soft-arg-max angles as fp32 tensors on the logits' device (``legacy``: roll through
+    the arg-max table)."""
+    if loss_type in ('kl', 'ce'):
+        pred_vfov, pred_pitch, pred_roll = bins2vfov(pred_vfov), bins2pitch(pred_pitch), bins2roll(pred_roll)
+    elif loss_type in ('softargmax_l2', 'softargmax_biased_l2'):
+        if pred_vfov.device.type != 'cuda':
+            pred_vfov, pred_pitch, pred_roll = pred_vfov.cuda(), pred_pitch.cuda(), pred_roll.cuda()
+        roll_logits = pred_roll
+        d = decode_camera(pred_vfov, pred_pitch, pred_roll)
+        pred_vfov, pred_pitch, pred_roll = d['vfov'], d['pitch'], d['roll']
+        if legacy:
+            pred_roll = bins2roll(roll_logits)
+
+    if return_type == 'np' and isinstance(pred_vfov, torch.Tensor):
+        return (pred_vfov.cpu().numpy(), pred_pitch.cpu().numpy(),
+                pred_roll.cpu().numpy() if isinstance(pred_roll, torch.Tensor) else pred_roll)
+
+    if return_type == 'torch' and isinstance(pred_vfov, np.ndarray):
+        return torch.from_numpy(pred_vfov), torch.from_numpy(pred_pitch), torch.from_numpy(pred_roll)
+
+    return pred_vfov, pred_pitch, pred_roll
 
 
 @torch.no_grad()

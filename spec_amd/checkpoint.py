@@ -27,9 +27,24 @@ def strip_lightning_prefix(state_dict, prefix='model.'):
 
 def load_pretrained_model(model, state_dict, strict=False, overwrite_shape_mismatch=True,
                           remove_lightning=False):
+    """Deliberate deviations from the PARE function this restates (documented, not silent):
+
+    * only a LEADING ``model.`` is stripped (upstream uses ``str.replace('model.', '')``, which would also mangle a
+      key that merely contains ``model.`` further in);
+    * the regressor-input patch applies to any key ending in ``head.fc1.weight`` (upstream: the literal
+      ``model.head.fc1.weight``), so it also works after the prefix was stripped or for a bare head module;
+    * besides upstream's growth case (2205 -> 2212 columns; like upstream, the seven new camera-feature columns are
+      filled with COPIES of the last seven source columns - a placeholder initialisation, not a meaningful one), the
+      inverse shrink case (2212 -> 2205: drop the camera-feature columns) is handled too;
+    * ``strict=True`` keeps the reference's failure mode: after patching, missing / unexpected keys or a shape
+      mismatch that cannot be patched raise ``RuntimeError`` (CamCalib loads strictly, scripts/camcalib_demo.py:81).
+    """
     if remove_lightning:
         state_dict = strip_lightning_prefix(state_dict)
     own = model.state_dict()
+    # a one-element tensor saved as shape (1,) for a 0-d buffer (num_batches_tracked) is the same value: reshape it
+    state_dict = OrderedDict((k, v.reshape(own[k].shape) if k in own and hasattr(v, 'shape') and v.numel() == 1
+                              and own[k].numel() == 1 else v) for k, v in state_dict.items())
     mismatched = [k for k, v in state_dict.items()
                   if k in own and hasattr(v, 'shape') and tuple(own[k].shape) != tuple(v.shape)]
     if not mismatched:
@@ -38,6 +53,7 @@ def load_pretrained_model(model, state_dict, strict=False, overwrite_shape_misma
     if not overwrite_shape_mismatch:
         raise RuntimeError(f'shape mismatch for {mismatched} and overwrite_shape_mismatch=False')
     patched = OrderedDict(state_dict)
+    dropped = []
     for k in mismatched:
         src, dst = state_dict[k], own[k]
         if k.endswith('head.fc1.weight') and src.dim() == 2 and src.shape[0] == dst.shape[0]:
@@ -49,6 +65,12 @@ def load_pretrained_model(model, state_dict, strict=False, overwrite_shape_misma
                 patched[k] = src[:, :-7]
                 continue
         del patched[k]
+        dropped.append(k)
+    if strict:
+        if dropped:
+            raise RuntimeError(f'strict load: shape mismatch that cannot be patched for {dropped}')
+        model.load_state_dict(patched, strict=True)        # raises on missing / unexpected keys
+        return model
     model.load_state_dict(patched, strict=False)
     return model
 
@@ -71,12 +93,23 @@ class _StubDict(dict):
             self.__dict__.update(state)
 
 
+_ALLOWED_ROOTS = ('torch', 'collections', 'numpy', 'builtins', '_codecs', 'copyreg')
+_BLOCKED_BUILTINS = {'eval', 'exec', 'compile', 'open', '__import__', 'getattr', 'setattr', 'delattr', 'input', 'breakpoint'}
+
+
 class _TolerantUnpickler(pickle.Unpickler):
+    """Fallback unpickler for Lightning checkpoints: only torch / collections / numpy (and harmless builtins) are
+    resolved for real; every other global a checkpoint names (yacs CfgNode, pytorch_lightning containers, argparse
+    namespaces, arbitrary user classes) becomes an inert stub, so nothing outside that allow-list can execute."""
+
     def find_class(self, module, name):
-        try:
-            return super().find_class(module, name)
-        except (ImportError, AttributeError, ModuleNotFoundError):
-            return _StubDict if 'CfgNode' in name or 'Dict' in name else _AnyStub
+        root = module.split('.')[0]
+        if root in _ALLOWED_ROOTS and not (root == 'builtins' and name in _BLOCKED_BUILTINS):
+            try:
+                return super().find_class(module, name)
+            except (ImportError, AttributeError, ModuleNotFoundError):
+                pass
+        return _StubDict if 'CfgNode' in name or 'Dict' in name else _AnyStub
 
 
 _tolerant_pickle = types.SimpleNamespace(
@@ -85,8 +118,10 @@ _tolerant_pickle = types.SimpleNamespace(
 
 
 def read_checkpoint(path, map_location='cpu'):
-    """torch.load for trusted reference checkpoints, tolerant of missing third-party classes."""
+    """torch.load of a reference checkpoint.  First ``weights_only=True``; ONLY when that fails because the pickle
+    names a class outside torch's allow-list (``pickle.UnpicklingError``) it is re-read with the restricted stubbing
+    unpickler above.  I/O errors, truncated or corrupt files propagate instead of triggering the fallback."""
     try:
         return torch.load(path, map_location=map_location, weights_only=True)
-    except Exception:
+    except pickle.UnpicklingError:
         return torch.load(path, map_location=map_location, weights_only=False, pickle_module=_tolerant_pickle)

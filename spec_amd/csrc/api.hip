@@ -7,9 +7,6 @@
 
 #include "specmi_internal.h"
 
-namespace specmi {
-void conv_igemm_force_variant(int v);
-}
 using namespace specmi;
 
 // ------------------------------------------------------------------------------------------
@@ -62,6 +59,9 @@ struct specmi_handle {
     FcW fc_cam[3][3];          // CamCalib: vfov, pitch, roll x up to 3 stacked Linear layers (camcalib/model.py:59-70: no activation between them)
     int fc_layers = 1, feat_ch = 2048;
     FcW fc1, fc2, dec;         // HMR head (dec = decpose|decshape|deccam)
+    FcW head_c;                // the 3 IEF iterations composed into ONE affine map [xf | cam feats] -> 157 (commit_head_collapsed)
+    bool has_head_c = false;
+    int xc_ld = 2240;          // row stride of the IEF state [xf (feat_ch) | pose6d | shape | cam | rot6d(R) | vfov | 0-pad]
     float *init_pose = nullptr, *init_shape = nullptr, *init_cam = nullptr;
     SmplDev smpl;
     std::vector<void*> param_allocs;
@@ -279,6 +279,93 @@ static int commit_fc(specmi_handle* h, const std::vector<std::string>& names, co
     return SPECMI_OK;
 }
 
+// HMRHead in eval mode is an affine map: there is no activation between fc1, fc2 and the decoders and dropout is
+// the identity (pare HMRHead = SPIN's regressor, call site spec/models/hmr.py:96-98).  With the state s = [pose6d |
+// shape | cam] (157), features xf (F) and camera features c (7, use_cam_feats) one iteration is
+//     s' = s + Wd (W2 (W1 [xf | s | c] + b1) + b2) + bd = (I + Q) s + P xf + T c + r,
+// [P | Q | T] = Wd W2 W1, r = Wd (W2 b1 + b2) + bd, so three iterations from s0 = init_{pose,shape,cam} give
+//     s3 = G (P xf + T c) + (E^3 s0 + G r),   E = I + Q,  G = I + E + E^2.
+// The composition runs in float64 and is rounded once; the forward is then ONE (F+164 -> 157) GEMM instead of 9 GEMMs.
+static int commit_head_collapsed(specmi_handle* h, int F, int ucf) {
+    const int nin = F + 157 + (ucf ? 7 : 0), NS = 157, NH = 1024;
+    const HostTensor *w1, *b1, *w2, *b2, *wp, *bp, *wsh, *bsh, *wc, *bc, *ip, *is, *ic;
+    int rc;
+    if ((rc = need(h, "head.fc1.weight", {NH, nin}, false, &w1)) || (rc = need(h, "head.fc1.bias", {NH}, false, &b1)) ||
+        (rc = need(h, "head.fc2.weight", {NH, NH}, false, &w2)) || (rc = need(h, "head.fc2.bias", {NH}, false, &b2)) ||
+        (rc = need(h, "head.decpose.weight", {144, NH}, false, &wp)) || (rc = need(h, "head.decpose.bias", {144}, false, &bp)) ||
+        (rc = need(h, "head.decshape.weight", {10, NH}, false, &wsh)) || (rc = need(h, "head.decshape.bias", {10}, false, &bsh)) ||
+        (rc = need(h, "head.deccam.weight", {3, NH}, false, &wc)) || (rc = need(h, "head.deccam.bias", {3}, false, &bc)) ||
+        (rc = need(h, "head.init_pose", {144}, false, &ip)) || (rc = need(h, "head.init_shape", {10}, false, &is)) ||
+        (rc = need(h, "head.init_cam", {3}, false, &ic)))
+        return rc;
+    std::vector<double> Wd((size_t)NS * NH), bd(NS), s0(NS);
+    for (int i = 0; i < NS; ++i) {
+        const float* src = i < 144 ? wp->f.data() + (size_t)i * NH : i < 154 ? wsh->f.data() + (size_t)(i - 144) * NH
+                                                                             : wc->f.data() + (size_t)(i - 154) * NH;
+        for (int k = 0; k < NH; ++k) Wd[(size_t)i * NH + k] = src[k];
+        bd[i] = i < 144 ? bp->f[i] : i < 154 ? bsh->f[i - 144] : bc->f[i - 154];
+        s0[i] = i < 144 ? ip->f[i] : i < 154 ? is->f[i - 144] : ic->f[i - 154];
+    }
+    // M = Wd W2 (157 x 1024), PQT = M W1 (157 x nin), r = M b1 + Wd b2 + bd
+    std::vector<double> M((size_t)NS * NH, 0.0), PQT((size_t)NS * nin, 0.0), r(NS);
+    for (int i = 0; i < NS; ++i) {
+        double* mi = M.data() + (size_t)i * NH;
+        for (int k = 0; k < NH; ++k) {
+            const double a = Wd[(size_t)i * NH + k];
+            const float* w2k = w2->f.data() + (size_t)k * NH;
+            for (int j = 0; j < NH; ++j) mi[j] += a * (double)w2k[j];
+        }
+        double* pi = PQT.data() + (size_t)i * nin;
+        double ri = bd[i];
+        for (int k = 0; k < NH; ++k) {
+            const double a = mi[k];
+            const float* w1k = w1->f.data() + (size_t)k * nin;
+            for (int j = 0; j < nin; ++j) pi[j] += a * (double)w1k[j];
+            ri += a * (double)b1->f[k] + Wd[(size_t)i * NH + k] * (double)b2->f[k];
+        }
+        r[i] = ri;
+    }
+    // E = I + Q, E2 = E E, G = I + E + E2, E3 = E2 E
+    auto matmul = [&](const std::vector<double>& A, const std::vector<double>& Bm, std::vector<double>& C) {
+        C.assign((size_t)NS * NS, 0.0);
+        for (int i = 0; i < NS; ++i)
+            for (int k = 0; k < NS; ++k) {
+                const double a = A[(size_t)i * NS + k];
+                for (int j = 0; j < NS; ++j) C[(size_t)i * NS + j] += a * Bm[(size_t)k * NS + j];
+            }
+    };
+    std::vector<double> E((size_t)NS * NS), E2, E3, G((size_t)NS * NS);
+    for (int i = 0; i < NS; ++i)
+        for (int j = 0; j < NS; ++j) E[(size_t)i * NS + j] = PQT[(size_t)i * nin + F + j] + (i == j ? 1.0 : 0.0);
+    matmul(E, E, E2);
+    matmul(E2, E, E3);
+    for (int i = 0; i < NS; ++i)
+        for (int j = 0; j < NS; ++j) G[(size_t)i * NS + j] = (i == j ? 1.0 : 0.0) + E[(size_t)i * NS + j] + E2[(size_t)i * NS + j];
+    // composed weight over the xc row layout [xf | state (zero columns) | c], bias = E3 s0 + G r
+    FcW& fc = h->head_c;
+    fc.nin = nin; fc.nout = NS; fc.Kp = round_up(nin, 32); fc.Npad = round_up(NS, 64);
+    std::vector<float> wcat((size_t)NS * nin, 0.f), bias(fc.Npad, 0.f), ones(fc.Npad, 1.f), packed;
+    for (int i = 0; i < NS; ++i) {
+        double bi = 0.0;
+        for (int k = 0; k < NS; ++k) bi += E3[(size_t)i * NS + k] * s0[k] + G[(size_t)i * NS + k] * r[k];
+        bias[i] = (float)bi;
+        std::vector<double> row(nin, 0.0);
+        for (int k = 0; k < NS; ++k) {
+            const double g = G[(size_t)i * NS + k];
+            const double* pk = PQT.data() + (size_t)k * nin;
+            for (int j = 0; j < F; ++j) row[j] += g * pk[j];
+            for (int j = F + NS; j < nin; ++j) row[j] += g * pk[j];
+        }
+        for (int j = 0; j < nin; ++j) wcat[(size_t)i * nin + j] = (float)row[j];
+    }
+    pack_gemm_weights(wcat.data(), NS, nin, 1, 1, fc.Kp, fc.Npad, packed);
+    if ((rc = dev_upload(h, packed.data(), packed.size() * 4, (void**)&fc.w, h->param_allocs))) return rc;
+    if ((rc = dev_upload(h, ones.data(), ones.size() * 4, (void**)&fc.scale, h->param_allocs))) return rc;
+    if ((rc = dev_upload(h, bias.data(), bias.size() * 4, (void**)&fc.shift, h->param_allocs))) return rc;
+    h->has_head_c = true;
+    return SPECMI_OK;
+}
+
 // torchvision ResNet-50 (Bottleneck [3,4,6,3], v1.5: stride on the 3x3) or ResNet-34 (BasicBlock [3,4,6,3]) trunk
 static void build_resnet(specmi_handle* h, int depth) {
     h->stem = ConvW();
@@ -408,7 +495,7 @@ static int ensure_ws(specmi_handle* h, int B, int H, int W) {
     h->act_elems = elems;
     const int Bp = round_up(Bw, 8);
     const int V = h->smpl.V > 0 ? h->smpl.V : 1;
-    if ((rc = dev_alloc(h, (size_t)Bp * XC_LD * 4, (void**)&h->xc, h->ws_allocs))) return rc;
+    if ((rc = dev_alloc(h, (size_t)Bp * h->xc_ld * 4, (void**)&h->xc, h->ws_allocs))) return rc;
     if ((rc = dev_alloc(h, (size_t)Bp * 1024 * 4, (void**)&h->h1, h->ws_allocs))) return rc;
     if ((rc = dev_alloc(h, (size_t)Bp * 1024 * 4, (void**)&h->h2, h->ws_allocs))) return rc;
     if ((rc = dev_alloc(h, (size_t)Bp * 2048 * 4, (void**)&h->xf, h->ws_allocs))) return rc;
@@ -440,6 +527,7 @@ static int run_fc(specmi_handle* h, const FcW& fc, const float* x, int ldx, int 
     a.B = B; a.H = 1; a.W = 1; a.Cin = fc.Kp; a.ldx = ldx;
     a.OH = 1; a.OW = 1; a.Cout = fc.nout; a.Npad = fc.Npad; a.ldo = ldo;
     a.KH = 1; a.KW = 1; a.stride = 1; a.pad = 0; a.relu = 0;
+    a.force_variant = opt_i(h, "force_conv_variant", 0);
     LaunchCtx ctx{s, &h->prof, label};
     const int S = opt_i(h, "fc_splitk", 1) ? conv_igemm_splitk_plan(a) : 1;
     if (S > 1 && h->splitk_ws && h->zeros && (size_t)S * B * fc.Npad <= h->splitk_floats && fc.Npad <= 4096) {
@@ -491,6 +579,8 @@ static int exec_op(specmi_handle* h, const TrunkOp& op, const float* images, flo
     a.B = nb; a.H = op.H; a.W = op.W; a.Cin = c.cin; a.ldx = c.cin;
     a.OH = op.OH; a.OW = op.OW; a.Cout = c.cout; a.Npad = c.Npad; a.ldo = c.cout;
     a.KH = c.k; a.KW = c.k; a.stride = c.stride; a.pad = c.pad; a.relu = op.relu;
+    a.force_variant = opt_i(h, "force_conv_variant", 0);
+    a.wino_variant = opt_i(h, "force_wino_variant", 0);
     if (op.fused) {
         const Bneck& bk = *op.fused;
         a.w = bk.f_w; a.scale = bk.f_scale; a.shift = bk.f_shift; a.Npad = bk.f_Npad; a.res = nullptr;
@@ -591,32 +681,55 @@ static int run_trunk(specmi_handle* h, const float* images, int B, int H, int W,
     return SPECMI_OK;
 }
 
+// per-image strides of the HMR outputs: dense, or all equal to option "output_ld" (the outputs are then columns of
+// one caller-owned (B, output_ld) record, e.g. the packed all-gather record of SURVEY.md 8e)
+struct OutLd {
+    long pose = 216, shape = 10, cam = 3, p6d = 144, verts = 0, j3d = 147, j2d = 98, camt = 3;
+};
+static OutLd out_ld(specmi_handle* h) {
+    OutLd o;
+    const long ld = opt_i(h, "output_ld", 0);
+    if (ld > 0) o.pose = o.shape = o.cam = o.p6d = o.verts = o.j3d = o.j2d = o.camt = ld;
+    return o;
+}
+
 static int run_head(specmi_handle* h, const float* feat, int B, int fh, int fw, const float* R, const float* K,
                     const float* img_h, float* pred_pose, float* pred_shape, float* pred_cam, float* pred_pose_6d,
-                    hipStream_t s) {
+                    const OutLd& old, hipStream_t s) {
     int rc;
     const int ucf = opt_i(h, "use_cam_feats", 0);
+    const int F = h->feat_ch, LD = h->xc_ld;
     if (ucf && (!R || !K || !img_h))
         return fail(h, SPECMI_ERR_ARG, "use_cam_feats needs cam_rotmat, cam_intrinsics and img_h");
     {
         LaunchCtx ctx{s, &h->prof, "head.avgpool"};
-        LAUNCHCHK(h, launch_avgpool(feat, h->xc, B, fh * fw, 2048, XC_LD, ctx), "avgpool");
+        LAUNCHCHK(h, launch_avgpool(feat, h->xc, B, fh * fw, F, LD, ctx), "avgpool");
     }
     {
         LaunchCtx ctx{s, &h->prof, "head.init"};
-        LAUNCHCHK(h, launch_head_init(h->xc, h->init_pose, h->init_shape, h->init_cam, R, K, img_h, ucf, B, ctx),
+        LAUNCHCHK(h, launch_head_init(h->xc, h->init_pose, h->init_shape, h->init_cam, R, K, img_h, ucf, B, F, LD, ctx),
                   "head_init");
     }
-    for (int it = 0; it < 3; ++it) {
-        if ((rc = run_fc(h, h->fc1, h->xc, XC_LD, B, nullptr, h->h1, 1024, s, "head.fc1"))) return rc;
-        if ((rc = run_fc(h, h->fc2, h->h1, 1024, B, nullptr, h->h2, 1024, s, "head.fc2"))) return rc;
-        float* state = h->xc + XC_STATE_OFF;  // dec* + running estimate, in place
-        if ((rc = run_fc(h, h->dec, h->h2, 1024, B, state, state, XC_LD, s, "head.dec"))) return rc;
+    const float* state = h->xc + F;
+    long ld_state = LD;
+    if (h->has_head_c && opt_i(h, "head_collapse", 1)) {
+        // the three IEF iterations as one composed affine map (commit_head_collapsed)
+        if ((rc = run_fc(h, h->head_c, h->xc, LD, B, nullptr, h->h1, 1024, s, "head.ief_collapsed"))) return rc;
+        state = h->h1;
+        ld_state = 1024;
+    } else {
+        for (int it = 0; it < 3; ++it) {
+            if ((rc = run_fc(h, h->fc1, h->xc, LD, B, nullptr, h->h1, 1024, s, "head.fc1"))) return rc;
+            if ((rc = run_fc(h, h->fc2, h->h1, 1024, B, nullptr, h->h2, 1024, s, "head.fc2"))) return rc;
+            float* st = h->xc + F;  // dec* + running estimate, in place
+            if ((rc = run_fc(h, h->dec, h->h2, 1024, B, st, st, LD, s, "head.dec"))) return rc;
+        }
     }
     {
         LaunchCtx ctx{s, &h->prof, "head.final"};
-        LAUNCHCHK(h, launch_head_final(h->xc, pred_pose, pred_shape, pred_cam, pred_pose_6d, h->rot_ws, h->betas_ws,
-                                       h->cam_ws, B, ctx),
+        const long ld[4] = {old.pose, old.shape, old.cam, old.p6d};
+        LAUNCHCHK(h, launch_head_final(state, ld_state, pred_pose, pred_shape, pred_cam, pred_pose_6d, ld, h->rot_ws,
+                                       h->betas_ws, h->cam_ws, B, ctx),
                   "head_final");
     }
     return SPECMI_OK;
@@ -625,7 +738,7 @@ static int run_head(specmi_handle* h, const float* feat, int B, int fh, int fw, 
 static int run_smpl(specmi_handle* h, const float* rotmat, const float* betas, const float* cam, int B, const float* R,
                     const float* K, const float* bbox_scale, const float* bbox_center, const float* img_w,
                     const float* img_h, float* vertices, float* joints3d, float* joints2d, float* cam_t,
-                    hipStream_t s) {
+                    const OutLd& old, hipStream_t s) {
     const int use_cam = opt_i(h, "use_cam", 0);
     if (use_cam && (!R || !K || !bbox_scale || !bbox_center || !img_w || !img_h))
         return fail(h, SPECMI_ERR_ARG, "use_cam needs cam_rotmat, cam_intrinsics, bbox_scale, bbox_center, img_w, img_h");
@@ -633,7 +746,9 @@ static int run_smpl(specmi_handle* h, const float* rotmat, const float* betas, c
     a.rotmat = rotmat; a.betas = betas; a.cam = cam; a.cam_rotmat = R; a.cam_intrinsics = K;
     a.bbox_scale = bbox_scale; a.bbox_center = bbox_center; a.img_w = img_w; a.img_h = img_h;
     a.vertices = vertices ? vertices : h->verts_ws;
+    a.ld_verts = vertices ? old.verts : 0;
     a.joints3d = joints3d; a.joints2d = joints2d; a.cam_t = cam_t;
+    a.ld_j3d = old.j3d; a.ld_j2d = old.j2d; a.ld_camt = old.camt;
     a.pose_feat = h->pf_ws; a.A = h->A_ws; a.posed_j = h->pj_ws;
     a.B = B;
     a.mode = use_cam ? 0 : 1;
@@ -650,11 +765,11 @@ static int run_smpl(specmi_handle* h, const float* rotmat, const float* betas, c
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
-const char* specmi_version(void) { return "specmi 0.1 (gfx950, fp32 MFMA)"; }
+const char* specmi_version(void) { return "specmi 0.2 (gfx950, fp32 MFMA)"; }
 
 int specmi_create(specmi_handle** out, int device_id, int model_kind) {
     if (!out) return fail(nullptr, SPECMI_ERR_ARG, "out is NULL");
-    if (model_kind != SPECMI_MODEL_CAMCALIB && model_kind != SPECMI_MODEL_HMR)
+    if (model_kind != SPECMI_MODEL_CAMCALIB && model_kind != SPECMI_MODEL_HMR && model_kind != SPECMI_MODEL_SMPL)
         return fail(nullptr, SPECMI_ERR_ARG, "unknown model kind %d", model_kind);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -685,8 +800,6 @@ const char* specmi_last_error(const specmi_handle* h) { return h ? h->err.c_str(
 
 int specmi_set_option_i32(specmi_handle* h, const char* name, int value) {
     if (!h || !name) return fail(h, SPECMI_ERR_ARG, "null argument");
-    if (!std::strcmp(name, "force_conv_variant")) { conv_igemm_force_variant(value); return SPECMI_OK; }
-    if (!std::strcmp(name, "force_wino_variant")) { conv_wino_force_variant(value); return SPECMI_OK; }
     h->opt_i[name] = value;
     return SPECMI_OK;
 }
@@ -727,6 +840,13 @@ int specmi_commit(specmi_handle* h) {
     free_pool(h->param_allocs);
     h->committed = false;
     int rc;
+    if (h->kind == SPECMI_MODEL_SMPL) {   // the body model alone (evaluation: ground-truth meshes / joints)
+        if ((rc = commit_smpl(h))) return rc;
+        free_pool(h->ws_allocs);
+        h->act_elems = 0; h->ws_B = 0;
+        h->committed = true;
+        return SPECMI_OK;
+    }
     const std::string bp = "backbone.";
     const int depth = opt_i(h, "backbone", 50);
     if (depth != 50 && depth != 34) return fail(h, SPECMI_ERR_ARG, "backbone %d: resnet50 and resnet34 are built", depth);
@@ -761,7 +881,9 @@ int specmi_commit(specmi_handle* h) {
             }
     } else {
         const int ucf = opt_i(h, "use_cam_feats", 0);
-        const int nin = 2048 + 144 + 13 + (ucf ? 7 : 0);
+        const int nin = h->feat_ch + 144 + 13 + (ucf ? 7 : 0);
+        h->xc_ld = round_up(h->feat_ch + 164, 32);
+        h->has_head_c = false;
         if ((rc = commit_fc(h, {"head.fc1"}, {1024}, nin, h->fc1))) return rc;
         if ((rc = commit_fc(h, {"head.fc2"}, {1024}, 1024, h->fc2))) return rc;
         if ((rc = commit_fc(h, {"head.decpose", "head.decshape", "head.deccam"}, {144, 10, 3}, 1024, h->dec))) return rc;
@@ -772,6 +894,7 @@ int specmi_commit(specmi_handle* h) {
         if ((rc = dev_upload(h, ip->f.data(), 144 * 4, (void**)&h->init_pose, h->param_allocs))) return rc;
         if ((rc = dev_upload(h, is->f.data(), 10 * 4, (void**)&h->init_shape, h->param_allocs))) return rc;
         if ((rc = dev_upload(h, ic->f.data(), 3 * 4, (void**)&h->init_cam, h->param_allocs))) return rc;
+        if (opt_i(h, "head_collapse", 1) && (rc = commit_head_collapsed(h, h->feat_ch, ucf))) return rc;
         if ((rc = commit_smpl(h))) return rc;
         // the SMPL vertex count sizes the workspace
         free_pool(h->ws_allocs);
@@ -833,7 +956,17 @@ int specmi_camcalib_decode(specmi_handle* h, const float* lv, const float* lp, c
     if ((f_pix || K) && !img_h) return fail(h, SPECMI_ERR_ARG, "f_pix / K need img_h");
     if (K && !img_w) return fail(h, SPECMI_ERR_ARG, "K needs img_w");
     LaunchCtx ctx{(hipStream_t)stream, &h->prof, "camcalib.decode"};
-    LAUNCHCHK(h, launch_camcalib_decode(lv, lp, lr, B, nbins, img_h, img_w, vfov, pitch, roll, f_pix, R, K, ctx), "decode");
+    LAUNCHCHK(h, launch_camcalib_decode(lv, lp, lr, B, nbins, img_h, img_w, vfov, pitch, roll, f_pix, R, K,
+                                        (long)(opt_i(h, "angle_ld", 0) > 0 ? opt_i(h, "angle_ld", 0) : 1), ctx), "decode");
+    return SPECMI_OK;
+}
+
+int specmi_camcalib_bins(specmi_handle* h, const float* logits, int rows, int nbins, int32_t* argmax_idx,
+                         float* soft_idx, void* stream) {
+    ENTER(h);
+    if (!logits || rows <= 0 || nbins < 2 || (!argmax_idx && !soft_idx)) return fail(h, SPECMI_ERR_ARG, "bad argument");
+    LaunchCtx ctx{(hipStream_t)stream, &h->prof, "camcalib.bins"};
+    LAUNCHCHK(h, launch_bins_reduce(logits, rows, nbins, argmax_idx, soft_idx, ctx), "bins_reduce");
     return SPECMI_OK;
 }
 
@@ -854,7 +987,8 @@ int specmi_hmr_head_forward(specmi_handle* h, const float* feat, int B, int fh, 
     if (!feat || B <= 0 || fh <= 0 || fw <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
     int rc;
     if ((rc = ensure_ws(h, B, 32, 32))) return rc;
-    return run_head(h, feat, B, fh, fw, R, K, img_h, pred_pose, pred_shape, pred_cam, pred_pose_6d, (hipStream_t)stream);
+    return run_head(h, feat, B, fh, fw, R, K, img_h, pred_pose, pred_shape, pred_cam, pred_pose_6d, out_ld(h),
+                    (hipStream_t)stream);
 }
 
 int specmi_smpl_forward(specmi_handle* h, const float* rotmat, const float* betas, const float* cam, int B,
@@ -862,12 +996,37 @@ int specmi_smpl_forward(specmi_handle* h, const float* rotmat, const float* beta
                         const float* img_w, const float* img_h, float* vertices, float* joints3d, float* joints2d,
                         float* cam_t, void* stream) {
     ENTER(h); NEED_COMMIT(h);
-    if (h->kind != SPECMI_MODEL_HMR) return fail(h, SPECMI_ERR_STATE, "handle is not an HMR model");
+    if (h->kind != SPECMI_MODEL_HMR && h->kind != SPECMI_MODEL_SMPL) return fail(h, SPECMI_ERR_STATE, "handle has no body model");
     if (!rotmat || !betas || !cam || B <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
     int rc;
     if ((rc = ensure_ws(h, B, 32, 32))) return rc;
     return run_smpl(h, rotmat, betas, cam, B, R, K, bbox_scale, bbox_center, img_w, img_h, vertices, joints3d, joints2d,
-                    cam_t, (hipStream_t)stream);
+                    cam_t, out_ld(h), (hipStream_t)stream);
+}
+
+int specmi_smpl_native(specmi_handle* h, const float* pose, int pose_is_axis_angle, const float* betas, int B,
+                       float* vertices, float* joints24, void* stream) {
+    ENTER(h); NEED_COMMIT(h);
+    if (h->kind != SPECMI_MODEL_HMR && h->kind != SPECMI_MODEL_SMPL) return fail(h, SPECMI_ERR_STATE, "handle has no body model");
+    if (!pose || !betas || B <= 0 || (!vertices && !joints24)) return fail(h, SPECMI_ERR_ARG, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = ensure_ws(h, B, 32, 32))) return rc;
+    const float* rot = pose;
+    if (pose_is_axis_angle) {
+        LaunchCtx ctx{s, &h->prof, "smpl.rodrigues"};
+        LAUNCHCHK(h, launch_rodrigues(pose, h->rot_ws, B * 24, ctx), "rodrigues");
+        rot = h->rot_ws;
+    }
+    SmplArgs a;
+    a.rotmat = rot; a.betas = betas; a.cam = nullptr; a.cam_rotmat = nullptr; a.cam_intrinsics = nullptr;
+    a.bbox_scale = a.bbox_center = a.img_w = a.img_h = nullptr;
+    a.vertices = vertices; a.joints3d = a.joints2d = a.cam_t = nullptr;
+    a.pose_feat = h->pf_ws; a.A = h->A_ws; a.posed_j = h->pj_ws;
+    a.B = B; a.mode = 1; a.focal_length = 0.f; a.img_res = 0.f; a.normalize_joints2d = 0;
+    LaunchCtx ctx{s, &h->prof, "smpl.native"};
+    LAUNCHCHK(h, launch_smpl_native(h->smpl, a, joints24, ctx), "smpl_native");
+    return SPECMI_OK;
 }
 
 int specmi_hmr_forward(specmi_handle* h, const float* images, int B, int H, int W, const float* R, const float* K,
@@ -879,10 +1038,27 @@ int specmi_hmr_forward(specmi_handle* h, const float* images, int B, int H, int 
     hipStream_t s = (hipStream_t)stream;
     const float* f; int fh, fw, rc;
     if ((rc = run_trunk(h, images, B, H, W, nullptr, &f, &fh, &fw, s))) return rc;
-    if ((rc = run_head(h, f, B, fh, fw, R, K, img_h, out->pred_pose, out->pred_shape, out->pred_cam, out->pred_pose_6d, s)))
+    const OutLd old = out_ld(h);
+    if ((rc = run_head(h, f, B, fh, fw, R, K, img_h, out->pred_pose, out->pred_shape, out->pred_cam, out->pred_pose_6d, old, s)))
         return rc;
     return run_smpl(h, h->rot_ws, h->betas_ws, h->cam_ws, B, R, K, bbox_scale, bbox_center, img_w, img_h,
-                    out->smpl_vertices, out->smpl_joints3d, out->smpl_joints2d, out->pred_cam_t, s);
+                    out->smpl_vertices, out->smpl_joints3d, out->smpl_joints2d, out->pred_cam_t, old, s);
+}
+
+int specmi_hmr_regress(specmi_handle* h, const float* feat, int B, int fh, int fw, const float* R, const float* K,
+                       const float* bbox_scale, const float* bbox_center, const float* img_w, const float* img_h,
+                       const specmi_hmr_outputs* out, void* stream) {
+    ENTER(h); NEED_COMMIT(h);
+    if (h->kind != SPECMI_MODEL_HMR) return fail(h, SPECMI_ERR_STATE, "handle is not an HMR model");
+    if (!feat || !out || B <= 0 || fh <= 0 || fw <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = ensure_ws(h, B, 32, 32))) return rc;
+    const OutLd old = out_ld(h);
+    if ((rc = run_head(h, feat, B, fh, fw, R, K, img_h, out->pred_pose, out->pred_shape, out->pred_cam, out->pred_pose_6d, old, s)))
+        return rc;
+    return run_smpl(h, h->rot_ws, h->betas_ws, h->cam_ws, B, R, K, bbox_scale, bbox_center, img_w, img_h,
+                    out->smpl_vertices, out->smpl_joints3d, out->smpl_joints2d, out->pred_cam_t, old, s);
 }
 
 int specmi_conv2d(specmi_handle* h, const float* x, int B, int H, int W, int Cin, const float* w_host,
@@ -926,6 +1102,8 @@ int specmi_conv2d(specmi_handle* h, const float* x, int B, int H, int W, int Cin
         a.x = x; a.w = dw; a.scale = dsc; a.shift = dsh; a.res = residual; a.out = out;
         a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.ldx = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout; a.Npad = Npad;
         a.ldo = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.relu = relu;
+        a.force_variant = opt_i(h, "force_conv_variant", 0);
+        a.wino_variant = opt_i(h, "force_wino_variant", 0);
         lrc = wino ? launch_conv_wino(a, ctx) : launch_conv_igemm(a, ctx);
     }
     hipError_t se = hipStreamSynchronize(s);
@@ -961,14 +1139,15 @@ int specmi_resize_normalize(specmi_handle* h, const uint8_t* frame, int H, int W
     const int ksh = pillow_coeffs(W, OW, hb, hk), ksv = pillow_coeffs(H, OH, vb, vk);
     const size_t o_hk = hb.size(), o_vb = o_hk + hk.size(), o_vk = o_vb + vb.size(), total = o_vk + vk.size();
     if (h->resize_geom[0] != H || h->resize_geom[1] != W || h->resize_geom[2] != OH || h->resize_geom[3] != OW || !h->resize_tab) {
+        // a resize enqueued earlier on ANY stream may still read the old tables (the handle is shared by callers on
+        // different streams): wait for the whole device before freeing / overwriting them
+        HIPCHK(h, hipDeviceSynchronize());
         if (total > h->resize_tab_ints) {
-            HIPCHK(h, hipStreamSynchronize(s));
             if (h->resize_tab) (void)hipFree(h->resize_tab);
             h->resize_tab = nullptr;
             HIPCHK(h, hipMalloc((void**)&h->resize_tab, total * 4));
             h->resize_tab_ints = total;
         }
-        HIPCHK(h, hipStreamSynchronize(s));   // a previous launch may still read the old tables
         h->resize_host.resize(total);
         std::memcpy(h->resize_host.data(), hb.data(), hb.size() * 4);
         std::memcpy(h->resize_host.data() + o_hk, hk.data(), hk.size() * 4);
@@ -1011,6 +1190,23 @@ int specmi_eval_joints(specmi_handle* h, const float* pred, const float* gt, int
     if (J < 1 || J > 32) return fail(h, SPECMI_ERR_ARG, "J must be in [1,32]");
     LaunchCtx ctx{(hipStream_t)stream, &h->prof, "eval.joints"};
     LAUNCHCHK(h, launch_eval_joints(pred, gt, B, J, mpjpe, pampjpe, ctx), "eval_joints");
+    return SPECMI_OK;
+}
+
+int specmi_regress_joints(specmi_handle* h, const float* vertices, int B, int V, const float* Jr, int J, float* joints,
+                          void* stream) {
+    ENTER(h);
+    if (!vertices || !Jr || !joints || B <= 0 || V <= 0 || J <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
+    LaunchCtx ctx{(hipStream_t)stream, &h->prof, "eval.regress_joints"};
+    LAUNCHCHK(h, launch_regress_joints(vertices, B, V, Jr, J, joints, ctx), "regress_joints");
+    return SPECMI_OK;
+}
+
+int specmi_rotate_points(specmi_handle* h, const float* R, const float* points, int B, int N, float* out, void* stream) {
+    ENTER(h);
+    if (!R || !points || !out || B <= 0 || N <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
+    LaunchCtx ctx{(hipStream_t)stream, &h->prof, "eval.rotate_points"};
+    LAUNCHCHK(h, launch_rotate_points(R, points, B, N, out, ctx), "rotate_points");
     return SPECMI_OK;
 }
 

@@ -413,14 +413,9 @@ static int launch_variant(const KArgs& k, int M, const LaunchCtx& ctx, const cha
     constexpr size_t ab = (size_t)(2 * BM * (BK + 4) + (b_lds ? 2 * (BK / 4) * BN * 4 : 0)) * sizeof(float);
     constexpr size_t cb = (size_t)BM * (BN + 4) * sizeof(float);
     constexpr size_t smem = ab > cb ? ab : cb;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&conv_igemm_f32_kernel<BM, BN, WGM, WGN, IS1X1, BK, DUAL, SPLITK, BDIR>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static DevOnce once;
+    if (int e = set_dyn_lds_once(once, reinterpret_cast<const void*>(&conv_igemm_f32_kernel<BM, BN, WGM, WGN, IS1X1, BK, DUAL, SPLITK, BDIR>), (int)smem))
+        return e;
     KArgs kk = k;
     kk.nbn = k.Npad / BN;
     const int nbm = (M + BM - 1) / BM;
@@ -439,8 +434,7 @@ static unsigned long long* g_tprof = nullptr;
 void conv_igemm_set_ablate(int v) { g_ablate = v; }
 void conv_igemm_set_tprof(unsigned long long* p) { g_tprof = p; }
 #endif
-static int g_force_variant = 0;  // 0 auto, 1: 128x128/4 waves, 2: 128x64/4, 3: 64x64/4, 4: 128x128/8 waves
-void conv_igemm_force_variant(int v) { g_force_variant = v; }
+// forced tile (ConvArgs::force_variant, per handle): 0 auto, 1: 128x128/4 waves, 2: 128x64/4, 3: 64x64/4, 4: 128x128/8 waves
 
 static const char* kVariantNames[] = {"", "conv_igemm_f32<128x128,2x2>", "conv_igemm_f32<128x64,2x2>",
                                       "conv_igemm_f32<64x64,2x2>", "conv_igemm_f32<128x128,4x2>",
@@ -448,10 +442,10 @@ static const char* kVariantNames[] = {"", "conv_igemm_f32<128x128,2x2>", "conv_i
                                       "conv_igemm_f32<64x64,2x2,ldsB>", "conv_igemm_f32<128x128,4x2,bdir>",
                                       "conv_igemm_f32<64x128,2x2,bdir>", "conv_igemm_f32<128x64,2x2,bdir>", "conv_igemm_f32<64x64,2x2,bdir,bk64>"};
 
-static int pick_variant(int M, int Npad, bool is1x1, int K) {
-    if (g_force_variant >= 1 && g_force_variant <= 12) {
-        const bool needs128 = (g_force_variant == 1 || g_force_variant == 4 || g_force_variant == 6 || g_force_variant == 9 || g_force_variant == 10);
-        if (!needs128 || Npad % 128 == 0) return g_force_variant;
+static int pick_variant(int M, int Npad, bool is1x1, int K, int force) {
+    if (force >= 1 && force <= 12) {
+        const bool needs128 = (force == 1 || force == 4 || force == 6 || force == 9 || force == 10);
+        if (!needs128 || Npad % 128 == 0) return force;
     }
     // Measured on MI355X at B=256 (tools/igemm_bench, profiles/): the 64x64 tile with the B fragments
     // streamed straight from L2 (A alone in LDS: 18 KB, 7 workgroups per CU) wins everywhere except on
@@ -462,7 +456,7 @@ static int pick_variant(int M, int Npad, bool is1x1, int K) {
 }
 
 const char* conv_igemm_variant(const ConvArgs& a) {
-    return kVariantNames[pick_variant(a.B * a.OH * a.OW, a.Npad, a.KH == 1 && a.KW == 1 && a.pad == 0, a.Cin + a.Cin2)];
+    return kVariantNames[pick_variant(a.B * a.OH * a.OW, a.Npad, a.KH == 1 && a.KW == 1 && a.pad == 0, a.Cin + a.Cin2, a.force_variant)];
 }
 
 static int dispatch_dual(int v, const KArgs& k, int M, const LaunchCtx& ctx, double flops, double bytes) {
@@ -532,7 +526,7 @@ static int launch_one(const ConvArgs& a, const LaunchCtx& ctx) {
     const double bytes = 4.0 * ((double)a.B * a.H * a.W * a.Cin + (dual ? (double)M * a.Cin2 : 0.0) +
                                 (double)M * a.Cout * (a.res ? 2.0 : 1.0) + Kd * a.Cout);
     const bool is1x1 = (a.KH == 1 && a.KW == 1 && a.pad == 0);
-    const int v = pick_variant(M, a.Npad, is1x1, a.Cin + (dual ? a.Cin2 : 0));
+    const int v = pick_variant(M, a.Npad, is1x1, a.Cin + (dual ? a.Cin2 : 0), a.force_variant);
     if (dual) return dispatch_dual(v, k, M, ctx, flops, bytes);
     return is1x1 ? dispatch<true>(v, k, M, ctx, flops, bytes) : dispatch<false>(v, k, M, ctx, flops, bytes);
 }
@@ -570,7 +564,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
 int conv_igemm_splitk_plan(const ConvArgs& a) {
     const bool is1x1 = (a.KH == 1 && a.KW == 1 && a.pad == 0 && a.stride == 1);
     const int M = a.B * a.OH * a.OW;
-    if (!is1x1 || a.x2 || M > 1024 || g_force_variant) return 1;
+    if (!is1x1 || a.x2 || M > 1024 || a.force_variant) return 1;
     const int nch = a.Cin / 32;
     int best = 1;
     for (int s = 2; s <= 16; ++s)

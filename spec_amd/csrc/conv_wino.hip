@@ -413,12 +413,11 @@ void conv_wino_set_tprof(unsigned long long* p) { g_wino_tprof = p; }
 #endif
 static int g_wino_persistent = 1;
 void conv_wino_set_persistent(int v) { g_wino_persistent = v; }
-static int g_wino_variant = 0;   // 0 auto, 16 / 8 = force the frequencies-per-wave variant
-void conv_wino_force_variant(int v) { g_wino_variant = v; }
 
 static int wino_pick(const ConvArgs& a) {
-    if (g_wino_variant == 8) return 8;
-    if (g_wino_variant == 16 && a.Cout % 128 == 0) return 16;
+    // ConvArgs::wino_variant (per handle): 0 auto, 16 / 8 = force the frequencies-per-wave variant
+    if (a.wino_variant == 8) return 8;
+    if (a.wino_variant == 16 && a.Cout % 128 == 0) return 16;
     // Measured on MI355X at B=256 (tools/wino_bench): two 128-accumulator waves per SIMD cover each other's
     // prologue / epilogue and win by ~10 % up to Cin = 256; from Cin = 512 (32 stages per tile) the
     // 128-channel workgroup (half the A traffic per MFMA) is ahead.
@@ -429,13 +428,8 @@ template <int NF>
 static int wino_launch_variant(WArgs k, int Cout, const LaunchCtx& ctx, double flops, double bytes) {
     constexpr int NT = NF == 16 ? 128 : 64;
     constexpr int smem = (NF == 16 ? 3 : 2) * WINO_BUF + 2 * WINO_TAB;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_f32_kernel<NF>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static DevOnce once;
+    if (int e = set_dyn_lds_once(once, reinterpret_cast<const void*>(&conv_wino_f32_kernel<NF>), smem)) return e;
     k.nbn = Cout / NT;
     k.nbm = (k.Mt + 31) / 32;
     // persistent grid: as many workgroups as the chip holds at once (256 CUs x 1 or 2), split evenly over the

@@ -177,6 +177,49 @@ __global__ void __launch_bounds__(64) eval_joints_kernel(const float* __restrict
     if (pampjpe) pampjpe[b] = pa;
 }
 
+// joints (B,J,3) = J_regressor (J,V) @ vertices (B,V,3)  (torch.einsum('bik,ji->bjk'), compute_error.py:184,187;
+// torch.matmul(J_regressor_batch, vertices), :53,58): one workgroup per (image, joint)
+__global__ void __launch_bounds__(256) regress_joints_kernel(const float* __restrict__ verts, int V,
+                                                              const float* __restrict__ Jr, int J, float* __restrict__ out) {
+    __shared__ float red[4];
+    const int b = blockIdx.x / J, j = blockIdx.x % J, t = threadIdx.x;
+    const float* v = verts + (size_t)b * V * 3;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int i = t; i < V; i += 256) {
+        const float w = Jr[(size_t)j * V + i];
+        a0 = fmaf(w, v[i * 3 + 0], a0); a1 = fmaf(w, v[i * 3 + 1], a1); a2 = fmaf(w, v[i * 3 + 2], a2);
+    }
+    const float s0 = block_sum_256(a0, red), s1 = block_sum_256(a1, red), s2 = block_sum_256(a2, red);
+    if (t == 0) {
+        float* o = out + ((size_t)b * J + j) * 3;
+        o[0] = s0; o[1] = s1; o[2] = s2;
+    }
+}
+
+int launch_regress_joints(const float* verts, int B, int V, const float* Jr, int J, float* out, const LaunchCtx& ctx) {
+    ProfScope ps(ctx, "regress_joints", 2.0 * B * (double)V * 3 * J, 4.0 * ((double)B * V * 3 + (double)J * V + (double)B * J * 3));
+    hipLaunchKernelGGL(regress_joints_kernel, dim3(B * J), dim3(256), 0, ctx.stream, verts, V, Jr, J, out);
+    return (int)hipGetLastError();
+}
+
+// out[b,n,:] = R[b] @ x[b,n,:]  (torch.bmm(R, x.transpose(2,1)).transpose(2,1), compute_error.py:164-165,189)
+__global__ void __launch_bounds__(256) rotate_points_kernel(const float* __restrict__ R, const float* __restrict__ x,
+                                                             int N, long total, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float* r = R + (i / N) * 9;
+    const float x0 = x[i * 3 + 0], x1 = x[i * 3 + 1], x2 = x[i * 3 + 2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[i * 3 + c] = r[c * 3 + 0] * x0 + r[c * 3 + 1] * x1 + r[c * 3 + 2] * x2;
+}
+
+int launch_rotate_points(const float* R, const float* x, int B, int N, float* out, const LaunchCtx& ctx) {
+    const long total = (long)B * N;
+    ProfScope ps(ctx, "rotate_points", 18.0 * total, 4.0 * (6.0 * total + 9.0 * B));
+    hipLaunchKernelGGL(rotate_points_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx.stream, R, x, N, total, out);
+    return (int)hipGetLastError();
+}
+
 int launch_eval_mesh(const float* pred, const float* gt, int B, int V, const float* Jr, int J, const int* sel, int nsel,
                      float* mpjpe, float* pampjpe, float* v2v, const LaunchCtx& ctx) {
     if (J > kMaxJ || nsel > kMaxJ || nsel < 1 || J < 1) return (int)hipErrorInvalidValue;

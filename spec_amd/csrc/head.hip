@@ -20,10 +20,11 @@ __global__ void __launch_bounds__(256) head_init_kernel(float* __restrict__ xc, 
                                                          const float* __restrict__ init_shape,
                                                          const float* __restrict__ init_cam,
                                                          const float* __restrict__ R, const float* __restrict__ K,
-                                                         const float* __restrict__ img_h, int use_cam_feats, int B) {
+                                                         const float* __restrict__ img_h, int use_cam_feats, int B,
+                                                         int state_off, int ld) {
     const int b = blockIdx.x;
-    float* row = xc + (size_t)b * XC_LD + XC_STATE_OFF;
-    for (int i = threadIdx.x; i < XC_LD - XC_STATE_OFF; i += blockDim.x) {
+    float* row = xc + (size_t)b * ld + state_off;
+    for (int i = threadIdx.x; i < ld - state_off; i += blockDim.x) {
         float v = 0.f;
         if (i < 144) v = init_pose[i];
         else if (i < 154) v = init_shape[i - 144];
@@ -40,29 +41,32 @@ __global__ void __launch_bounds__(256) head_init_kernel(float* __restrict__ xc, 
 
 int launch_head_init(float* xc, const float* init_pose, const float* init_shape, const float* init_cam,
                      const float* cam_rotmat, const float* cam_intrinsics, const float* img_h, int use_cam_feats,
-                     int B, const LaunchCtx& ctx) {
-    ProfScope ps(ctx, "head_init", 0.0, 4.0 * B * (XC_LD - XC_STATE_OFF));
+                     int B, int state_off, int ld, const LaunchCtx& ctx) {
+    ProfScope ps(ctx, "head_init", 0.0, 4.0 * B * (ld - state_off));
     hipLaunchKernelGGL(head_init_kernel, dim3(B), dim3(256), 0, ctx.stream, xc, init_pose, init_shape, init_cam,
-                       cam_rotmat, cam_intrinsics, img_h, use_cam_feats, B);
+                       cam_rotmat, cam_intrinsics, img_h, use_cam_feats, B, state_off, ld);
     return (int)hipGetLastError();
 }
 
-__global__ void __launch_bounds__(256) head_final_kernel(const float* __restrict__ xc, float* __restrict__ pred_pose,
-                                                          float* __restrict__ pred_shape, float* __restrict__ pred_cam,
-                                                          float* __restrict__ pred_pose_6d, float* __restrict__ rot_ws,
-                                                          float* __restrict__ betas_ws, float* __restrict__ cam_ws,
-                                                          int B) {
+// `state` = the 157 regressor outputs [pose6d | shape | cam] of image b at state[b * ld_state]; every output
+// pointer addresses image 0 and is advanced by its own per-image stride (dense, or the row stride of a packed record)
+__global__ void __launch_bounds__(256) head_final_kernel(const float* __restrict__ state, long ld_state,
+                                                          float* __restrict__ pred_pose, float* __restrict__ pred_shape,
+                                                          float* __restrict__ pred_cam, float* __restrict__ pred_pose_6d,
+                                                          long ld_pose, long ld_shape, long ld_cam, long ld_p6d,
+                                                          float* __restrict__ rot_ws, float* __restrict__ betas_ws,
+                                                          float* __restrict__ cam_ws, int B) {
     const int b = blockIdx.x, t = threadIdx.x;
-    const float* s = xc + (size_t)b * XC_LD + XC_STATE_OFF;
-    if (t < 144 && pred_pose_6d) pred_pose_6d[(size_t)b * 144 + t] = s[t];
+    const float* s = state + (size_t)b * ld_state;
+    if (t < 144 && pred_pose_6d) pred_pose_6d[(size_t)b * ld_p6d + t] = s[t];
     if (t >= 144 && t < 154) {
         const float v = s[t];
-        if (pred_shape) pred_shape[(size_t)b * 10 + t - 144] = v;
+        if (pred_shape) pred_shape[(size_t)b * ld_shape + t - 144] = v;
         if (betas_ws) betas_ws[(size_t)b * 10 + t - 144] = v;
     }
     if (t >= 154 && t < 157) {
         const float v = s[t];
-        if (pred_cam) pred_cam[(size_t)b * 3 + t - 154] = v;
+        if (pred_cam) pred_cam[(size_t)b * ld_cam + t - 154] = v;
         if (cam_ws) cam_ws[(size_t)b * 3 + t - 154] = v;
     }
     if (t >= 192 && t < 216) {
@@ -82,17 +86,18 @@ __global__ void __launch_bounds__(256) head_final_kernel(const float* __restrict
         const float Rm[9] = {b1x, b2x, b3x, b1y, b2y, b3y, b1z, b2z, b3z};  // columns b1 b2 b3
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            if (pred_pose) pred_pose[((size_t)b * 24 + j) * 9 + k] = Rm[k];
+            if (pred_pose) pred_pose[(size_t)b * ld_pose + j * 9 + k] = Rm[k];
             if (rot_ws) rot_ws[((size_t)b * 24 + j) * 9 + k] = Rm[k];
         }
     }
 }
 
-int launch_head_final(const float* xc, float* pred_pose, float* pred_shape, float* pred_cam, float* pred_pose_6d,
-                      float* rotmat_ws, float* betas_ws, float* cam_ws, int B, const LaunchCtx& ctx) {
+int launch_head_final(const float* state, long ld_state, float* pred_pose, float* pred_shape, float* pred_cam,
+                      float* pred_pose_6d, const long ld[4], float* rotmat_ws, float* betas_ws, float* cam_ws, int B,
+                      const LaunchCtx& ctx) {
     ProfScope ps(ctx, "head_final_rot6d", 0.0, 4.0 * B * (157 + 157 + 216));
-    hipLaunchKernelGGL(head_final_kernel, dim3(B), dim3(256), 0, ctx.stream, xc, pred_pose, pred_shape, pred_cam,
-                       pred_pose_6d, rotmat_ws, betas_ws, cam_ws, B);
+    hipLaunchKernelGGL(head_final_kernel, dim3(B), dim3(256), 0, ctx.stream, state, ld_state, pred_pose, pred_shape,
+                       pred_cam, pred_pose_6d, ld[0], ld[1], ld[2], ld[3], rotmat_ws, betas_ws, cam_ws, B);
     return (int)hipGetLastError();
 }
 
@@ -139,7 +144,7 @@ __global__ void __launch_bounds__(192) camcalib_decode_kernel(const float* __res
                                                                const float* __restrict__ img_w, float* __restrict__ vfov,
                                                                float* __restrict__ pitch, float* __restrict__ roll,
                                                                float* __restrict__ f_pix, float* __restrict__ R,
-                                                               float* __restrict__ K) {
+                                                               float* __restrict__ K, long ld_ang) {
     __shared__ float ang[3];
     const int b = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -168,9 +173,9 @@ __global__ void __launch_bounds__(192) camcalib_decode_kernel(const float* __res
     __syncthreads();
     if (threadIdx.x == 0) {
         const float vf = ang[0], pt = ang[1], rl = ang[2];
-        if (vfov) vfov[b] = vf;
-        if (pitch) pitch[b] = pt;
-        if (roll) roll[b] = rl;
+        if (vfov) vfov[(size_t)b * ld_ang] = vf;
+        if (pitch) pitch[(size_t)b * ld_ang] = pt;
+        if (roll) roll[(size_t)b * ld_ang] = rl;
         const float h = img_h ? img_h[b] : 0.f, w = img_w ? img_w[b] : 0.f;
         const float f = h / 2.0f / tanf(vf / 2.0f);
         if (f_pix) f_pix[b] = f;
@@ -180,10 +185,50 @@ __global__ void __launch_bounds__(192) camcalib_decode_kernel(const float* __res
 
 int launch_camcalib_decode(const float* lv, const float* lp, const float* lr, int B, int nbins, const float* img_h,
                            const float* img_w, float* vfov, float* pitch, float* roll, float* f_pix, float* R,
-                           float* K, const LaunchCtx& ctx) {
+                           float* K, long ld_ang, const LaunchCtx& ctx) {
     ProfScope ps(ctx, "camcalib_decode", 0.0, 4.0 * B * (3.0 * nbins + 24));
     hipLaunchKernelGGL(camcalib_decode_kernel, dim3(B), dim3(192), 0, ctx.stream, lv, lp, lr, nbins, img_h, img_w, vfov,
-                       pitch, roll, f_pix, R, K);
+                       pitch, roll, f_pix, R, K, ld_ang);
+    return (int)hipGetLastError();
+}
+
+// The two per-row reductions camcalib/cam_utils.py applies to a (rows, nbins) logit tensor, one wave per row:
+//   idx[row]  = np.argmax(row)            (bins2vfov / bins2pitch / bins2roll / bins2horizon, cam_utils.py:66-91):
+//               FIRST index of the maximum, a NaN counts as the maximum (NumPy semantics) - index work, bit-exact;
+//   soft[row] = softargmax1d(row, normalize_keypoints=True) in [-1, 1] (get_softargmax, cam_utils.py:110-118).
+__global__ void __launch_bounds__(256) bins_reduce_kernel(const float* __restrict__ x, int rows, int nbins,
+                                                           int* __restrict__ idx, float* __restrict__ soft) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* r = x + (size_t)row * nbins;
+    float mx = -INFINITY;
+    int mi = 0x7fffffff, nan_i = 0x7fffffff;
+    for (int i = lane; i < nbins; i += 64) {
+        const float v = r[i];
+        if (v != v) nan_i = min(nan_i, i);
+        if (v > mx || (v == mx && i < mi)) { mx = v; mi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float omx = __shfl_xor(mx, o, 64);
+        const int omi = __shfl_xor(mi, o, 64);
+        nan_i = min(nan_i, __shfl_xor(nan_i, o, 64));
+        if (omx > mx || (omx == mx && omi < mi)) { mx = omx; mi = omi; }
+    }
+    if (idx && lane == 0) idx[row] = nan_i != 0x7fffffff ? nan_i : (mi == 0x7fffffff ? 0 : mi);
+    if (soft) {
+        float se = 0.f, sp = 0.f;
+        for (int i = lane; i < nbins; i += 64) se += expf(r[i] - mx);
+        se = wave_sum(se);
+        for (int i = lane; i < nbins; i += 64) sp += expf(r[i] - mx) / se * (float)i;
+        sp = wave_sum(sp);
+        if (lane == 0) soft[row] = sp / (float)(nbins - 1) * 2.0f - 1.0f;
+    }
+}
+
+int launch_bins_reduce(const float* x, int rows, int nbins, int* idx, float* soft, const LaunchCtx& ctx) {
+    ProfScope ps(ctx, "bins_reduce", 0.0, 4.0 * rows * (nbins + 2.0));
+    hipLaunchKernelGGL(bins_reduce_kernel, dim3((rows + 3) / 4), dim3(256), 0, ctx.stream, x, rows, nbins, idx, soft);
     return (int)hipGetLastError();
 }
 

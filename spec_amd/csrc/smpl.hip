@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(256) smpl_skin_kernel(const float* __restrict_
                                                          const float* __restrict__ lbs_w,
                                                          const float* __restrict__ betas_t,
                                                          const float* __restrict__ pf_t, const float* __restrict__ A,
-                                                         float* __restrict__ verts, int V, int B) {
+                                                         float* __restrict__ verts, long ld_verts, int V, int B) {
     const int v = blockIdx.x * 256 + threadIdx.x;
     const bool vok = v < V;
     const int vv = vok ? v : V - 1;
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256) smpl_skin_kernel(const float* __restrict_
 #pragma unroll
             for (int e = 0; e < 12; ++e) T[e] = fmaf(w[j], At[(i * 24 + j) * 12 + e], T[e]);
         if (vok) {
-            float* o = verts + ((size_t)(b0 + i) * V + v) * 3;
+            float* o = verts + (size_t)(b0 + i) * ld_verts + (size_t)v * 3;
 #pragma unroll
             for (int c = 0; c < 3; ++c)
                 o[c] = T[c * 4 + 0] * vp[i][0] + T[c * 4 + 1] * vp[i][1] + T[c * 4 + 2] * vp[i][2] + T[c * 4 + 3];
@@ -195,6 +195,7 @@ struct JointArgs {
     const float* cam; const float* R; const float* K; const float* bbox_scale; const float* bbox_center;
     const float* img_w; const float* img_h;
     float* joints3d; float* joints2d; float* cam_t;
+    long ld_verts, ld_j3d, ld_j2d, ld_camt;
     int V, mode, normalize; float focal, img_res;
 };
 
@@ -203,7 +204,7 @@ __global__ void __launch_bounds__(256) smpl_joints_kernel(const JointArgs a) {
     __shared__ float J54[54][3];
     __shared__ float ct[3];
     const int b = blockIdx.x, t = threadIdx.x;
-    const float* vb = a.verts + (size_t)b * a.V * 3;
+    const float* vb = a.verts + (size_t)b * a.ld_verts;
     float acc[9][3];
 #pragma unroll
     for (int e = 0; e < 9; ++e) acc[e][0] = acc[e][1] = acc[e][2] = 0.f;
@@ -246,12 +247,12 @@ __global__ void __launch_bounds__(256) smpl_joints_kernel(const JointArgs a) {
     __syncthreads();
     if (t < 27) J54[45 + t / 3][t % 3] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
     __syncthreads();
-    if (t < 3 && a.cam_t) a.cam_t[b * 3 + t] = ct[t];
+    if (t < 3 && a.cam_t) a.cam_t[(size_t)b * a.ld_camt + t] = ct[t];
     if (t < 49) {
         const int jm = a.joint_map[t];
         const float X0 = J54[jm][0], X1 = J54[jm][1], X2 = J54[jm][2];
         if (a.joints3d) {
-            float* o = a.joints3d + ((size_t)b * 49 + t) * 3;
+            float* o = a.joints3d + (size_t)b * a.ld_j3d + t * 3;
             o[0] = X0; o[1] = X1; o[2] = X2;
         }
         if (a.joints2d) {
@@ -271,14 +272,65 @@ __global__ void __launch_bounds__(256) smpl_joints_kernel(const JointArgs a) {
             float u = Km[0] * x0 + Km[1] * x1 + Km[2] * x2;
             float vv = Km[3] * x0 + Km[4] * x1 + Km[5] * x2;
             if (a.normalize) { u = u / (a.img_res / 2.0f); vv = vv / (a.img_res / 2.0f); }
-            a.joints2d[((size_t)b * 49 + t) * 2 + 0] = u;
-            a.joints2d[((size_t)b * 49 + t) * 2 + 1] = vv;
+            a.joints2d[(size_t)b * a.ld_j2d + t * 2 + 0] = u;
+            a.joints2d[(size_t)b * a.ld_j2d + t * 2 + 1] = vv;
         }
     }
 }
 
+// smplx.lbs.batch_rodrigues (0.1.28): angle = |r + 1e-8| (the epsilon is added to every component), axis = r / angle,
+// R = I + sin(angle) K + (1 - cos(angle)) K K with K the cross-product matrix of the axis
+__global__ void rodrigues_kernel(const float* __restrict__ aa, float* __restrict__ rot, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = aa[i * 3 + 0], y = aa[i * 3 + 1], z = aa[i * 3 + 2];
+    const float ex = x + 1e-8f, ey = y + 1e-8f, ez = z + 1e-8f;
+    const float angle = sqrtf(ex * ex + ey * ey + ez * ez);
+    const float rx = x / angle, ry = y / angle, rz = z / angle;
+    const float c = cosf(angle), sn = sinf(angle);
+    const float K[9] = {0.f, -rz, ry, rz, 0.f, -rx, -ry, rx, 0.f};
+    float* R = rot + (size_t)i * 9;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int cidx = 0; cidx < 3; ++cidx) {
+            const float kk = K[r * 3 + 0] * K[0 * 3 + cidx] + K[r * 3 + 1] * K[1 * 3 + cidx] + K[r * 3 + 2] * K[2 * 3 + cidx];
+            R[r * 3 + cidx] = ((r == cidx) ? 1.0f : 0.0f) + sn * K[r * 3 + cidx] + (1.0f - c) * kk;
+        }
+}
+
+int launch_rodrigues(const float* aa, float* rot, int n, const LaunchCtx& ctx) {
+    ProfScope ps(ctx, "smpl_rodrigues", 0.0, 4.0 * n * 12);
+    hipLaunchKernelGGL(rodrigues_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx.stream, aa, rot, n);
+    return (int)hipGetLastError();
+}
+
+// smplx.SMPL.forward(pose2rot=False) without the 49-joint wrapper: vertices + the 24 posed kinematic-chain joints
+// (`.joints[:, :24]` of the reference's smpl_native / body_model_orig, spec/trainer.py:249-254, compute_error.py:156-160)
+int launch_smpl_native(const SmplDev& m, const SmplArgs& a, float* joints24, const LaunchCtx& ctx) {
+    const int B = a.B, V = m.V;
+    const long ld_verts = a.ld_verts > 0 ? a.ld_verts : (long)V * 3;
+    const int tiles = (B + IT - 1) / IT;
+    float* pf_t = a.pose_feat;
+    float* betas_t = a.pose_feat + (size_t)tiles * PF_LD * IT;
+    {
+        ProfScope ps(ctx, "smpl_pose_chain", 0.0, 4.0 * B * (216 + 10 + 207 + 288 + 72));
+        hipLaunchKernelGGL(smpl_pose_kernel, dim3(B), dim3(64), 0, ctx.stream, a.rotmat, a.betas, m.J_template,
+                           m.J_shapedirs, m.parents, pf_t, betas_t, a.A, joints24 ? joints24 : a.posed_j);
+    }
+    if (a.vertices) {
+        const double flops = 2.0 * (double)B * V * (3.0 * 207 + 30 + 288 + 9);
+        const double bytes = 4.0 * ((double)B * V * 3 + (double)tiles * V * (3.0 * 207 + 3 + 30 + 24));
+        ProfScope ps(ctx, "smpl_skin_lbs", flops, bytes);
+        hipLaunchKernelGGL(smpl_skin_kernel, dim3((V + 255) / 256, tiles), dim3(256), 0, ctx.stream, m.v_template,
+                           m.shapedirs, m.posedirs, m.lbs_weights, betas_t, pf_t, a.A, a.vertices, ld_verts, V, B);
+    }
+    return (int)hipGetLastError();
+}
+
 int launch_smpl(const SmplDev& m, const SmplArgs& a, const LaunchCtx& ctx) {
     const int B = a.B, V = m.V;
+    const long ld_verts = a.ld_verts > 0 ? a.ld_verts : (long)V * 3;
     // workspace layout inside pose_feat: [tiles][208][IT] pose features, then [tiles][10][IT] betas
     const int tiles = (B + IT - 1) / IT;
     float* pf_t = a.pose_feat;
@@ -293,7 +345,7 @@ int launch_smpl(const SmplDev& m, const SmplArgs& a, const LaunchCtx& ctx) {
         const double bytes = 4.0 * ((double)B * V * 3 + (double)tiles * V * (3.0 * 207 + 3 + 30 + 24));
         ProfScope ps(ctx, "smpl_skin_lbs", flops, bytes);
         hipLaunchKernelGGL(smpl_skin_kernel, dim3((V + 255) / 256, tiles), dim3(256), 0, ctx.stream, m.v_template,
-                           m.shapedirs, m.posedirs, m.lbs_weights, betas_t, pf_t, a.A, a.vertices, V, B);
+                           m.shapedirs, m.posedirs, m.lbs_weights, betas_t, pf_t, a.A, a.vertices, ld_verts, V, B);
     }
     {
         JointArgs j;
@@ -301,6 +353,7 @@ int launch_smpl(const SmplDev& m, const SmplArgs& a, const LaunchCtx& ctx) {
         j.joint_map = m.joint_map; j.cam = a.cam; j.R = a.cam_rotmat; j.K = a.cam_intrinsics;
         j.bbox_scale = a.bbox_scale; j.bbox_center = a.bbox_center; j.img_w = a.img_w; j.img_h = a.img_h;
         j.joints3d = a.joints3d; j.joints2d = a.joints2d; j.cam_t = a.cam_t;
+        j.ld_verts = ld_verts; j.ld_j3d = a.ld_j3d; j.ld_j2d = a.ld_j2d; j.ld_camt = a.ld_camt;
         j.V = V; j.mode = a.mode; j.normalize = a.normalize_joints2d; j.focal = a.focal_length; j.img_res = a.img_res;
         ProfScope ps(ctx, "smpl_joints_project", 2.0 * B * V * 27.0, 4.0 * B * ((double)V * 3 + 9.0 * V + 49 * 5));
         hipLaunchKernelGGL(smpl_joints_kernel, dim3(B), dim3(256), 0, ctx.stream, j);

@@ -56,6 +56,22 @@ struct ProfScope {  // RAII: records e0 at construction, e1 at destruction
     }
 };
 
+// hipFuncSetAttribute is a per-DEVICE setting: remember per (kernel instantiation, device) whether the
+// dynamic-LDS limit was raised (a second device in the same process must get its own call).
+struct DevOnce {
+    bool done[64] = {};
+};
+inline int set_dyn_lds_once(DevOnce& once, const void* fn, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev >= 0 && dev < 64 && once.done[dev]) return 0;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    if (dev >= 0 && dev < 64) once.done[dev] = true;
+    return 0;
+}
+
 // ----------------------------------------------------------------------------------------
 // implicit-GEMM convolution / linear layer on fp32 MFMA  (conv_igemm.hip)
 // ----------------------------------------------------------------------------------------
@@ -74,6 +90,9 @@ struct ConvArgs {
     // used to fold a bottleneck's downsample branch into its conv3
     const float* x2 = nullptr;
     int H2 = 0, W2 = 0, ldx2 = 0, Cin2 = 0, stride2 = 1;
+    // per-handle tuning overrides (tests / tools): 0 = automatic choice
+    int force_variant = 0;   // conv_igemm tile (1: 128x128/4 waves, 2: 128x64/4, 3: 64x64/4, 4: 128x128/8 waves)
+    int wino_variant = 0;    // conv_wino frequencies per wave (16 / 8)
 };
 // Cin % 32 == 0, Npad % 64 == 0.  Returns hipError as int.
 int launch_conv_igemm(const ConvArgs& a, const LaunchCtx& ctx);
@@ -91,7 +110,6 @@ const char* conv_igemm_variant(const ConvArgs& a);
 bool conv_wino_supported(const ConvArgs& a);
 void pack_wino_weights(const float* w_oihw, int cout, int cin, std::vector<float>& out);
 int launch_conv_wino(const ConvArgs& a, const LaunchCtx& ctx);
-void conv_wino_force_variant(int nf);   // 0 auto, 16 / 8 frequencies per wave (tests, tuning)
 
 // ----------------------------------------------------------------------------------------
 // stem + pooling  (stem.hip)
@@ -108,17 +126,22 @@ int launch_avgpool(const float* x, float* out, int B, int HW, int C, int ldo, co
 // ----------------------------------------------------------------------------------------
 // heads  (head.hip)
 // ----------------------------------------------------------------------------------------
-constexpr int XC_LD = 2240;       // row stride of the IEF state [xf | pose6d | shape | cam | rot6d(R) | vfov | 0-pad]
-constexpr int XC_STATE_OFF = 2048;
+// IEF state row of image b at xc + b*ld: [xf (F) | pose6d 144 | shape 10 | cam 3 | rot6d(R) 6 | vfov 1 | 0-pad], F = trunk
+// features (2048 for ResNet-50: ld = 2240), state_off = F
 int launch_head_init(float* xc, const float* init_pose, const float* init_shape,
                      const float* init_cam, const float* cam_rotmat, const float* cam_intrinsics,
-                     const float* img_h, int use_cam_feats, int B, const LaunchCtx& ctx);
-int launch_head_final(const float* xc, float* pred_pose, float* pred_shape, float* pred_cam,
-                      float* pred_pose_6d, float* rotmat_ws, float* betas_ws, float* cam_ws,
+                     const float* img_h, int use_cam_feats, int B, int state_off, int ld, const LaunchCtx& ctx);
+// state: 157 regressor outputs per image at stride ld_state; ld[4] = per-image strides of pred_pose / pred_shape /
+// pred_cam / pred_pose_6d (216 / 10 / 3 / 144 when dense)
+int launch_head_final(const float* state, long ld_state, float* pred_pose, float* pred_shape, float* pred_cam,
+                      float* pred_pose_6d, const long ld[4], float* rotmat_ws, float* betas_ws, float* cam_ws,
                       int B, const LaunchCtx& ctx);
+// ld_ang: per-image stride of vfov / pitch / roll (1 when dense)
 int launch_camcalib_decode(const float* lv, const float* lp, const float* lr, int B, int nbins,
                            const float* img_h, const float* img_w, float* vfov, float* pitch,
-                           float* roll, float* f_pix, float* R, float* K, const LaunchCtx& ctx);
+                           float* roll, float* f_pix, float* R, float* K, long ld_ang, const LaunchCtx& ctx);
+// per-row argmax (first maximum, NumPy NaN semantics) and / or normalised soft-argmax of (rows, nbins) logits
+int launch_bins_reduce(const float* x, int rows, int nbins, int* idx, float* soft, const LaunchCtx& ctx);
 
 int launch_cam_params(const float* pitch, const float* roll, const float* f_pix, const float* img_w, const float* img_h,
                       int B, float* R, float* K, const LaunchCtx& ctx);
@@ -153,6 +176,7 @@ struct SmplArgs {
     float* joints3d;   // (B,49,3)
     float* joints2d;   // (B,49,2)
     float* cam_t;      // (B,3)
+    long ld_verts = 0, ld_j3d = 147, ld_j2d = 98, ld_camt = 3;   // per-image strides (0: V*3)
     // workspace
     float* pose_feat;  // (B,208)
     float* A;          // (B,24,12)
@@ -164,6 +188,10 @@ struct SmplArgs {
     int normalize_joints2d;
 };
 int launch_smpl(const SmplDev& m, const SmplArgs& a, const LaunchCtx& ctx);
+// vertices (optional) + the 24 posed kinematic joints (optional; a.posed_j receives them otherwise)
+int launch_smpl_native(const SmplDev& m, const SmplArgs& a, float* joints24, const LaunchCtx& ctx);
+// axis-angle (n,3) -> rotation matrices (n,3,3), smplx batch_rodrigues
+int launch_rodrigues(const float* aa, float* rot, int n, const LaunchCtx& ctx);
 
 // ----------------------------------------------------------------------------------------
 // evaluation metrics  (eval.hip)
@@ -172,6 +200,8 @@ int launch_eval_mesh(const float* pred, const float* gt, int B, int V, const flo
                      float* mpjpe, float* pampjpe, float* v2v, const LaunchCtx& ctx);
 int launch_eval_joints(const float* pred, const float* gt, int B, int J, float* mpjpe, float* pampjpe,
                        const LaunchCtx& ctx);
+int launch_regress_joints(const float* verts, int B, int V, const float* Jr, int J, float* out, const LaunchCtx& ctx);
+int launch_rotate_points(const float* R, const float* x, int B, int N, float* out, const LaunchCtx& ctx);
 
 // ----------------------------------------------------------------------------------------
 // crop + normalise  (preprocess.hip)

@@ -156,13 +156,8 @@ void pack_stem_weights(const float* w, std::vector<float>& out) {
 int launch_stem(const float* x, const float* w, const float* scale, const float* shift, float* out, int B, int H,
                 int W, int OH, int OW, int relu, const LaunchCtx& ctx) {
     constexpr size_t smem = (SM_WF + SM_PATCH) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_conv7x7_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static DevOnce once;
+    if (int e = set_dyn_lds_once(once, reinterpret_cast<const void*>(&stem_conv7x7_kernel), (int)smem)) return e;
     // 32-bit buffer offsets on both sides: split the batch if a side reaches 2 GiB
     const size_t in_img = (size_t)3 * H * W * 4, out_img = (size_t)OH * OW * 64 * 4;
     const size_t limit = (size_t)1 << 31;

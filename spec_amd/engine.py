@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 
-KIND = {'camcalib': _lib.MODEL_CAMCALIB, 'hmr': _lib.MODEL_HMR}
+KIND = {'camcalib': _lib.MODEL_CAMCALIB, 'hmr': _lib.MODEL_HMR, 'smpl': _lib.MODEL_SMPL}
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -44,6 +44,7 @@ class Engine:
         self.nbins = 256
         self.feat_channels = 2048
         self.num_verts = 0
+        self._ld_opts = {}        # current value of the stride options ("output_ld", "angle_ld") on the handle
 
     def close(self):
         if getattr(self, 'h', None) is not None and self.h:
@@ -98,6 +99,33 @@ class Engine:
         self.feat_channels = 512 if int(options.get('backbone', 50)) == 34 else 2048
         _lib.check(self.h, self.lib.specmi_commit(self.h))
 
+    def _set_ld(self, name: str, value: int):
+        if self._ld_opts.get(name, 0) != value:
+            self.set_option(name, int(value))
+            self._ld_opts[name] = value
+
+    # ---- packed per-image record (SURVEY.md 8e) ------------------------------------------------
+    def record_layout(self):
+        """[(key, offset, per-image shape)] of the packed record the kernels can write directly:
+        85,164 B of SPEC outputs + 12 B of camera angles = 21,294 floats for V = 6890."""
+        lay, off = [], 0
+        for k, shp in (('smpl_vertices', (self.num_verts, 3)), ('smpl_joints3d', (49, 3)), ('smpl_joints2d', (49, 2)),
+                       ('pred_cam_t', (3,)), ('pred_pose', (24, 3, 3)), ('pred_cam', (3,)), ('pred_shape', (10,)),
+                       ('pred_pose_6d', (144,)), ('cam_vfov', ()), ('cam_pitch', ()), ('cam_roll', ())):
+            n = int(np.prod(shp)) if shp else 1
+            lay.append((k, off, shp))
+            off += n
+        return lay, off
+
+    def record_views(self, record: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """Views of a (B, record_floats) record as the output dict (no copy)."""
+        lay, total = self.record_layout()
+        if record.dim() != 2 or record.shape[1] != total or record.dtype != torch.float32 or record.stride(1) != 1:
+            raise ValueError(f'record must be a (B, {total}) fp32 tensor with unit column stride')
+        B = record.shape[0]
+        return {k: record[:, off:off + (int(np.prod(shp)) if shp else 1)].view(B, *shp) if shp
+                else record[:, off] for k, off, shp in lay}
+
     # ---- forward ---------------------------------------------------------------------------
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -132,13 +160,23 @@ class Engine:
             self.h, _ptr(x), B, H, W, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), self._stream()))
         return [out[0], out[1], out[2]]
 
-    def camcalib_decode(self, lv, lp, lr, img_h=None, img_w=None):
+    def camcalib_decode(self, lv, lp, lr, img_h=None, img_w=None, angles_out=None):
+        """``angles_out``: optional (vfov, pitch, roll) tensors of shape (B,) with a common element stride
+        (e.g. three columns of the packed record) that the kernel writes directly."""
         lv, lp, lr = (_dev_f32(t, self.device) for t in (lv, lp, lr))
         B, nb = lv.shape
         img_h = _dev_f32(img_h, self.device, (B,))
         img_w = _dev_f32(img_w, self.device, (B,))
         mk = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)
-        vf, pt, rl = mk(B), mk(B), mk(B)
+        if angles_out is not None:
+            vf, pt, rl = angles_out
+            ld = vf.stride(0) if B > 1 else 1
+            if any(t.shape != (B,) or t.dtype != torch.float32 or (B > 1 and t.stride(0) != ld) for t in (vf, pt, rl)):
+                raise ValueError('angles_out: three (B,) fp32 tensors with one common stride')
+            self._set_ld('angle_ld', ld if ld != 1 else 0)
+        else:
+            vf, pt, rl = mk(B), mk(B), mk(B)
+            self._set_ld('angle_ld', 0)
         f = mk(B) if img_h is not None else None
         R = mk(B, 3, 3)
         K = mk(B, 3, 3) if (img_h is not None and img_w is not None) else None
@@ -146,6 +184,16 @@ class Engine:
             self.h, _ptr(lv), _ptr(lp), _ptr(lr), B, nb, _ptr(img_h), _ptr(img_w), _ptr(vf), _ptr(pt),
             _ptr(rl), _ptr(f), _ptr(R), _ptr(K), self._stream()))
         return {'vfov': vf, 'pitch': pt, 'roll': rl, 'f_pix': f, 'cam_rotmat': R, 'cam_intrinsics': K}
+
+    def camcalib_bins(self, logits, argmax=True, soft=False):
+        """Per-row argmax (int32) and / or normalised soft-argmax of (..., nbins) device logits."""
+        x = _dev_f32(logits, self.device)
+        nb = x.shape[-1]
+        rows = x.numel() // nb
+        idx = torch.empty(x.shape[:-1], device=self.device, dtype=torch.int32) if argmax else None
+        sf = torch.empty(x.shape[:-1], device=self.device, dtype=torch.float32) if soft else None
+        _lib.check(self.h, self.lib.specmi_camcalib_bins(self.h, _ptr(x), rows, nb, _ptr(idx), _ptr(sf), self._stream()))
+        return idx, sf
 
     def _cam_args(self, B, cam_rotmat, cam_intrinsics, bbox_scale, bbox_center, img_w, img_h):
         d = self.device
@@ -159,34 +207,63 @@ class Engine:
                 'smpl_joints2d': mk(B, 49, 2), 'pred_cam_t': mk(B, 3), 'pred_pose': mk(B, 24, 3, 3),
                 'pred_cam': mk(B, 3), 'pred_shape': mk(B, 10), 'pred_pose_6d': mk(B, 144)}
 
+    def _out_for(self, B, record):
+        """Output dict + the handle's output stride: dense tensors, or views of a (B, record_floats) record the
+        kernels write in place."""
+        if record is None:
+            self._set_ld('output_ld', 0)
+            return None
+        if record.shape[0] != B or record.device != self.device:
+            raise ValueError('record must be a (B, record_floats) tensor on the model device')
+        views = self.record_views(record)
+        self._set_ld('output_ld', record.stride(0))
+        return views
+
     def hmr_forward(self, images, cam_rotmat=None, cam_intrinsics=None, bbox_scale=None,
-                    bbox_center=None, img_w=None, img_h=None, out: Optional[Dict[str, torch.Tensor]] = None):
+                    bbox_center=None, img_w=None, img_h=None, out: Optional[Dict[str, torch.Tensor]] = None,
+                    record: Optional[torch.Tensor] = None):
         x = self._images(images)
         B, _, H, W = x.shape
         R, K, sc, ce, iw, ih = self._cam_args(B, cam_rotmat, cam_intrinsics, bbox_scale, bbox_center, img_w, img_h)
-        out = out if out is not None else self._hmr_outputs(B)
+        views = self._out_for(B, record)
+        out = views if views is not None else (out if out is not None else self._hmr_outputs(B))
         o = _lib.HmrOutputs(**{k: out[k].data_ptr() for k, _ in _lib.HmrOutputs._fields_})
         _lib.check(self.h, self.lib.specmi_hmr_forward(
             self.h, _ptr(x), B, H, W, _ptr(R), _ptr(K), _ptr(sc), _ptr(ce), _ptr(iw), _ptr(ih),
             C.byref(o), self._stream()))
         return out
 
-    def hmr_head(self, feat_nhwc, cam_rotmat=None, cam_intrinsics=None, img_h=None):
+    def hmr_regress(self, feat_nhwc, cam_rotmat=None, cam_intrinsics=None, bbox_scale=None, bbox_center=None,
+                    img_w=None, img_h=None, record: Optional[torch.Tensor] = None):
+        """Regressor head + SMPL head from a trunk feature map (hmr.py:94-122), one library call."""
+        f = _dev_f32(feat_nhwc, self.device)
+        B, fh, fw, _ = f.shape
+        R, K, sc, ce, iw, ih = self._cam_args(B, cam_rotmat, cam_intrinsics, bbox_scale, bbox_center, img_w, img_h)
+        views = self._out_for(B, record)
+        out = views if views is not None else self._hmr_outputs(B)
+        o = _lib.HmrOutputs(**{k: out[k].data_ptr() for k, _ in _lib.HmrOutputs._fields_})
+        _lib.check(self.h, self.lib.specmi_hmr_regress(
+            self.h, _ptr(f), B, fh, fw, _ptr(R), _ptr(K), _ptr(sc), _ptr(ce), _ptr(iw), _ptr(ih),
+            C.byref(o), self._stream()))
+        return out
+
+    def hmr_head(self, feat_nhwc, cam_rotmat=None, cam_intrinsics=None, img_h=None, record=None):
         f = _dev_f32(feat_nhwc, self.device)
         B, fh, fw, _ = f.shape
         R = _dev_f32(cam_rotmat, self.device, (B, 3, 3))
         K = _dev_f32(cam_intrinsics, self.device, (B, 3, 3))
         ih = _dev_f32(img_h, self.device, (B,))
         mk = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)
-        out = {'pred_pose': mk(B, 24, 3, 3), 'pred_shape': mk(B, 10), 'pred_cam': mk(B, 3),
-               'pred_pose_6d': mk(B, 144)}
+        views = self._out_for(B, record)
+        out = ({k: views[k] for k in ('pred_pose', 'pred_shape', 'pred_cam', 'pred_pose_6d')} if views is not None else
+               {'pred_pose': mk(B, 24, 3, 3), 'pred_shape': mk(B, 10), 'pred_cam': mk(B, 3), 'pred_pose_6d': mk(B, 144)})
         _lib.check(self.h, self.lib.specmi_hmr_head_forward(
             self.h, _ptr(f), B, fh, fw, _ptr(R), _ptr(K), _ptr(ih), _ptr(out['pred_pose']),
             _ptr(out['pred_shape']), _ptr(out['pred_cam']), _ptr(out['pred_pose_6d']), self._stream()))
         return out
 
     def smpl(self, rotmat, betas, cam, cam_rotmat=None, cam_intrinsics=None, bbox_scale=None,
-             bbox_center=None, img_w=None, img_h=None):
+             bbox_center=None, img_w=None, img_h=None, record=None):
         rot = _dev_f32(rotmat, self.device)
         B = rot.shape[0]
         rot = rot.reshape(B, 24, 3, 3).contiguous()
@@ -194,13 +271,33 @@ class Engine:
         cm = _dev_f32(cam, self.device, (B, 3))
         R, K, sc, ce, iw, ih = self._cam_args(B, cam_rotmat, cam_intrinsics, bbox_scale, bbox_center, img_w, img_h)
         mk = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)
-        out = {'smpl_vertices': mk(B, self.num_verts, 3), 'smpl_joints3d': mk(B, 49, 3),
-               'smpl_joints2d': mk(B, 49, 2), 'pred_cam_t': mk(B, 3)}
+        views = self._out_for(B, record)
+        out = ({k: views[k] for k in ('smpl_vertices', 'smpl_joints3d', 'smpl_joints2d', 'pred_cam_t')}
+               if views is not None else
+               {'smpl_vertices': mk(B, self.num_verts, 3), 'smpl_joints3d': mk(B, 49, 3),
+                'smpl_joints2d': mk(B, 49, 2), 'pred_cam_t': mk(B, 3)})
         _lib.check(self.h, self.lib.specmi_smpl_forward(
             self.h, _ptr(rot), _ptr(be), _ptr(cm), B, _ptr(R), _ptr(K), _ptr(sc), _ptr(ce), _ptr(iw),
             _ptr(ih), _ptr(out['smpl_vertices']), _ptr(out['smpl_joints3d']), _ptr(out['smpl_joints2d']),
             _ptr(out['pred_cam_t']), self._stream()))
         return out
+
+    def smpl_native(self, pose, betas, vertices=True, joints24=True):
+        """smplx-style body model call: ``pose`` (B,24,3,3) rotation matrices or (B,72) axis-angle; returns
+        (vertices (B,V,3) | None, joints24 (B,24,3) | None)."""
+        p = _dev_f32(pose, self.device)
+        B = p.shape[0]
+        aa = p.dim() == 2
+        if aa and p.shape[1] != 72 or not aa and tuple(p.shape[1:]) != (24, 3, 3):
+            raise ValueError(f'pose must be (B,72) axis-angle or (B,24,3,3) rotation matrices, got {tuple(p.shape)}')
+        be = _dev_f32(betas, self.device, (B, 10))
+        mk = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)
+        v = mk(B, self.num_verts, 3) if vertices else None
+        j = mk(B, 24, 3) if joints24 else None
+        self._set_ld('output_ld', 0)
+        _lib.check(self.h, self.lib.specmi_smpl_native(self.h, _ptr(p), int(aa), _ptr(be), B, _ptr(v), _ptr(j),
+                                                       self._stream()))
+        return v, j
 
     def conv2d(self, x, w_oihw, scale, shift, stride, pad, residual=None, relu=True, nchw_input=False):
         """Single fused layer (tests).  x NHWC device tensor (NCHW for the 7x7 stem)."""

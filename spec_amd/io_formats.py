@@ -7,8 +7,9 @@ files:
   reader ``spec/utils/cam_params.py:28-35`` which calls ``.item()`` on vfov/pitch/roll);
 * SPEC result pickle ``<out>/spec_results/<image stem>.pkl`` = joblib dump of the forward's
   output dict as NumPy arrays (``spec/tester.py:153-163``);
-* evaluation dump ``evaluation_results_<ds>.pkl`` (``spec/trainer.py:348-353,533-536``): the
-  accumulated ``pred_pose / pred_shape / pred_cam / pred_vertices`` lists.
+* evaluation dump ``evaluation_results_<ds>.pkl`` (``spec/trainer.py:118-135,348-353,533-536``): the
+  accumulated ``pose / shape / cam / vertices`` arrays (+ ``imgname``, ``dataset_name``, per-joint errors), read
+  back by ``compute_error`` (``spec/utils/compute_error.py:95-110``).
 """
 from __future__ import annotations
 
@@ -60,21 +61,36 @@ def write_spec_result(output_path: str, img_fname: str, output: Dict[str, torch.
 
 
 class EvalDump:
-    """Accumulates what ``validation_step`` stashes (spec/trainer.py:348-353) and writes
-    ``evaluation_results_<ds>.pkl`` like ``validation_epoch_end`` (:533-536)."""
-    KEYS = ('pred_pose', 'pred_shape', 'pred_cam', 'pred_vertices')
+    """Accumulates what ``validation_step`` stashes in ``self.evaluation_results`` (spec/trainer.py:118-135,
+    337-353) and writes ``evaluation_results_<ds>.pkl`` like ``validation_epoch_end`` (:533-536): keys ``imgname``,
+    ``dataset_name``, ``mpjpe``, ``pampjpe``, ``mpjpe_24``, ``pampjpe_24`` (per-joint errors, when given) and - with
+    ``TESTING.SAVE_RESULTS`` - ``pose`` (N,24,3,3), ``shape`` (N,10), ``cam`` (N,3), ``vertices`` (N,6890,3), the
+    array ``compute_error`` reads back (spec/utils/compute_error.py:108)."""
+    KEYS = ('pose', 'shape', 'cam', 'vertices')
 
     def __init__(self):
         self.data = {k: [] for k in self.KEYS}
+        self.meta = {'imgname': [], 'dataset_name': []}
+        self.errors = {}
 
-    def add(self, pred: Dict[str, torch.Tensor]):
-        self.data['pred_pose'].append(_np(pred['pred_pose']))
-        self.data['pred_shape'].append(_np(pred['pred_shape']))
-        self.data['pred_cam'].append(_np(pred['pred_cam']))
-        self.data['pred_vertices'].append(_np(pred['smpl_vertices']))
+    def add(self, pred: Dict[str, torch.Tensor], imgnames=None, dataset_name=None, **per_joint_errors):
+        self.data['pose'].append(_np(pred['pred_pose']))
+        self.data['shape'].append(_np(pred['pred_shape']))
+        self.data['cam'].append(_np(pred['pred_cam']))
+        self.data['vertices'].append(_np(pred['smpl_vertices']))
+        n = self.data['cam'][-1].shape[0]
+        if imgnames is not None:
+            self.meta['imgname'] += list(imgnames)
+            self.meta['dataset_name'] += [dataset_name] * n
+        for k, v in per_joint_errors.items():
+            self.errors.setdefault(k, []).append(_np(v))
 
     def write(self, log_dir: str, dataset_name: str) -> str:
         path = os.path.join(log_dir, f'evaluation_results_{dataset_name}.pkl')
         os.makedirs(log_dir, exist_ok=True)
-        joblib.dump({k: np.concatenate(v) for k, v in self.data.items() if v}, path)
+        out = {k: np.concatenate(v) for k, v in self.data.items() if v}
+        out.update({k: np.concatenate(v) for k, v in self.errors.items() if v})
+        if self.meta['imgname']:
+            out.update({k: np.array(v) for k, v in self.meta.items()})
+        joblib.dump(out, path)
         return path

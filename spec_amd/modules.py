@@ -162,10 +162,25 @@ class _EngineModule(nn.Module):
         self._engine = None
         self._sig = None
         self._frozen = False
+        self._tracked = None          # cached list of the parameter / buffer tensors (see _signature)
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
 
-    # parameters are re-uploaded when any tensor was replaced or modified in place
+    def _invalidate(self):
+        self._tracked = None
+        self._sig = None
+
+    def _apply(self, fn, *a, **k):    # .to() / .cuda() / .float() may replace the tensors
+        self._invalidate()
+        return super()._apply(fn, *a, **k)
+
+    # Parameters are re-uploaded when any tensor was replaced or modified in place.  The tensor list is cached
+    # (walking ~330 state_dict entries per forward matters at batch 1) and rebuilt after load_state_dict / _apply;
+    # the per-forward check is (data_ptr, _version) of the cached tensors.  In-place edits through ``.data`` do not
+    # bump ``_version`` and assigning a new nn.Parameter object is not seen by the cache: call ``commit()`` after either.
     def _signature(self):
-        return tuple((k, v.data_ptr(), v._version) for k, v in self.state_dict(keep_vars=True).items())
+        if self._tracked is None:
+            self._tracked = list(self.state_dict(keep_vars=True).values())
+        return tuple((v.data_ptr(), v._version) for v in self._tracked)
 
     def _options(self):
         return {}
@@ -188,6 +203,7 @@ class _EngineModule(nn.Module):
         sd = {k: v for k, v in self.state_dict().items()
               if not k.startswith('smpl.') and v.dtype.is_floating_point}
         self._engine.load(sd, smpl=self._smpl_model(), **self._options())
+        self._tracked = None
         self._sig = self._signature()
         self._frozen = freeze
         return self

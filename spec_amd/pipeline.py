@@ -31,10 +31,14 @@ class SpecPipeline:
     trunk's kernels with the other trunk's work and lets bandwidth-bound layers of one run
     beside MFMA-bound layers of the other."""
 
-    def __init__(self, camcalib, hmr, overlap: bool = True):
+    def __init__(self, camcalib, hmr, overlap: bool = True, packed: bool = True):
+        """``packed=True``: the kernels write every per-image output straight into ONE (B, 21294)-float record (the
+        all-gather payload of config 4); the returned tensors are views of it and ``out['record']`` is the record
+        itself, so collecting results over RCCL needs no packing copy."""
         self.camcalib = camcalib
         self.hmr = hmr
         self.overlap = overlap
+        self.packed = packed
         self._side = {}
 
     def _side_stream(self, device):
@@ -43,35 +47,50 @@ class SpecPipeline:
         return self._side[device]
 
     @torch.no_grad()
-    def __call__(self, images, bbox_scale, bbox_center, img_w, img_h, camcalib_images=None) -> Dict[str, torch.Tensor]:
+    def __call__(self, images, bbox_scale, bbox_center, img_w, img_h, camcalib_images=None,
+                 record: torch.Tensor = None) -> Dict[str, torch.Tensor]:
         """``images``: (B,3,224,224) crops for SPEC.  ``camcalib_images``: what CamCalib sees
-        (the full frame in the reference demo; defaults to the same crops, as in the benchmark)."""
+        (the full frame in the reference demo; defaults to the same crops, as in the benchmark).
+        ``record``: optional caller-owned (B, record_floats) fp32 tensor to write the packed outputs into."""
         cam_in = images if camcalib_images is None else camcalib_images
+        device = images.device
+        eng = self.hmr.engine(device)
+        angles = None
+        if record is None and self.packed and self.hmr.use_cam:
+            record = torch.empty(images.shape[0], eng.record_layout()[1], device=device, dtype=torch.float32)
+        if record is not None:
+            v = eng.record_views(record)
+            angles = (v['cam_vfov'], v['cam_pitch'], v['cam_roll'])
         if not (self.overlap and self.hmr.use_cam):
             logits = self.camcalib(cam_in)
-            cam = cam_utils.decode_camera(logits[0], logits[1], logits[2], img_h=img_h, img_w=img_w)
-            out = self.hmr(images, cam_rotmat=cam['cam_rotmat'], cam_intrinsics=cam['cam_intrinsics'],
-                           bbox_scale=bbox_scale, bbox_center=bbox_center, img_w=img_w, img_h=img_h)
+            cam = cam_utils.decode_camera(logits[0], logits[1], logits[2], img_h=img_h, img_w=img_w, angles_out=angles)
+            if self.hmr.use_cam:
+                out = eng.hmr_forward(images, cam['cam_rotmat'], cam['cam_intrinsics'], bbox_scale, bbox_center,
+                                      img_w, img_h, record=record)
+            else:
+                out = self.hmr(images, cam_rotmat=cam['cam_rotmat'], cam_intrinsics=cam['cam_intrinsics'],
+                               bbox_scale=bbox_scale, bbox_center=bbox_center, img_w=img_w, img_h=img_h)
         else:
-            device = images.device
             main = torch.cuda.current_stream(device)
             side = self._side_stream(device)
             side.wait_stream(main)                      # inputs were produced on the main stream
             with torch.cuda.stream(side):
                 logits = self.camcalib(cam_in)
-                cam = cam_utils.decode_camera(logits[0], logits[1], logits[2], img_h=img_h, img_w=img_w)
-            eng = self.hmr.engine(device)
+                cam = cam_utils.decode_camera(logits[0], logits[1], logits[2], img_h=img_h, img_w=img_w,
+                                              angles_out=angles)
             feat = eng.trunk(images)                    # SPEC trunk on the main stream, concurrently
             main.wait_stream(side)                      # the head needs (R, K)
             for v in cam.values():
                 if v is not None:
                     v.record_stream(main)
-            out = eng.hmr_head(feat, cam['cam_rotmat'], cam['cam_intrinsics'], img_h)
-            out.update(eng.smpl(out['pred_pose'], out['pred_shape'], out['pred_cam'], cam['cam_rotmat'],
-                                cam['cam_intrinsics'], bbox_scale, bbox_center, img_w, img_h))
+            out = eng.hmr_regress(feat, cam['cam_rotmat'], cam['cam_intrinsics'], bbox_scale, bbox_center, img_w, img_h,
+                                  record=record)
+        out = dict(out)
         out.update({'cam_vfov': cam['vfov'], 'cam_pitch': cam['pitch'], 'cam_roll': cam['roll'],
                     'cam_f_pix': cam['f_pix'], 'cam_rotmat': cam['cam_rotmat'],
                     'cam_intrinsics': cam['cam_intrinsics']})
+        if record is not None:
+            out['record'] = record
         return out
 
 
@@ -81,24 +100,36 @@ class GraphedPipeline:
     submission.  Inputs are copied into static buffers; outputs are the static output tensors
     (valid until the next call)."""
 
-    def __init__(self, pipeline: SpecPipeline, images, bbox_scale, bbox_center, img_w, img_h, warmup: int = 2):
+    def __init__(self, pipeline: SpecPipeline, images, bbox_scale, bbox_center, img_w, img_h, warmup: int = 2,
+                 buffers: int = 1):
+        """``buffers`` > 1 captures that many graphs, each writing its own static output set, replayed round-robin:
+        a consumer (e.g. the asynchronous all-gather of step s) may still read buffer s % buffers while step s+1
+        runs."""
         self.static_in = [t.clone() for t in (images, bbox_scale, bbox_center, img_w, img_h)]
         for _ in range(warmup):                      # allocates workspaces, sets kernel attributes
             pipeline(*self.static_in)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        # thread-local error mode: another thread's runtime calls (e.g. the RCCL watchdog's event queries in a
-        # multi-GPU job) must not invalidate this capture
-        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
-            self.static_out = pipeline(*self.static_in)
+        self.graphs, self.static_outs, self.turn = [], [], 0
+        for i in range(max(1, buffers)):
+            g = torch.cuda.CUDAGraph()
+            # thread-local error mode: another thread's runtime calls (e.g. the RCCL watchdog's event queries in a
+            # multi-GPU job) must not invalidate this capture
+            kw = {'pool': self.graphs[0].pool()} if self.graphs else {}
+            with torch.cuda.graph(g, capture_error_mode='thread_local', **kw):
+                out = pipeline(*self.static_in)
+            self.graphs.append(g)
+            self.static_outs.append(out)
+        self.graph, self.static_out = self.graphs[0], self.static_outs[0]
 
     @torch.no_grad()
     def __call__(self, images, bbox_scale, bbox_center, img_w, img_h):
         for dst, src in zip(self.static_in, (images, bbox_scale, bbox_center, img_w, img_h)):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src)
-        self.graph.replay()
-        return self.static_out
+        i = self.turn
+        self.turn = (i + 1) % len(self.graphs)
+        self.graphs[i].replay()
+        return self.static_outs[i]
 
 
 def shard_range(total: int, rank: int, world: int):
@@ -110,6 +141,11 @@ def shard_range(total: int, rank: int, world: int):
 
 
 def pack_outputs(out: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """The (B, record) tensor of a step: the record the kernels wrote (``SpecPipeline(packed=True)``, no copy), or a
+    concatenation when the outputs are separate tensors."""
+    rec = out.get('record')
+    if rec is not None and rec.is_contiguous():
+        return rec
     B = out['pred_cam'].shape[0]
     return torch.cat([out[k].reshape(B, -1) for k, _ in PACKED_KEYS], dim=1).contiguous()
 
@@ -146,10 +182,16 @@ class AsyncGather:
             self.results.append(full)
         self.last = full
 
-    def submit(self, out: Dict[str, torch.Tensor]):
-        import torch.distributed as dist
+    def reserve(self):
+        """Call BEFORE enqueueing a step whose output buffer may be one a pending collective still reads
+        (``GraphedPipeline(buffers=depth)`` reuses buffer s % depth): retires the oldest collectives until a slot is
+        free.  ``work.wait()`` makes the current stream wait, not the host."""
         while len(self.pending) >= self.depth:
             self._retire()
+
+    def submit(self, out: Dict[str, torch.Tensor]):
+        import torch.distributed as dist
+        self.reserve()
         packed = pack_outputs(out)
         world = dist.get_world_size(self.group)
         full = torch.empty(world * packed.shape[0], packed.shape[1], device=packed.device, dtype=packed.dtype)

@@ -40,6 +40,19 @@ def _worker(rank, world, port, total, q):
             ag.submit({k: v + 100.0 * step for k, v in out.items()})
         steps = ag.drain()
         ok = len(steps) == 5 and all(torch.equal(s_, full + 100.0 * i) for i, s_ in enumerate(steps))
+        # the graph-replay flow: records written IN PLACE into two alternating buffers; reserve() before a buffer is
+        # overwritten guarantees the collective that still reads it has finished
+        rec0 = pack_outputs(out)
+        bufs = [torch.empty_like(rec0), torch.empty_like(rec0)]
+        ag2 = AsyncGather(depth=2, keep_results=True)
+        for step in range(6):
+            ag2.reserve()
+            buf = bufs[step % 2]
+            buf.copy_(rec0 + 100.0 * step)                 # stands for the kernels writing the record
+            got = ag2.submit({'record': buf, 'pred_cam': out['pred_cam']})
+            assert got.shape[0] == world * rec0.shape[0]
+        steps2 = ag2.drain()
+        ok = ok and len(steps2) == 6 and all(torch.equal(s_, full + 100.0 * i) for i, s_ in enumerate(steps2))
         q.put((rank, full.numpy() if ok else None))
     finally:
         dist.destroy_process_group()

@@ -1,0 +1,87 @@
+"""BASELINE.json config 5 as far as it can be exercised without the licensed data: the whole evaluation flow
+(``scripts/spec_eval.py`` -> run_evaluation -> compute_error) over a stand-in ``data/`` tree written in the REAL
+container formats, against the CPU oracle's restatement of spec/utils/compute_error.py:89-223 - including the
+north-star criterion |delta W-MPJPE| < 0.1 mm."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import t
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+DEV = torch.device('cuda:0')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ('wv2v', 'v2v', 'wmpjpe', 'mpjpe', 'pampjpe', 'pampjpe_24', 'wmpjpe_24', 'mpjpe_24')
+
+
+def _oracle_models(gt):
+    from oracle import heads
+    from oracle.models import HMROracle, load_numpy_state
+    from oracle.smpl import SMPLOracle
+    heads.set_assets(smpl_model=gt['smpl_model'])
+    ohm = load_numpy_state(HMROracle(use_cam=True, use_cam_feats=True).eval(), gt['hmr_state'])
+    return ohm, SMPLOracle(gt['smpl_model'])
+
+
+def test_smpl_native_axis_angle_vs_oracle():
+    from oracle.smpl import SMPLOracle
+    from spec_amd import metrics, synth
+    model = synth.smpl_model(1003)
+    body = metrics.BodyModel(model, device=DEV)
+    rng = np.random.default_rng(5)
+    pose = (rng.standard_normal((9, 72)) * 0.4).astype(np.float32)
+    pose[0] = 0.0                          # |r + 1e-8| guard of batch_rodrigues
+    pose[1, :3] = [3.1, 0.0, 0.0]          # near pi
+    betas = (rng.standard_normal((9, 10)) * 0.8).astype(np.float32)
+    v, j = body.native(t(pose).to(DEV), t(betas).to(DEV))
+    ov, oj = SMPLOracle(model).native_axis_angle(t(betas), t(pose))
+    assert np.abs(v.cpu().numpy() - ov.numpy()).max() < 5e-6
+    assert np.abs(j.cpu().numpy() - oj[:, :24].numpy()).max() < 5e-6
+    # rotation-matrix input and the joints-only / vertices-only variants
+    from oracle.smpl import batch_rodrigues
+    R = batch_rodrigues(t(pose).reshape(-1, 3)).view(9, 24, 3, 3)
+    v2, j2 = body.native(R.to(DEV), t(betas).to(DEV))
+    assert np.abs(v2.cpu().numpy() - ov.numpy()).max() < 5e-6 and np.abs(j2.cpu().numpy() - oj[:, :24].numpy()).max() < 5e-6
+    assert body.native(R.to(DEV), t(betas).to(DEV), vertices=False)[0] is None
+
+
+@pytest.mark.parametrize('dataset', ['spec-syn', 'spec-mtp'])
+def test_c5_standin_flow_vs_oracle(tmp_path, dataset):
+    from oracle import metrics as OM
+    from spec_amd import assets, evaluation
+    d = str(tmp_path)
+    gt = evaluation.write_standin_data_tree(d, n_images=6, dataset=dataset)
+    hp = evaluation.load_config(os.path.join(d, 'data/spec/checkpoints/spec_config.yaml'))
+    lines = []
+    res = evaluation.run_evaluation(hp, data_root=d, log=lines.append)[dataset]
+    assert any('W-MPJPE-24' in l for l in lines) and any('README' in l for l in lines)
+    import joblib
+    ev = joblib.load(os.path.join(d, 'logs/eval_standin', f'evaluation_results_{dataset}.pkl'))
+    assert ev['vertices'].shape == (6, 6890, 3) and len(ev['imgname']) == 6
+    # oracle side: the same crops (the device crop has its own parity tests) through the CPU restatement
+    ohm, osmpl = _oracle_models(gt)
+    ds = evaluation.EvalDataset(dataset, d)
+    b = ds.batch(np.arange(6), DEV, 224, False)
+    pred = ohm(b['img'].cpu(), cam_rotmat=b['cam_rotmat'].cpu(), cam_intrinsics=b['cam_int'].cpu(),
+               bbox_scale=b['scale'].cpu(), bbox_center=b['center'].cpu(), img_w=b['img_w'].cpu(), img_h=b['img_h'].cpu())
+    assert np.abs(ev['vertices'] - pred['smpl_vertices'].numpy()).max() / np.abs(ev['vertices']).max() < 1e-4
+    pred_R = None if dataset == 'spec-syn' else joblib.load(os.path.join(d, f'data/camcalib/{dataset}_cam_rotmat.pkl'))
+    ref = OM.compute_error(pred['smpl_vertices'], ds.data, dataset, osmpl, np.load(os.path.join(d, 'data/J_regressor_h36m.npy')),
+                           pred_cam_rotmat=pred_R)
+    for k in KEYS:
+        diff = np.abs(res['per_sample'][k] - ref[k]).max()
+        assert diff < 0.05, (k, diff, res['per_sample'][k], ref[k])              # millimetres
+    assert abs(res['mean']['wmpjpe_24'] - ref['wmpjpe_24'].mean()) < 0.1          # BASELINE.json: W-MPJPE within 0.1 mm
+    assets.use_synthetic_assets(1003)
+
+
+def test_spec_eval_cli_standin(tmp_path):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'spec_eval.py'), '--standin', str(tmp_path)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert 'W-MPJPE-24:' in r.stdout and 'PA-MPJPE-24:' in r.stdout and 'W-V2V:' in r.stdout and 'README 74.9' in r.stdout

@@ -264,7 +264,7 @@ def test_eval_flow_synthetic(tmp_path):
     assert 0.5 < float(lines['W-MPJPE-24']) < 6.0 and 0.5 < float(lines['PA-MPJPE-24']) < 6.0
     assert 14.0 < float(lines['W-V2V']) < 18.0
     ev = joblib.load(os.path.join(str(tmp_path), 'evaluation_results_spec-syn.pkl'))
-    assert ev['pred_vertices'].shape == (96, 6890, 3) and ev['pred_pose'].shape == (96, 24, 3, 3)
+    assert ev['vertices'].shape == (96, 6890, 3) and ev['pose'].shape == (96, 24, 3, 3)
 
 
 # camcalib/model.py:84-101 (the reference's own ``test_model``): both trunks x {1,2,3} FC layers x {256,512,1024} hidden

@@ -29,9 +29,16 @@ def test_mesh_metrics_vs_reference_fixture():
     assert np.allclose(pa.cpu().numpy(), g['pampjpe'], rtol=1e-4)
     assert np.allclose(vv.cpu().numpy(), g['v2v'], rtol=1e-4)
     J24 = synth.smpl_model(int(g['seed_smpl']))['J_regressor']
-    mp24, pa24 = metrics.w_mpjpe_24(t(pr_v).to(DEV), t(gt_v).to(DEV), t(J24).to(DEV))
+    # the fixture's eval_j_24 inputs are einsum('bik,ji->bjk') regressions of both meshes (make_fixtures.py)
+    pj, gj = metrics.regress_joints(t(pr_v).to(DEV), t(J24).to(DEV)), metrics.regress_joints(t(gt_v).to(DEV), t(J24).to(DEV))
+    ref_pj = torch.einsum('bik,ji->bjk', t(pr_v), t(J24))
+    assert np.abs(pj.cpu().numpy() - ref_pj.numpy()).max() < 2e-6
+    mp24, pa24 = metrics.eval_j_24(pj, gj)
     assert np.allclose(mp24.cpu().numpy(), g['mpjpe24'], rtol=1e-4)
     assert np.allclose(pa24.cpu().numpy(), g['pampjpe24'], rtol=1e-4)
+    # W-MPJPE-24 (README metric): regressed prediction against GIVEN ground-truth joints
+    mp24b, _ = metrics.w_mpjpe_24(t(pr_v).to(DEV), gj, t(J24).to(DEV))
+    assert np.allclose(mp24b.cpu().numpy(), g['mpjpe24'], rtol=1e-4)
 
 
 @pytest.mark.parametrize('B,J', [(1, 14), (37, 24), (256, 17)])

@@ -30,11 +30,14 @@ def test_spec_result_and_eval_dump(tmp_path):
     assert p.endswith(os.path.join('spec_results', 'img_07.pkl'))                 # spec/tester.py:158-162
     back = joblib.load(p)
     assert all(isinstance(v, np.ndarray) for v in back.values()) and back['smpl_vertices'].shape == (2, 6890, 3)
-    d = F.EvalDump(); d.add(out); d.add(out)
+    d = F.EvalDump(); d.add(out, imgnames=['a.jpg', 'b.jpg'], dataset_name='spec-syn'); d.add(out, imgnames=['c.jpg', 'd.jpg'], dataset_name='spec-syn')
     q = d.write(str(tmp_path), 'spec-syn')
     assert os.path.basename(q) == 'evaluation_results_spec-syn.pkl'               # spec/trainer.py:533-536
     ev = joblib.load(q)
-    assert ev['pred_vertices'].shape == (4, 6890, 3) and set(ev) == {'pred_pose', 'pred_shape', 'pred_cam', 'pred_vertices'}
+    # the reference's evaluation_results keys (spec/trainer.py:118-135); compute_error reads ['vertices'] (compute_error.py:108)
+    assert ev['vertices'].shape == (4, 6890, 3) and ev['pose'].shape == (4, 24, 3, 3)
+    assert set(ev) == {'pose', 'shape', 'cam', 'vertices', 'imgname', 'dataset_name'}
+    assert list(ev['imgname']) == ['a.jpg', 'b.jpg', 'c.jpg', 'd.jpg']
 
 
 @pytest.mark.gpu

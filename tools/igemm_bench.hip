@@ -11,7 +11,6 @@
 #include "../spec_amd/csrc/conv_igemm.hip"
 
 using namespace specmi;
-namespace specmi { void conv_igemm_force_variant(int v); }
 static const char* PH[7] = {"issue", "mfma", "wait+store", "barrier", "prologue", "loop", "epilogue"};
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
@@ -55,7 +54,6 @@ int main(int argc, char** argv) {
     conv_igemm_set_ablate(ablate);
     unsigned long long* dtp; CK(hipMalloc(&dtp, 128));   // inputs are post-ReLU activations (as in the trunk)
     long long* dclk; CK(hipMalloc(&dclk, 16)); long long hclk[2];
-    conv_igemm_force_variant(variant);
     std::vector<Layer> layers = {
         {"l1.conv1  1x1  64->64  56", 64, 64, 1, 1, 56, 0, 1},
         {"l1.conv2  3x3  64->64  56", 64, 64, 3, 1, 56, 0, 3},
@@ -110,7 +108,7 @@ int main(int argc, char** argv) {
         if (L.res) { std::vector<float> hr(no); for (auto& v : hr) v = frand(seed); CK(hipMalloc(&dres, no * 4)); CK(hipMemcpy(dres, hr.data(), no * 4, hipMemcpyHostToDevice)); }
         ConvArgs a; a.x = dx; a.w = dp; a.scale = dsc; a.shift = dsh; a.res = dres; a.out = dout;
         a.B = B; a.H = H; a.W = W; a.Cin = L.cin; a.ldx = L.cin; a.OH = OH; a.OW = OW; a.Cout = L.cout; a.Npad = Npad; a.ldo = L.cout;
-        a.KH = L.k; a.KW = L.k; a.stride = L.stride; a.pad = pad; a.relu = 1;
+        a.KH = L.k; a.KW = L.k; a.stride = L.stride; a.pad = pad; a.relu = 1; a.force_variant = variant;
         LaunchCtx ctx{s, nullptr, "bench"};
         int rc = launch_conv_igemm(a, ctx); if (rc) { printf("launch failed %d\n", rc); return 1; }
         CK(hipStreamSynchronize(s));

@@ -42,7 +42,6 @@ int main(int argc, char** argv) {
     int check = argc > 2 ? atoi(argv[2]) : 1;
     int only = argc > 3 ? atoi(argv[3]) : -1;
     int variant = argc > 4 ? atoi(argv[4]) : 0;
-    conv_wino_force_variant(variant);
     conv_wino_set_persistent(argc > 5 ? atoi(argv[5]) : 1);
     std::vector<Layer> layers = {
         {"odd      3x3  16->128  7x9 ", 16, 128, 7, 9, 0, 3},
@@ -79,7 +78,7 @@ int main(int argc, char** argv) {
         ConvArgs a;
         a.x = dx; a.w = du; a.scale = ds; a.shift = db; a.res = nullptr; a.out = dout;
         a.B = b; a.H = L.h; a.W = L.w; a.Cin = L.cin; a.ldx = L.cin; a.OH = L.h; a.OW = L.w; a.Cout = L.cout;
-        a.Npad = L.cout; a.ldo = L.cout; a.KH = 3; a.KW = 3; a.stride = 1; a.pad = 1; a.relu = 1;
+        a.Npad = L.cout; a.ldo = L.cout; a.KH = 3; a.KW = 3; a.stride = 1; a.pad = 1; a.relu = 1; a.wino_variant = variant;
         LaunchCtx ctx{nullptr, nullptr, "bench"};
         int rc = launch_conv_wino(a, ctx);
         if (rc) { printf("launch failed rc=%d\n", rc); return 1; }
