@@ -247,9 +247,11 @@ def cpu_baseline(cs, hs, budget_s=22.0, batch=16):
 
     sweep = {}
     for nt in sorted({n for n in (8, 16, 32, 64, physical, logical) if 1 <= n <= logical}):
-        if time.perf_counter() - t_start > budget_s * 0.55:
+        if time.perf_counter() - t_start > budget_s * 0.5:
             break
         sweep[nt] = round(rate(nt, batch), 2)
+        if sweep[nt] < 0.6 * max(sweep.values()):      # past the knee: more threads only oversubscribe (SMT, NUMA)
+            break
     best_nt = max(sweep, key=sweep.get)
     torch.set_num_threads(best_nt)
     n, t0 = 0, time.perf_counter()
@@ -257,7 +259,7 @@ def cpu_baseline(cs, hs, budget_s=22.0, batch=16):
         full_pipeline(occ, ohm, x, sc, ce, iw, ih)
         n += batch
         el = time.perf_counter() - t0
-        if time.perf_counter() - t_start >= budget_s * 0.85 or n >= 10 * batch:
+        if time.perf_counter() - t_start >= budget_s * 0.85 or n >= 16 * batch:
             break
     best = n / el
     b1 = rate(best_nt, 1, reps=3)

@@ -77,7 +77,7 @@ def read_image_rgb(path: str) -> np.ndarray:
     """(H,W,3) uint8 RGB (the reference's ``read_img`` = cv2.imread + BGR->RGB)."""
     from PIL import Image
     with Image.open(path) as im:
-        return np.asarray(im.convert('RGB'))
+        return np.array(im.convert('RGB'))       # a writable copy (torch.from_numpy needs one)
 
 
 class EvalDataset:
