@@ -98,13 +98,18 @@ def cam_params(pitch, roll, f_pix, img_w, img_h):
 
 
 class HMROracle(nn.Module):
-    """spec/models/hmr.py:29-122 (resnet50 branch)."""
+    """spec/models/hmr.py:29-122 (resnet50 and the hrnet_w32 / hrnet_w48 '-conv' / '-interp' branches, :44-53)."""
 
     def __init__(self, backbone='resnet50', focal_length=5000., img_res=224, pretrained=None,
                  use_cam=False, p=0.0, estimate_var=False, use_separate_var_branch=False,
                  uncertainty_activation='', use_cam_feats=False):
         super().__init__()
-        self.backbone = ResNet50Trunk()
+        if backbone.startswith('hrnet'):
+            from . import hrnet
+            backbone, use_conv = backbone.split('-')                                  # :45
+            self.backbone = getattr(hrnet, backbone)(pretrained=True, downsample=True, use_conv=(use_conv == 'conv'))
+        else:
+            self.backbone = ResNet50Trunk()
         self.use_cam_feats = use_cam_feats
         self.head = HMRHead(num_input_features=get_backbone_info(backbone)['n_output_channels'],
                             backbone=backbone, use_cam_feats=use_cam_feats)

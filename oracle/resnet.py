@@ -127,5 +127,6 @@ def get_backbone_info(backbone):
     info = {
         'resnet18': {'n_output_channels': 512}, 'resnet34': {'n_output_channels': 512},
         'resnet50': {'n_output_channels': 2048}, 'resnet101': {'n_output_channels': 2048},
+        'hrnet_w32': {'n_output_channels': 480}, 'hrnet_w48': {'n_output_channels': 720},
     }
     return info[backbone]

@@ -5,88 +5,13 @@
 #include <cstdarg>
 #include <cstring>
 
-#include "specmi_internal.h"
+#include "handle.h"
 
 using namespace specmi;
 
-// ------------------------------------------------------------------------------------------
-// handle
-// ------------------------------------------------------------------------------------------
-struct HostTensor {
-    std::vector<float> f;
-    std::vector<int32_t> i;
-    std::vector<int64_t> shape;
-    bool is_int = false;
-    size_t numel() const { return is_int ? i.size() : f.size(); }
-};
+std::string g_create_err;
 
-struct ConvW {
-    std::string name;  // state-dict prefix of the conv ("layer1.0.conv1"), bn under bn_name
-    std::string bn_name;
-    int cin = 0, cout = 0, k = 1, stride = 1, pad = 0;
-    int Kp = 0, Npad = 0;
-    float *w = nullptr, *scale = nullptr, *shift = nullptr;  // device
-    float* wino = nullptr;  // device: Winograd-domain filters (3x3 stride-1 layers only)
-};
-
-struct Bneck {
-    ConvW c1, c2, c3, ds;
-    bool has_ds = false;
-    bool basic = false;   // torchvision BasicBlock (ResNet-18/34): c1 = 3x3 (stride), c2 = 3x3, no c3
-    // conv3 + bn3 and downsample conv + bn folded into ONE 1x1 GEMM over [conv2 output | block input]:
-    // weights pre-multiplied by the BN scales (fp64), shift = shift3 + shift_ds, scale = 1
-    float *f_w = nullptr, *f_scale = nullptr, *f_shift = nullptr;
-    int f_Npad = 0;
-};
-
-struct FcW {  // Linear layers as H=W=1 convolutions
-    int nin = 0, nout = 0, Kp = 0, Npad = 0;
-    float *w = nullptr, *scale = nullptr, *shift = nullptr;
-};
-
-struct specmi_handle {
-    int device = 0;
-    int kind = 0;
-    std::map<std::string, HostTensor> staged;
-    std::map<std::string, int> opt_i;
-    std::map<std::string, float> opt_f;
-    bool committed = false;
-    std::string err;
-
-    // packed parameters (device)
-    ConvW stem;
-    std::vector<Bneck> blocks;
-    FcW fc_cam[3][3];          // CamCalib: vfov, pitch, roll x up to 3 stacked Linear layers (camcalib/model.py:59-70: no activation between them)
-    int fc_layers = 1, feat_ch = 2048;
-    FcW fc1, fc2, dec;         // HMR head (dec = decpose|decshape|deccam)
-    FcW head_c;                // the 3 IEF iterations composed into ONE affine map [xf | cam feats] -> 157 (commit_head_collapsed)
-    bool has_head_c = false;
-    int xc_ld = 2240;          // row stride of the IEF state [xf (feat_ch) | pose6d | shape | cam | rot6d(R) | vfov | 0-pad]
-    float *init_pose = nullptr, *init_shape = nullptr, *init_cam = nullptr;
-    SmplDev smpl;
-    std::vector<void*> param_allocs;
-
-    // workspace (device), grown on demand
-    std::vector<void*> ws_allocs;
-    float* act[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t act_elems = 0;
-    float *xc = nullptr, *h1 = nullptr, *h2 = nullptr, *xf = nullptr;
-    float *rot_ws = nullptr, *betas_ws = nullptr, *cam_ws = nullptr, *verts_ws = nullptr;
-    float *pf_ws = nullptr, *A_ws = nullptr, *pj_ws = nullptr;
-    int ws_B = 0;
-    int* resize_tab = nullptr;          // device copy of the Pillow coefficient tables of the last resize geometry
-    size_t resize_tab_ints = 0;
-    std::vector<int> resize_host;       // host image of the same (kept alive for the async copy)
-    int resize_geom[4] = {0, 0, 0, 0};  // H, W, OH, OW the tables were built for
-    float *splitk_ws = nullptr, *zeros = nullptr;   // split-K partial tiles (own allocations: hipMalloc here is graph-unsafe, so done in ensure_ws)
-    size_t splitk_floats = 0;
-
-    Profiler prof;
-};
-
-static std::string g_create_err;
-
-static int fail(specmi_handle* h, int code, const char* fmt, ...) {
+int fail(specmi_handle* h, int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -96,28 +21,12 @@ static int fail(specmi_handle* h, int code, const char* fmt, ...) {
     return code;
 }
 
-#define HIPCHK(h, call)                                                                         \
-    do {                                                                                        \
-        hipError_t e__ = (call);                                                                \
-        if (e__ != hipSuccess)                                                                  \
-            return fail(h, SPECMI_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
-                        __FILE__, __LINE__);                                                    \
-    } while (0)
-
-#define LAUNCHCHK(h, rc, what)                                                                   \
-    do {                                                                                        \
-        int rc__ = (rc);                                                                        \
-        if (rc__ != 0)                                                                          \
-            return fail(h, SPECMI_ERR_HIP, "launch %s failed: %s", what,                        \
-                        hipGetErrorString((hipError_t)rc__));                                   \
-    } while (0)
-
-static int round_up(int x, int m) { return (x + m - 1) / m * m; }
+int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // ------------------------------------------------------------------------------------------
 // device memory helpers
 // ------------------------------------------------------------------------------------------
-static int dev_upload(specmi_handle* h, const void* src, size_t bytes, void** out, std::vector<void*>& pool) {
+int dev_upload(specmi_handle* h, const void* src, size_t bytes, void** out, std::vector<void*>& pool) {
     void* p = nullptr;
     HIPCHK(h, hipMalloc(&p, bytes ? bytes : 4));
     pool.push_back(p);
@@ -126,7 +35,7 @@ static int dev_upload(specmi_handle* h, const void* src, size_t bytes, void** ou
     return SPECMI_OK;
 }
 
-static int dev_alloc(specmi_handle* h, size_t bytes, void** out, std::vector<void*>& pool) {
+int dev_alloc(specmi_handle* h, size_t bytes, void** out, std::vector<void*>& pool) {
     void* p = nullptr;
     HIPCHK(h, hipMalloc(&p, bytes ? bytes : 4));
     pool.push_back(p);
@@ -134,7 +43,7 @@ static int dev_alloc(specmi_handle* h, size_t bytes, void** out, std::vector<voi
     return SPECMI_OK;
 }
 
-static void free_pool(std::vector<void*>& pool) {
+void free_pool(std::vector<void*>& pool) {
     for (void* p : pool) (void)hipFree(p);
     pool.clear();
 }
@@ -169,12 +78,12 @@ static void fold_bn(const float* gamma, const float* beta, const float* mean, co
     }
 }
 
-static const HostTensor* find(specmi_handle* h, const std::string& name) {
+const HostTensor* find(specmi_handle* h, const std::string& name) {
     auto it = h->staged.find(name);
     return it == h->staged.end() ? nullptr : &it->second;
 }
 
-static int need(specmi_handle* h, const std::string& name, std::initializer_list<int64_t> shape, bool is_int,
+int need(specmi_handle* h, const std::string& name, std::initializer_list<int64_t> shape, bool is_int,
                 const HostTensor** out) {
     const HostTensor* t = find(h, name);
     if (!t) return fail(h, SPECMI_ERR_MISSING, "missing tensor '%s'", name.c_str());
@@ -188,7 +97,7 @@ static int need(specmi_handle* h, const std::string& name, std::initializer_list
     return SPECMI_OK;
 }
 
-static int commit_conv(specmi_handle* h, const std::string& prefix, ConvW& c) {
+int commit_conv(specmi_handle* h, const std::string& prefix, ConvW& c) {
     const HostTensor *w, *g, *b, *m, *v;
     int rc;
     if ((rc = need(h, prefix + c.name + ".weight", {c.cout, c.cin, c.k, c.k}, false, &w))) return rc;
@@ -197,23 +106,40 @@ static int commit_conv(specmi_handle* h, const std::string& prefix, ConvW& c) {
     if ((rc = need(h, prefix + c.bn_name + ".running_mean", {c.cout}, false, &m))) return rc;
     if ((rc = need(h, prefix + c.bn_name + ".running_var", {c.cout}, false, &v))) return rc;
     std::vector<float> packed, scale, shift;
-    if (c.cin == 3) {
+    const int cin = c.cin_p > 0 ? c.cin_p : c.cin, cout = c.cout_p > 0 ? c.cout_p : c.cout;
+    const float* wsrc = w->f.data();
+    std::vector<float> wpad;
+    if (cin != c.cin || cout != c.cout) {   // zero-padded OIHW copy: the layer is then an ordinary (cin_p -> cout_p) conv
+        wpad.assign((size_t)cout * cin * c.k * c.k, 0.f);
+        for (int n = 0; n < c.cout; ++n)
+            for (int ci = 0; ci < c.cin; ++ci)
+                std::memcpy(wpad.data() + ((size_t)n * cin + ci) * c.k * c.k, wsrc + ((size_t)n * c.cin + ci) * c.k * c.k,
+                            (size_t)c.k * c.k * 4);
+        wsrc = wpad.data();
+    }
+    if (c.cin == 3 && c.k == 7) {
         c.Kp = 148;
         c.Npad = 64;
-        pack_stem_weights(w->f.data(), packed);
+        pack_stem_weights(wsrc, packed);
+    } else if (c.cin == 3) {                // small-Cin direct convolution (hrnet.hip): plain [k = (ci*KH + ky)*KW + kx][cout]
+        c.Kp = 3 * c.k * c.k;
+        c.Npad = cout;
+        packed.assign((size_t)c.Kp * cout, 0.f);
+        for (int n = 0; n < cout; ++n)
+            for (int k = 0; k < c.Kp; ++k) packed[(size_t)k * cout + n] = wsrc[(size_t)n * c.Kp + k];
     } else {
-        c.Kp = c.cin * c.k * c.k;
-        c.Npad = round_up(c.cout, 64);
-        pack_gemm_weights(w->f.data(), c.cout, c.cin, c.k, c.k, c.Kp, c.Npad, packed);
+        c.Kp = cin * c.k * c.k;
+        c.Npad = round_up(cout, 64);
+        pack_gemm_weights(wsrc, cout, cin, c.k, c.k, c.Kp, c.Npad, packed);
     }
-    fold_bn(g->f.data(), b->f.data(), m->f.data(), v->f.data(), c.cout, 1e-5f, c.Npad, scale, shift);
+    fold_bn(g->f.data(), b->f.data(), m->f.data(), v->f.data(), c.cout, 1e-5f, c.Npad > cout ? c.Npad : cout, scale, shift);
     if ((rc = dev_upload(h, packed.data(), packed.size() * 4, (void**)&c.w, h->param_allocs))) return rc;
     if ((rc = dev_upload(h, scale.data(), scale.size() * 4, (void**)&c.scale, h->param_allocs))) return rc;
     if ((rc = dev_upload(h, shift.data(), shift.size() * 4, (void**)&c.shift, h->param_allocs))) return rc;
     c.wino = nullptr;
-    if (c.k == 3 && c.stride == 1 && c.pad == 1 && c.cin % 16 == 0 && c.cout % 64 == 0) {
+    if (c.k == 3 && c.stride == 1 && c.pad == 1 && cin % 16 == 0 && cout % 64 == 0) {
         std::vector<float> u;
-        pack_wino_weights(w->f.data(), c.cout, c.cin, u);
+        pack_wino_weights(wsrc, cout, cin, u);
         if ((rc = dev_upload(h, u.data(), u.size() * 4, (void**)&c.wino, h->param_allocs))) return rc;
     }
     return SPECMI_OK;
@@ -404,11 +330,11 @@ static void build_resnet(specmi_handle* h, int depth) {
     h->feat_ch = inplanes;
 }
 
-static int opt_i(specmi_handle* h, const char* name, int dflt) {
+int opt_i(specmi_handle* h, const char* name, int dflt) {
     auto it = h->opt_i.find(name);
     return it == h->opt_i.end() ? dflt : it->second;
 }
-static float opt_f(specmi_handle* h, const char* name, float dflt) {
+float opt_f(specmi_handle* h, const char* name, float dflt) {
     auto it = h->opt_f.find(name);
     return it == h->opt_f.end() ? dflt : it->second;
 }
@@ -473,7 +399,7 @@ static int commit_smpl(specmi_handle* h) {
 // ------------------------------------------------------------------------------------------
 // workspace
 // ------------------------------------------------------------------------------------------
-static int conv_out(int x, int k, int s, int p) { return (x + 2 * p - k) / s + 1; }
+int conv_out(int x, int k, int s, int p) { return (x + 2 * p - k) / s + 1; }
 
 static int ensure_ws(specmi_handle* h, int B, int H, int W) {
     const int oh1 = conv_out(H, 7, 2, 3), ow1 = conv_out(W, 7, 2, 3);
@@ -605,6 +531,11 @@ static int run_trunk(specmi_handle* h, const float* images, int B, int H, int W,
     int rc;
     if (H < 32 || W < 32) return fail(h, SPECMI_ERR_ARG, "image size %dx%d too small", H, W);
     if ((rc = ensure_ws(h, B, H, W))) return rc;
+    if (h->hrnet) {
+        if ((rc = hrnet_forward(h, images, B, H, W, feat_out, fh, fw, s))) return rc;
+        *feat = feat_out ? feat_out : hrnet_feat_ws(h);
+        return SPECMI_OK;
+    }
     std::vector<TrunkOp> ops;
     std::vector<int> stage_of;   // resnet stage (0 = stem/pool, 1..4) of each op
     const int oh1 = conv_out(H, 7, 2, 3), ow1 = conv_out(W, 7, 2, 3);
@@ -792,6 +723,7 @@ int specmi_destroy(specmi_handle* h) {
     free_pool(h->ws_allocs);
     free_pool(h->param_allocs);
     if (h->resize_tab) (void)hipFree(h->resize_tab);
+    hrnet_free(h->hrnet);
     delete h;
     return SPECMI_OK;
 }
@@ -849,17 +781,26 @@ int specmi_commit(specmi_handle* h) {
     }
     const std::string bp = "backbone.";
     const int depth = opt_i(h, "backbone", 50);
-    if (depth != 50 && depth != 34) return fail(h, SPECMI_ERR_ARG, "backbone %d: resnet50 and resnet34 are built", depth);
-    if (depth != 50 && h->kind != SPECMI_MODEL_CAMCALIB)
-        return fail(h, SPECMI_ERR_ARG, "the HMR regressor is built for the resnet50 trunk (2048 features) only");
-    build_resnet(h, depth);
-    if ((rc = commit_conv(h, bp, h->stem))) return rc;
-    for (Bneck& b : h->blocks) {
-        if ((rc = commit_conv(h, bp, b.c1))) return rc;
-        if ((rc = commit_conv(h, bp, b.c2))) return rc;
-        if (!b.basic && (rc = commit_conv(h, bp, b.c3))) return rc;
-        if (b.has_ds && (rc = commit_conv(h, bp, b.ds))) return rc;
-        if (!b.basic && b.has_ds && b.c3.cin % 32 == 0 && b.ds.cin % 32 == 0 && (rc = commit_fused_ds(h, bp, b))) return rc;
+    if (depth != 50 && depth != 34 && depth != 32 && depth != 48)
+        return fail(h, SPECMI_ERR_ARG, "backbone %d: resnet50 (50), resnet34 (34), hrnet_w32 (32) and hrnet_w48 (48) are built", depth);
+    if (depth == 34 && h->kind != SPECMI_MODEL_CAMCALIB)
+        return fail(h, SPECMI_ERR_ARG, "the reference builds HMR on resnet50 or hrnet_w32 / w48 (spec/models/hmr.py:44-53)");
+    if ((depth == 32 || depth == 48) && h->kind != SPECMI_MODEL_HMR)
+        return fail(h, SPECMI_ERR_ARG, "the HRNet trunks belong to HMR (camcalib/model.py:33 builds resnet trunks only)");
+    if (h->hrnet) { hrnet_free(h->hrnet); h->hrnet = nullptr; }
+    if (depth == 32 || depth == 48) {
+        h->blocks.clear();
+        if ((rc = hrnet_commit(h, bp, depth, opt_i(h, "hrnet_use_conv", 1)))) return rc;
+    } else {
+        build_resnet(h, depth);
+        if ((rc = commit_conv(h, bp, h->stem))) return rc;
+        for (Bneck& b : h->blocks) {
+            if ((rc = commit_conv(h, bp, b.c1))) return rc;
+            if ((rc = commit_conv(h, bp, b.c2))) return rc;
+            if (!b.basic && (rc = commit_conv(h, bp, b.c3))) return rc;
+            if (b.has_ds && (rc = commit_conv(h, bp, b.ds))) return rc;
+            if (!b.basic && b.has_ds && b.c3.cin % 32 == 0 && b.ds.cin % 32 == 0 && (rc = commit_fused_ds(h, bp, b))) return rc;
+        }
     }
     if (h->kind == SPECMI_MODEL_CAMCALIB) {
         // camcalib/model.py:39-57: one Linear per angle, or Sequential(Linear x num_fc_layers) WITHOUT activations

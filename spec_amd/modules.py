@@ -97,6 +97,80 @@ def resnet34(pretrained=False, **kwargs):
     return ResNet34Params()
 
 
+# ---- HRNet-W32 / W48 (pare.models.backbone.hrnet as HMR builds it, spec/models/hmr.py:44-51) -------------------
+def _cbn(cin, cout, k, stride, relu=False, extra=None):
+    """Sequential(conv, bn[, relu][, extra]) - index layout of the upstream state_dict ('.0' conv, '.1' bn)."""
+    mods = [nn.Conv2d(cin, cout, k, stride, 1 if k == 3 else 0, bias=False), nn.BatchNorm2d(cout)]
+    if relu:
+        mods.append(nn.ReLU(inplace=True))
+    if extra is not None:
+        mods.append(extra)
+    return nn.Sequential(*mods)
+
+
+class _HRModuleParams(nn.Module):
+    """HighResolutionModule: ``branches.{b}.{k}.(conv1|bn1|conv2|bn2)`` and ``fuse_layers.{i}.{j}...``."""
+
+    def __init__(self, channels):
+        super().__init__()
+        nb = len(channels)
+        self.branches = nn.ModuleList([nn.Sequential(*[_BasicBlockParams(c, c, 1, False) for _ in range(4)]) for c in channels])
+        fuse = []
+        for i in range(nb):
+            row = []
+            for j in range(nb):
+                if j > i:
+                    row.append(_cbn(channels[j], channels[i], 1, 1, extra=nn.Upsample(scale_factor=2 ** (j - i), mode='nearest')))
+                elif j == i:
+                    row.append(None)
+                else:
+                    row.append(nn.Sequential(*[_cbn(channels[j], channels[i] if k == i - j - 1 else channels[j], 3, 2,
+                                                    relu=(k != i - j - 1)) for k in range(i - j)]))
+            fuse.append(nn.ModuleList(row))
+        self.fuse_layers = nn.ModuleList(fuse)
+
+
+class HRNetParams(nn.Module):
+    """Parameter container with the upstream PoseHighResolutionNet key layout (downsample=True head)."""
+
+    def __init__(self, width=32, use_conv=True):
+        super().__init__()
+        C = [width, width * 2, width * 4, width * 8]
+        self.width, self.use_conv = width, use_conv
+        self.conv1 = nn.Conv2d(3, 64, 3, 2, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.conv2 = nn.Conv2d(64, 64, 3, 2, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(64)
+        self.layer1 = nn.Sequential(*[_BottleneckParams(64 if b == 0 else 256, 64, 1, downsample=(b == 0)) for b in range(4)])
+        self.transition1 = nn.ModuleList([_cbn(256, C[0], 3, 1, relu=True), nn.Sequential(_cbn(256, C[1], 3, 2, relu=True))])
+        self.stage2 = nn.Sequential(_HRModuleParams(C[:2]))
+        self.transition2 = nn.ModuleList([None, None, nn.Sequential(_cbn(C[1], C[2], 3, 2, relu=True))])
+        self.stage3 = nn.Sequential(*[_HRModuleParams(C[:3]) for _ in range(4)])
+        self.transition3 = nn.ModuleList([None, None, None, nn.Sequential(_cbn(C[2], C[3], 3, 2, relu=True))])
+        self.stage4 = nn.Sequential(*[_HRModuleParams(C) for _ in range(3)])
+        if use_conv:
+            for d, n in enumerate((3, 2, 1)):
+                mods = []
+                for _ in range(n):
+                    mods += [nn.Conv2d(C[d], C[d], 3, 2, 1, bias=False), nn.BatchNorm2d(C[d]), nn.ReLU(inplace=True)]
+                setattr(self, f'downsample_stage_{d + 1}', nn.Sequential(*mods))
+
+    def forward(self, *a, **k):
+        raise RuntimeError('HRNetParams only holds parameters; the trunk runs inside libspecmi')
+
+
+def hrnet_w32(pretrained=False, downsample=True, use_conv=True, **kwargs):
+    if not downsample:
+        raise NotImplementedError('HMR builds the HRNet trunks with downsample=True (spec/models/hmr.py:47-50)')
+    return HRNetParams(32, use_conv)
+
+
+def hrnet_w48(pretrained=False, downsample=True, use_conv=True, **kwargs):
+    if not downsample:
+        raise NotImplementedError('HMR builds the HRNet trunks with downsample=True (spec/models/hmr.py:47-50)')
+    return HRNetParams(48, use_conv)
+
+
 def resnet50(pretrained=False, **kwargs):
     """Name looked up by the reference via ``eval(backbone)`` (hmr.py:53, camcalib/model.py:33).
     ``pretrained`` never touches the network here; weights come from a checkpoint."""
@@ -104,7 +178,10 @@ def resnet50(pretrained=False, **kwargs):
 
 
 def get_backbone_info(backbone):
-    return {'resnet50': {'n_output_channels': 2048}, 'resnet34': {'n_output_channels': 512}}[backbone]
+    """pare.models.backbone.utils.get_backbone_info: the trunk's feature width (HRNet, downsample=True head: the four
+    branches concatenated, 32+64+128+256 / 48+96+192+384)."""
+    return {'resnet50': {'n_output_channels': 2048}, 'resnet34': {'n_output_channels': 512},
+            'hrnet_w32': {'n_output_channels': 480}, 'hrnet_w48': {'n_output_channels': 720}}[backbone]
 
 
 class HMRHeadParams(nn.Module):
@@ -278,11 +355,23 @@ class HMR(_EngineModule):
                  p=0.0, estimate_var=False, use_separate_var_branch=False, uncertainty_activation='',
                  use_cam_feats=False):
         super().__init__()
-        if backbone != 'resnet50':
-            raise NotImplementedError(f'backbone {backbone!r}: only resnet50 (the released model) is built')
         if estimate_var:
-            raise NotImplementedError('estimate_var is a training-only option')
-        self.backbone = resnet50(pretrained=True)
+            raise NotImplementedError('estimate_var (uncertainty outputs of HMRHead) is a training-time option the '
+                                      'inference callers never set (spec/tester.py:53-59, spec/trainer.py:50-56)')
+        self._hrnet_use_conv = 1
+        if backbone.startswith('hrnet'):                       # hrnet_w32-conv, hrnet_w32-interp (hmr.py:44-51)
+            backbone, use_conv = backbone.split('-')
+            if backbone not in ('hrnet_w32', 'hrnet_w48'):
+                raise NotImplementedError(f'backbone {backbone!r}: hrnet_w32 and hrnet_w48 are built')
+            self._hrnet_use_conv = int(use_conv == 'conv')
+            self.backbone = (hrnet_w32 if backbone == 'hrnet_w32' else hrnet_w48)(pretrained=True, downsample=True,
+                                                                                  use_conv=(use_conv == 'conv'))
+            self._backbone_id = 32 if backbone == 'hrnet_w32' else 48
+        elif backbone == 'resnet50':
+            self.backbone = resnet50(pretrained=True)
+            self._backbone_id = 50
+        else:
+            raise NotImplementedError(f'backbone {backbone!r}: resnet50, hrnet_w32-(conv|interp), hrnet_w48-(conv|interp) are built')
         self.use_cam_feats = use_cam_feats
         self.head = HMRHeadParams(get_backbone_info(backbone)['n_output_channels'], use_cam_feats)
         self.use_cam = use_cam
@@ -298,7 +387,8 @@ class HMR(_EngineModule):
 
     def _options(self):
         return {'use_cam': int(self.use_cam), 'use_cam_feats': int(self.use_cam_feats),
-                'img_res': int(self.img_res), 'focal_length': float(self.focal_length)}
+                'img_res': int(self.img_res), 'focal_length': float(self.focal_length),
+                'backbone': self._backbone_id, 'hrnet_use_conv': self._hrnet_use_conv}
 
     def _smpl_model(self):
         return self.smpl.smpl.as_model()

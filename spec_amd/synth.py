@@ -143,6 +143,44 @@ def resnet34_state(seed: int, prefix: str = '') -> 'OrderedDict[str, np.ndarray]
     return sd
 
 
+def hrnet_state(seed: int, width: int = 32, use_conv: bool = True, prefix: str = '') -> 'OrderedDict[str, np.ndarray]':
+    """Random HRNet-W32 / W48 trunk parameters in the upstream key layout (``spec_amd.modules.HRNetParams``); He-normal
+    convolutions, BatchNorm scales damped on the residual branches and on the exchange-unit terms so that activations
+    stay O(1) through the 8 modules."""
+    import torch.nn as nn
+    from .modules import HRNetParams
+    net = HRNetParams(width, use_conv)
+    sd = OrderedDict()
+    for name, m in net.named_modules():
+        if isinstance(m, nn.Conv2d):
+            cout, cin, k, _ = m.weight.shape
+            sd[f'{prefix}{name}.weight'] = normal(seed, name + '.weight', (cout, cin, k, k), std=math.sqrt(2.0 / (cin * k * k)))
+        elif isinstance(m, nn.BatchNorm2d):
+            n = m.num_features
+            last = name.rsplit('.', 1)[-1]
+            if 'fuse_layers' in name:
+                # chain members followed by a ReLU keep gain 1; the member that enters the sum is damped
+                parts = name.split('.')
+                i, j = int(parts[3]), int(parts[4])
+                if j < i:
+                    k = int(parts[5])
+                    g0 = 0.3 if k == i - j - 1 else 1.0
+                else:
+                    g0 = 0.3
+            elif last in ('bn2', 'bn3') and ('branches' in name or name.startswith('layer1')):
+                g0 = 0.25 if (last == 'bn3' or 'branches' in name) else 1.0
+            elif name.endswith('downsample.1'):
+                g0 = 0.7
+            else:
+                g0 = 1.0
+            sd[f'{prefix}{name}.weight'] = (g0 * (1.0 + 0.1 * normal(seed, name + '.weight', (n,)))).astype(np.float32)
+            sd[f'{prefix}{name}.bias'] = normal(seed, name + '.bias', (n,), std=0.05)
+            sd[f'{prefix}{name}.running_mean'] = normal(seed, name + '.running_mean', (n,), std=0.1)
+            sd[f'{prefix}{name}.running_var'] = uniform(seed, name + '.running_var', (n,), 0.8, 1.2)
+            sd[f'{prefix}{name}.num_batches_tracked'] = np.array(0, dtype=np.int64)
+    return sd
+
+
 def camcalib_state(seed: int = 1001, fc_std: float = 0.05, nbins: int = C.NUM_CAMCALIB_BINS, backbone: str = 'resnet50',
                    num_fc_layers: int = 1, num_fc_channels: int = 1024):
     """CameraRegressorNetwork parameters (camcalib/model.py:40-70 layout): one Linear per angle, or the
@@ -173,10 +211,18 @@ def _random_rot6d(seed, name, n):
     return out.reshape(-1).astype(np.float32)
 
 
-def hmr_state(seed: int = 1002, use_cam_feats: bool = True, dec_gain: float = 1.0):
-    """HMR parameters: trunk + HMRHead (fc1, fc2, decpose, decshape, deccam, init_*)."""
-    sd = resnet50_state(seed, 'backbone.')
-    nin = 2048 + 144 + 13 + (7 if use_cam_feats else 0)
+def hmr_state(seed: int = 1002, use_cam_feats: bool = True, dec_gain: float = 1.0, backbone: str = 'resnet50'):
+    """HMR parameters: trunk + HMRHead (fc1, fc2, decpose, decshape, deccam, init_*).  ``backbone``: 'resnet50' or
+    'hrnet_w32-conv' / 'hrnet_w32-interp' / 'hrnet_w48-...' (spec/models/hmr.py:44-53)."""
+    if backbone.startswith('hrnet'):
+        name, mode = backbone.split('-')
+        width = 32 if name == 'hrnet_w32' else 48
+        sd = hrnet_state(seed, width, mode == 'conv', 'backbone.')
+        feat = width * 15
+    else:
+        sd = resnet50_state(seed, 'backbone.')
+        feat = 2048
+    nin = feat + 144 + 13 + (7 if use_cam_feats else 0)
 
     def linear(name, nout, nin_, bound=None, bias_bound=None):
         bound = (1.0 / math.sqrt(nin_)) if bound is None else bound

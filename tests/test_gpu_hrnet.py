@@ -1,0 +1,99 @@
+"""HRNet-W32 / W48 trunks under the HMR regressor (spec/models/hmr.py:44-51: 'hrnet_w32-conv', 'hrnet_w32-interp', ...)
+against the CPU oracle's restatement of PARE's PoseHighResolutionNet, through the drop-in nn.Module and the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from spec_amd import synth
+from tests.util import rel_err, smpl_model, t
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+DEV = 'cuda:0'
+
+
+def _models(backbone, use_cam=True, ucf=True, seed=1202):
+    from oracle import heads
+    from oracle.models import HMROracle, load_numpy_state
+    from spec_amd import assets
+    from spec_amd.modules import HMR
+    hs = synth.hmr_state(seed, ucf, backbone=backbone)
+    assets.use_synthetic_assets(1003)
+    heads.set_assets(smpl_model=smpl_model())
+    hm = HMR(backbone=backbone, use_cam=use_cam, use_cam_feats=ucf)
+    missing, unexpected = hm.load_state_dict({k: t(v) for k, v in hs.items()}, strict=False)
+    assert not unexpected and all(m.startswith('smpl.') for m in missing), (missing[:5], unexpected[:5])
+    ohm = load_numpy_state(HMROracle(backbone=backbone, use_cam=use_cam, use_cam_feats=ucf).eval(), hs)
+    return hm.to(DEV).eval(), ohm
+
+
+def test_hrnet_state_dict_layout_matches_upstream_naming():
+    """Key list of the parameter container == key list of the oracle's PoseHighResolutionNet (strict load both ways)."""
+    from oracle.hrnet import hrnet_w32, hrnet_w48
+    from spec_amd.modules import HRNetParams, get_backbone_info
+    for width, ctor in ((32, hrnet_w32), (48, hrnet_w48)):
+        for use_conv in (True, False):
+            a = list(HRNetParams(width, use_conv).state_dict().keys())
+            b = list(ctor(use_conv=use_conv).state_dict().keys())
+            assert a == b
+            assert 'transition2.2.0.0.weight' in a and 'stage4.2.fuse_layers.3.0.2.1.running_var' in a
+            assert ('downsample_stage_1.6.weight' in a) == use_conv
+    assert get_backbone_info('hrnet_w32')['n_output_channels'] == 480
+    assert get_backbone_info('hrnet_w48')['n_output_channels'] == 720
+
+
+@pytest.mark.parametrize('backbone,B,H,W', [('hrnet_w32-conv', 2, 224, 224), ('hrnet_w32-interp', 2, 224, 224),
+                                            ('hrnet_w48-conv', 1, 224, 224), ('hrnet_w48-interp', 2, 96, 160)])
+def test_hrnet_trunk_vs_oracle(backbone, B, H, W):
+    hm, ohm = _models(backbone)
+    x = t(synth.images(61, B))[:, :, :H, :W].contiguous()
+    feat = hm.engine(torch.device(DEV)).trunk(x.to(DEV)).cpu()
+    ref = ohm.backbone(x).permute(0, 2, 3, 1)
+    assert feat.shape == ref.shape and feat.shape[-1] == (480 if 'w32' in backbone else 720)
+    err = rel_err(feat.numpy(), ref.numpy())
+    assert err < 5e-5, err
+
+
+def test_hrnet_rejects_sizes_the_reference_cannot_fuse():
+    hm, _ = _models('hrnet_w32-conv')
+    from spec_amd._lib import SpecmiError
+    with pytest.raises(SpecmiError):
+        hm.engine(torch.device(DEV)).trunk(torch.zeros(1, 3, 200, 224, device=DEV))
+
+
+@pytest.mark.parametrize('backbone,use_cam,ucf', [('hrnet_w32-conv', True, True), ('hrnet_w32-interp', True, False),
+                                                  ('hrnet_w48-conv', False, False)])
+def test_hmr_hrnet_end_to_end_vs_oracle(backbone, use_cam, ucf):
+    hm, ohm = _models(backbone, use_cam, ucf)
+    B = 3
+    x = t(synth.images(62, B))
+    sc, ce, iw, ih = [t(a) for a in synth.bbox_inputs(62, B, 640., 480.)]
+    kw, okw = {}, {}
+    if use_cam:
+        from spec_amd.cam_utils import cam_params_from_angles
+        R, K = cam_params_from_angles(np.array([0.1, -0.2, 0.3], np.float32), np.array([0.05, 0.1, -0.1], np.float32),
+                                      np.array([500., 700., 900.], np.float32), iw, ih)
+        kw = dict(cam_rotmat=R, cam_intrinsics=K, bbox_scale=sc.to(DEV), bbox_center=ce.to(DEV), img_w=iw.to(DEV), img_h=ih.to(DEV))
+        okw = dict(cam_rotmat=R.cpu(), cam_intrinsics=K.cpu(), bbox_scale=sc, bbox_center=ce, img_w=iw, img_h=ih)
+    out = hm(x.to(DEV), **kw)
+    ref = ohm(x, **okw)
+    assert set(out.keys()) == set(ref.keys())
+    for k in ref:
+        err = rel_err(out[k].cpu().numpy(), ref[k].numpy())
+        assert err < 1e-4, (k, err)
+    # collapsed regressor (default) vs the nine-GEMM loop on the 480 / 720-feature head
+    eng = hm.engine(torch.device(DEV))
+    eng.set_option('head_collapse', 0)
+    out_i = hm(x.to(DEV), **kw)
+    eng.set_option('head_collapse', 1)
+    for k in ('pred_pose_6d', 'smpl_vertices'):
+        assert rel_err(out[k].cpu().numpy(), out_i[k].cpu().numpy()) < 2e-5, k
+
+
+def test_hrnet_batch_invariance():
+    hm, _ = _models('hrnet_w32-conv')
+    x = t(synth.images(63, 5)).to(DEV)
+    eng = hm.engine(torch.device(DEV))
+    full = eng.trunk(x).clone()
+    one = eng.trunk(x[3:4])
+    assert torch.equal(one[0], full[3])
