@@ -290,6 +290,8 @@ def main():
     ap.add_argument('--force-variant', type=int, default=0, help='debug: force a conv tile (1:128x128 2:128x64 3:64x64)')
     ap.add_argument('--graph', action='store_true', help='(default) capture the step in a hipGraph and replay it')
     ap.add_argument('--no-graph', action='store_true', help='launch the ~120 kernels of a step eagerly')
+    ap.add_argument('--dist', action='store_true', help='run the N > 1 code path (torch.distributed.run launch, RCCL process '
+                                                        'group, asynchronous all-gather, two record buffers) even with --gpus 1')
     ap.add_argument('--subbatch', type=int, default=-1, help='trunk sub-batch for the early stages (0 = off, -1 = library default)')
     ap.add_argument('--subbatch-layers', type=int, default=-1)
     args = ap.parse_args()
@@ -297,7 +299,7 @@ def main():
     if args.gpus < 1:
         log('[bench] ERROR: --gpus must be >= 1')
         sys.exit(2)
-    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+    if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or args.dist):
         sys.exit(self_launch(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -312,10 +314,12 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        os.environ.setdefault('MASTER_PORT', '29531')
+        dist.init_process_group('nccl', device_id=device, rank=rank, world_size=world)
 
     from spec_amd.pipeline import SpecPipeline, AsyncGather, gather_outputs
     torch.set_grad_enabled(False)
@@ -336,7 +340,7 @@ def main():
     # while the kernels of step s+1 run (at most 2 in flight; everything is drained inside the timed region).  The
     # kernels write the record in place; under graph replay two record buffers alternate so that step s+1 never
     # writes the buffer the collective of step s still reads.
-    gather = AsyncGather(depth=2) if world > 1 else None
+    gather = AsyncGather(depth=2) if use_dist else None
 
     run = pipe
     launch_mode = 'eager launches'
@@ -345,7 +349,7 @@ def main():
         # (+1 % at B=256).  Same kernels, same work; falls back to eager launches if capture is unavailable.
         try:
             from spec_amd.pipeline import GraphedPipeline
-            run = GraphedPipeline(pipe, x, scale, center, img_w, img_h, buffers=2 if world > 1 else 1)
+            run = GraphedPipeline(pipe, x, scale, center, img_w, img_h, buffers=2 if use_dist else 1)
             launch_mode = 'hipGraph replay'
         except Exception as e:
             log('[bench] hipGraph capture failed, launching eagerly:', repr(e))
@@ -361,7 +365,7 @@ def main():
 
     def timed(nsteps):
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -370,7 +374,7 @@ def main():
         if gather is not None:
             gather.drain()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         return time.perf_counter() - t0
@@ -382,7 +386,7 @@ def main():
     local_elapsed = timed(args.steps)
     elapsed = local_elapsed
     per_rank = None
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([local_elapsed], device=device, dtype=torch.float64)
         allt = torch.empty(world, device=device, dtype=torch.float64)
         dist.all_gather_into_tensor(allt, tt)
@@ -396,7 +400,7 @@ def main():
     if not args.no_sustained:
         n_sus = max(args.steps, int(math.ceil(args.sustained_seconds / (ms_per_step * 1e-3))))
         el = timed(n_sus)
-        if world > 1:
+        if use_dist:
             tt = torch.tensor([el], device=device, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
@@ -405,7 +409,7 @@ def main():
 
     # ---- N > 1: the collective alone ------------------------------------------------------------------------
     comm = None
-    if world > 1:
+    if use_dist:
         out = pipe(x, scale, center, img_w, img_h)
         torch.cuda.synchronize()
         dist.barrier()
@@ -512,7 +516,7 @@ def main():
             'stages': stages,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()          # rank 0 may still be in its profiling pass
         dist.destroy_process_group()
 

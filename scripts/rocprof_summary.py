@@ -80,7 +80,9 @@ def traffic(dbs):
         out.update(main)
         out['correction'] = 'read = 2 x FETCH_SIZE (gfx950 counts 64 B per 128-B request), write = WRITE_SIZE'
     fams = {}
-    for name, pat in (('conv_wino_f32', 'conv_wino'), ('stem_conv7x7', 'stem_conv7x7'), ('maxpool3x3s2', 'maxpool')):
+    for name, pat in (('conv_igemm_f32<128x128>', 'conv_igemm_f32_kernel<128, 128'), ('conv_igemm_f32<64x64>', 'conv_igemm_f32_kernel<64, 64'),
+                      ('conv_wino_f32', 'conv_wino'), ('stem_conv7x7', 'stem_conv7x7'), ('maxpool3x3s2', 'maxpool'),
+                      ('smpl_skin', 'smpl_skin')):
         r = family(pat)
         if r:
             fams[name] = r

@@ -221,6 +221,31 @@ def test_two_rank_rccl_gather_matches_unsharded():
     assert 'RCCL_GATHER_OK' in r.stdout
 
 
+@pytest.mark.timeout(900)
+def test_single_rank_rccl_path():
+    """The N > 1 machinery with one rank (always runnable on a 1-GPU box): torch.distributed.run launch, RCCL process
+    group, in-place records, graph replay with two record buffers, asynchronous all-gather."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'rccl_gather_check.py'), '--gpus', '1'], env=env,
+                       capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert 'RCCL_GATHER_OK world=1' in r.stdout
+
+
+@pytest.mark.timeout(900)
+def test_bench_dist_path_single_rank():
+    """bench.py --gpus 1 --dist: the multi-GPU bench flow (self-launch, RCCL, AsyncGather, comm block) on one rank."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--dist', '--steps', '3', '--warmup', '1',
+                        '--batch', '32', '--no-cpu-baseline', '--no-profile', '--no-c2', '--sustained-seconds', '0.2'],
+                       capture_output=True, text=True, timeout=850, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 1 and line['comm']['backend'] == 'nccl' and line['comm']['world_size'] == 1
+    assert line['comm']['record_bytes_per_image'] == 85176 and line['value'] > 0
+    assert line['config']['launch'] == 'hipGraph replay'
+
+
 def test_bench_refuses_more_gpus_than_visible():
     n = torch.cuda.device_count() + 1
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--steps', '1', '--warmup', '0'],
