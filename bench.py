@@ -285,6 +285,7 @@ def main():
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--no-sustained', action='store_true', help='skip the >= 5 s sustained region')
     ap.add_argument('--sustained-seconds', type=float, default=5.0)
+    ap.add_argument('--no-small-batch', action='store_true', help='skip the batch-1 / batch-8 latency lines')
     ap.add_argument('--no-c2', action='store_true', help='skip the config-2 line (CamCalib trunk only, batch 64)')
     ap.add_argument('--no-overlap', action='store_true', help='run CamCalib and SPEC back to back on one stream')
     ap.add_argument('--force-variant', type=int, default=0, help='debug: force a conv tile (1:128x128 2:128x64 3:64x64)')
@@ -492,6 +493,31 @@ def main():
               'batch': 64, 'steps': n2, 'ms_per_step': round(ms2, 3), 'images_per_s': round(64e3 / ms2, 1),
               'algorithmic_TFLOPs': round(tf2, 2), 'frac_of_mfma_peak_algorithmic': round(tf2 / PEAK_FP32_MFMA_TFLOPS, 4)}
 
+    # ---- small batches: latency of one whole step (2 streams + hipGraph replay) ------------------------------------
+    small = None
+    if rank == 0 and not args.no_small_batch and not args.no_graph:
+        small = []
+        try:
+            from spec_amd.pipeline import GraphedPipeline
+            for b in (1, 8):
+                g = GraphedPipeline(pipe, x[:b].contiguous(), scale[:b].contiguous(), center[:b].contiguous(),
+                                    img_w[:b].contiguous(), img_h[:b].contiguous())
+                ins = g.static_in
+                for _ in range(5):
+                    g(*ins)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(50):
+                    g(*ins)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 50
+                small.append({'batch': b, 'ms_per_step': round(ms, 3), 'images_per_s': round(b * 1e3 / ms, 1)})
+                del g
+        except Exception as e:
+            log('[bench] small-batch latency failed:', repr(e))
+
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         try:
@@ -512,7 +538,7 @@ def main():
                        'streams': 1 if args.no_overlap else 2, 'launch': launch_mode,
                        'parallelism': (f'images sharded over {n_gpus} GPUs (one process per GPU), 1 asynchronous RCCL '
                                        f'all-gather of the packed records per step') if n_gpus > 1 else 'single GPU'},
-            'roofline': roof, 'cpu_baseline': cpu, 'sustained': sustained, 'c2': c2, 'comm': comm,
+            'roofline': roof, 'cpu_baseline': cpu, 'sustained': sustained, 'c2': c2, 'small_batch': small, 'comm': comm,
             'stages': stages,
         }
         print(json.dumps(line), flush=True)

@@ -448,19 +448,27 @@ static int ensure_ws(specmi_handle* h, int B, int H, int W) {
 // ------------------------------------------------------------------------------------------
 static int run_fc(specmi_handle* h, const FcW& fc, const float* x, int ldx, int B, const float* res, float* out,
                   int ldo, hipStream_t s, const char* label) {
-    ConvArgs a;
-    a.x = x; a.w = fc.w; a.scale = fc.scale; a.shift = fc.shift; a.res = res; a.out = out;
-    a.B = B; a.H = 1; a.W = 1; a.Cin = fc.Kp; a.ldx = ldx;
-    a.OH = 1; a.OW = 1; a.Cout = fc.nout; a.Npad = fc.Npad; a.ldo = ldo;
-    a.KH = 1; a.KW = 1; a.stride = 1; a.pad = 0; a.relu = 0;
-    a.force_variant = opt_i(h, "force_conv_variant", 0);
-    LaunchCtx ctx{s, &h->prof, label};
-    const int S = opt_i(h, "fc_splitk", 1) ? conv_igemm_splitk_plan(a) : 1;
-    if (S > 1 && h->splitk_ws && h->zeros && (size_t)S * B * fc.Npad <= h->splitk_floats && fc.Npad <= 4096) {
-        LAUNCHCHK(h, launch_conv_igemm_splitk(a, S, h->splitk_ws, fc.scale, h->zeros, ctx), label);   // fc.scale is all ones
-        return SPECMI_OK;
+    // Rows are processed in blocks of at most 1024 so that the K slicing (and with it the summation order of every
+    // output) is the same for every batch size: an image's result must not depend on how many images share its launch
+    // (rank-sharded 8 x 256 == unsharded 2048, bit for bit).
+    constexpr int RB = 1024;
+    for (int b0 = 0; b0 < B; b0 += RB) {
+        const int nb = B - b0 < RB ? B - b0 : RB;
+        ConvArgs a;
+        a.x = x + (size_t)b0 * ldx; a.w = fc.w; a.scale = fc.scale; a.shift = fc.shift;
+        a.res = res ? res + (size_t)b0 * ldo : nullptr; a.out = out + (size_t)b0 * ldo;
+        a.B = nb; a.H = 1; a.W = 1; a.Cin = fc.Kp; a.ldx = ldx;
+        a.OH = 1; a.OW = 1; a.Cout = fc.nout; a.Npad = fc.Npad; a.ldo = ldo;
+        a.KH = 1; a.KW = 1; a.stride = 1; a.pad = 0; a.relu = 0;
+        a.force_variant = opt_i(h, "force_conv_variant", 0);
+        LaunchCtx ctx{s, &h->prof, label};
+        const int S = opt_i(h, "fc_splitk", 1) ? conv_igemm_splitk_plan(a) : 1;
+        if (S > 1 && h->splitk_ws && h->zeros && (size_t)S * nb * fc.Npad <= h->splitk_floats && fc.Npad <= 4096) {
+            LAUNCHCHK(h, launch_conv_igemm_splitk(a, S, h->splitk_ws, fc.scale, h->zeros, ctx), label);   // fc.scale is all ones
+            continue;
+        }
+        LAUNCHCHK(h, launch_conv_igemm(a, ctx), label);
     }
-    LAUNCHCHK(h, launch_conv_igemm(a, ctx), label);
     return SPECMI_OK;
 }
 

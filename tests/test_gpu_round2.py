@@ -118,6 +118,33 @@ def test_graphed_pipeline_two_buffers(models):
     assert torch.equal(c, pipe(x2, sc, ce, iw, ih)['record'])
 
 
+def test_c4_shape_shards_equal_unsharded(models):
+    """BASELINE.json config 4 at its full size on one GPU: a global batch of 2048 cut into the 8 contiguous rank-major
+    shards of ``shard_range`` (256 images each, what rank r of an 8-GPU job runs), processed one after the other and
+    concatenated like the all-gather does, equals the unsharded forward of all 2048 images bit for bit."""
+    from spec_amd.pipeline import SpecPipeline, shard_range
+    cc, hm = models
+    total, world = 2048, 8
+    x16 = t(synth.images(71, 16)).to(DEV)
+    b16 = [t(a).to(DEV) for a in synth.bbox_inputs(71, 16, 640., 480.)]
+    rep = lambda a: a.repeat(*([total // 16] + [1] * (a.dim() - 1))).contiguous()
+    x, (sc, ce, iw, ih) = rep(x16), [rep(a) for a in b16]
+    pipe = SpecPipeline(cc, hm, overlap=True)
+    shards = []
+    for r in range(world):
+        lo, hi = shard_range(total, r, world)
+        assert hi - lo == 256
+        shards.append(pipe(x[lo:hi], sc[lo:hi], ce[lo:hi], iw[lo:hi], ih[lo:hi])['record'].clone())
+    gathered = torch.cat(shards, 0)
+    full = pipe(x, sc, ce, iw, ih)['record']
+    torch.cuda.synchronize()
+    assert gathered.shape == (2048, 21294) and torch.isfinite(full).all()
+    assert torch.equal(gathered, full)
+    assert torch.equal(full[16:32], full[0:16])                  # the 16 distinct crops repeat
+    del shards, gathered, full
+    torch.cuda.empty_cache()
+
+
 # ---- collapsed IEF regressor ------------------------------------------------------------------------------
 @pytest.mark.parametrize('tag,use_cam,ucf', [('camfeats', True, True), ('cam', True, False), ('nocam', False, False)])
 def test_collapsed_regressor_vs_iterative_and_fixture(tag, use_cam, ucf):
