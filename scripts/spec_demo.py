@@ -1,21 +1,21 @@
 #!/usr/bin/env python
-"""Build-owned counterpart of the reference's ``scripts/spec_demo.py`` flow on MI355X:
+"""The reference's ``scripts/spec_demo.py`` on MI355X - same command line, same ``SPECTester`` calls, same files:
 
-    frame -> CamCalib (vfov, pitch, roll) -> decode -> (R, K) -> crop detections on device ->
-    SPEC (HMR regressor + SMPL + projection) -> result pickles in the reference's formats.
+    python scripts/spec_demo.py --image_folder data/sample_images --output_folder logs/spec/sample_images \\
+        [--cfg data/spec/checkpoints/spec_config.yaml] [--ckpt data/spec/checkpoints/spec_checkpoint.ckpt] \\
+        --detections boxes.pkl
 
-Differences by design: CamCalib runs in-process (no ``os.system`` subprocess, spec/tester.py:86-88),
-crops are cut on the device, nothing is rendered.  The person detector (YOLOv3 + tracker,
-spec/tester.py:73-84) is out of scope: boxes come from ``--detections`` (joblib dict
-``{image name: (n,4) [cx, cy, w, h]}``) or default to one centred square box per frame.
+    frame -> CamCalib (vfov, pitch, roll) -> <out>/camcalib/<name>.pkl -> (R, K) -> crops on the device ->
+    SPEC (HMR regressor + SMPL + projection) -> <out>/spec_results/<stem>.pkl
 
-    python scripts/spec_demo.py --image_folder imgs --output_folder out \
-        --ckpt data/spec/checkpoints/spec_checkpoint.ckpt --camcalib_ckpt data/camcalib/checkpoints/camcalib_sa_biased_l2.ckpt
-    python scripts/spec_demo.py --synthetic 4 --output_folder /tmp/out      # random frames + random weights
-"""
+Differences by design (see spec_amd/tester.py): CamCalib runs in-process, crops are cut on the device, the person detector and
+the renderer are outside the path - boxes come from ``--detections`` (joblib: list per image or {image name: (n,4) [cx, cy, w,
+h]}); without it one centred square box per frame is used.  ``--synthetic N`` runs the same flow on N random frames with random
+weights (no licensed assets needed)."""
 import argparse
 import os
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -24,80 +24,93 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-
-def camcalib_input(frame_u8, min_size=600, device='cuda'):
-    """ImageFolder transform of camcalib/pano_dataset.py:156-162 (Resize(min side 600) of the PIL image,
-    ToTensor, ImageNet Normalize) on the device: the uint8 frame goes to HBM once and
-    ``specmi_resize_normalize`` reproduces Pillow's resample bit for bit."""
-    from spec_amd.preprocess import camcalib_transform
-    return camcalib_transform(torch.from_numpy(np.ascontiguousarray(frame_u8)).to(device), min_size)
+CFG = 'data/spec/checkpoints/spec_config.yaml'
+CKPT = 'data/spec/checkpoints/spec_checkpoint.ckpt'
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--image_folder', type=str, default=None)
-    ap.add_argument('--output_folder', type=str, default='logs/demo_results')
-    ap.add_argument('--ckpt', type=str, default=None, help='SPEC Lightning checkpoint')
-    ap.add_argument('--camcalib_ckpt', type=str, default=None)
-    ap.add_argument('--detections', type=str, default=None)
-    ap.add_argument('--synthetic', type=int, default=0, help='run on N random frames with random weights')
-    ap.add_argument('--no_save', action='store_true')
-    args = ap.parse_args()
+def default_boxes(image_folder):
+    from PIL import Image
+    from spec_amd.tester import list_images
+    out = []
+    for f in list_images(image_folder):
+        with Image.open(f) as im:
+            W, H = im.size
+        out.append(np.array([[W / 2, H / 2, 0.8 * min(H, W), 0.8 * min(H, W)]], np.float32))
+    return out
 
-    from spec_amd import assets, synth, io_formats, cam_utils
-    from spec_amd.checkpoint import load_pretrained_model, read_checkpoint
-    from spec_amd.modules import HMR, CameraRegressorNetwork
-    from spec_amd.preprocess import crop_detections
+
+def main(args):
+    from spec_amd.tester import SPECTester
     torch.set_grad_enabled(False)
-    dev = torch.device('cuda')
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
-
+    if args.mode != 'folder':
+        raise NotImplementedError                                    # as in the reference (video / webcam)
+    tmp = None
     if args.synthetic:
-        assets.use_synthetic_assets(1003)
-        cc = CameraRegressorNetwork(); cc.load_state_dict({k: t(v) for k, v in synth.camcalib_state(1001).items()})
-        hm = HMR(use_cam=True, use_cam_feats=True); hm.load_state_dict({k: t(v) for k, v in synth.hmr_state(1002, True).items()}, strict=False)
-        rng = np.random.default_rng(0)
-        frames = {f'synthetic_{i:03d}.jpg': (rng.random((480, 640, 3)) * 255).astype(np.uint8) for i in range(args.synthetic)}
-    else:
         from PIL import Image
-        assets.load_assets()
-        cc = CameraRegressorNetwork(backbone='resnet50', num_fc_layers=1, num_fc_channels=1024)
-        load_pretrained_model(cc, read_checkpoint(args.camcalib_ckpt)['state_dict'], remove_lightning=True, strict=True)
-        hm = HMR(backbone='resnet50', img_res=224, pretrained=None, use_cam_feats=True, use_cam=True)
-        load_pretrained_model(hm, read_checkpoint(args.ckpt)['state_dict'], overwrite_shape_mismatch=True, remove_lightning=True)
-        names = sorted(f for f in os.listdir(args.image_folder) if f.lower().endswith(('.png', '.jpg', '.jpeg')))
-        frames = {n: np.asarray(Image.open(os.path.join(args.image_folder, n)).convert('RGB')) for n in names}
-    cc.to(dev).eval().commit(dev, freeze=True)
-    hm.to(dev).eval().commit(dev, freeze=True)
-    dets_all = None
-    if args.detections:
-        import joblib
-        dets_all = joblib.load(args.detections)
+        from spec_amd import assets, synth
+        from spec_amd.modules import CameraRegressorNetwork
+        tmp = tempfile.TemporaryDirectory()
+        rng = np.random.default_rng(0)
+        for i in range(args.synthetic):
+            Image.fromarray((rng.random((480, 640, 3)) * 255).astype(np.uint8)).save(os.path.join(tmp.name, f'synthetic_{i:03d}.jpg'))
+        args.image_folder = tmp.name
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+        assets.use_synthetic_assets(1003)
+        cc = CameraRegressorNetwork()
+        cc.load_state_dict({k: t(v) for k, v in synth.camcalib_state(1001).items()})
+        args.camcalib_model = cc.to('cuda').eval()
+        args.ckpt = {'model.' + k: t(v) for k, v in synth.hmr_state(1002, True).items()}
+        args.cfg = os.path.join(tmp.name, 'spec_config.yaml')          # what the released spec_config.yaml sets
+        with open(args.cfg, 'w') as f:
+            f.write('METHOD: hmr_cam\nHMR:\n  BACKBONE: resnet50\n  USE_CAM_FEATS: true\nDATASET:\n  IMG_RES: 224\n')
+        output_path = args.output_folder
+    else:
+        input_image_folder = args.image_folder
+        output_path = os.path.join(args.output_folder, input_image_folder.rstrip('/').split('/')[-1] + '_' + args.exp)
+    os.makedirs(output_path, exist_ok=True)
+    output_img_folder = os.path.join(output_path, 'spec_results')
+    os.makedirs(output_img_folder, exist_ok=True)
+    num_frames = len(os.listdir(args.image_folder))
 
-    t0, nimg, nper = time.time(), 0, 0
-    for name, frame in frames.items():
-        H, W = frame.shape[:2]
-        # ---- CamCalib on the whole frame (scripts/camcalib_demo.py:95-140)
-        logits = cc(camcalib_input(frame).to(dev))
-        dets = dets_all[name] if dets_all is not None else np.array([[W / 2, H / 2, 0.8 * min(H, W), 0.8 * min(H, W)]], np.float32)
-        n = len(dets)
-        if n < 1:
-            continue
-        img_h = torch.full((1,), float(H), device=dev); img_w = torch.full((1,), float(W), device=dev)
-        cam = cam_utils.decode_camera(logits[0], logits[1], logits[2], img_h=img_h, img_w=img_w)
-        # ---- crops on the device (spec/tester.py:116-128) and SPEC forward (:143-151)
-        crops = crop_detections(t(frame).to(dev), t(np.asarray(dets, np.float32)).to(dev), scale=1.0, crop_size=224)
-        out = hm(crops['inp_images'], cam_rotmat=cam['cam_rotmat'].repeat(n, 1, 1),
-                 cam_intrinsics=cam['cam_intrinsics'].repeat(n, 1, 1), bbox_scale=crops['bbox_scale'],
-                 bbox_center=crops['bbox_center'], img_w=img_w.repeat(n), img_h=img_h.repeat(n))
-        if not args.no_save:
-            io_formats.write_camcalib_result(args.output_folder, name, cam['vfov'][0], cam['pitch'][0], cam['roll'][0], H)
-            io_formats.write_spec_result(args.output_folder, name, out)
-        nimg += 1; nper += n
+    total_time = time.time()
+    tester = SPECTester(args)
+    print(f'Number of input frames {num_frames}')
+    tester.run_camcalib(args.image_folder, output_path)                       # CamCalib
+    detections = tester.run_detector(args.image_folder) if args.detections else default_boxes(args.image_folder)
+    spec_time = time.time()
+    tester.run_on_image_folder(args.image_folder, detections, output_path, output_img_folder)
     torch.cuda.synchronize()
-    dt = time.time() - t0
-    print(f'SPEC FPS: {nimg / dt:.2f} frames/s, {nper / dt:.2f} persons/s over {nimg} frames (results in {args.output_folder})')
+    end = time.time()
+    print(f'SPEC FPS: {num_frames / (end - spec_time):.2f}')
+    total_time = time.time() - total_time
+    print(f'Total time spent: {total_time:.2f} seconds (including model loading time).')
+    print(f'Total FPS (including model loading time): {num_frames / total_time:.2f}.')
+    print('================= END =================')
+    if tmp is not None:
+        tmp.cleanup()
 
 
 if __name__ == '__main__':
-    main()
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--cfg', type=str, help='config file that defines model hyperparams', default=CFG)
+    parser.add_argument('--ckpt', type=str, help='checkpoint path', default=CKPT)
+    parser.add_argument('--camcalib_ckpt', type=str, default=None, help='CamCalib checkpoint (default: the path in scripts/camcalib_demo.py)')
+    parser.add_argument('--exp', type=str, default='', help='short description of the experiment')
+    parser.add_argument('--mode', default='folder', choices=['video', 'folder', 'webcam'], help='Demo type')
+    parser.add_argument('--vid_file', type=str, help='input video path or youtube link')
+    parser.add_argument('--image_folder', type=str, help='input image folder')
+    parser.add_argument('--output_folder', type=str, default='logs/demo/demo_results', help='output folder to write results')
+    parser.add_argument('--detections', type=str, default=None, help='joblib file with the person boxes (the detector is outside the path)')
+    parser.add_argument('--tracking_method', type=str, default='bbox', choices=['bbox', 'pose'])
+    parser.add_argument('--detector', type=str, default='yolo', choices=['yolo', 'maskrcnn'])
+    parser.add_argument('--yolo_img_size', type=int, default=416)
+    parser.add_argument('--tracker_batch_size', type=int, default=12)
+    parser.add_argument('--batch_size', type=int, default=16, help='batch size of SPEC')
+    parser.add_argument('--display', action='store_true')
+    parser.add_argument('--smooth', action='store_true')
+    parser.add_argument('--no_render', action='store_true', help='(rendering is never done by this build)')
+    parser.add_argument('--no_save', action='store_true', help='disable final save of output results.')
+    parser.add_argument('--save_obj', action='store_true')
+    parser.add_argument('--sideview', action='store_true')
+    parser.add_argument('--synthetic', type=int, default=0, help='run on N random frames with random weights')
+    main(parser.parse_args())

@@ -198,7 +198,7 @@ def write_standin_data_tree(root: str, n_images: int = 6, seed: int = 7, dataset
     rng = np.random.default_rng(seed)
     j = lambda *p: os.path.join(root, *p)
     for d in ('data/body_models/smpl', 'data/spec/checkpoints', f'data/dataset_folders/{dataset}/annotations',
-              f'data/dataset_folders/{dataset}/images', 'data/camcalib'):
+              f'data/dataset_folders/{dataset}/images', 'data/camcalib/checkpoints', 'data/sample_images'):
         os.makedirs(j(d), exist_ok=True)
     model = synth.smpl_model(smpl_seed)
     V = model['v_template'].shape[0]
@@ -274,6 +274,13 @@ def write_standin_data_tree(root: str, n_images: int = 6, seed: int = 7, dataset
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+    # CamCalib Lightning checkpoint (scripts/camcalib_demo.py:39,80-81: strict load after stripping 'model.')
+    cs = synth.camcalib_state(1001)
+    torch.save({'epoch': 26, 'global_step': 337742,
+                'state_dict': {'model.' + k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in cs.items()}},
+               j('data/camcalib/checkpoints/camcalib_sa_biased_l2.ckpt'))
+    for i in range(2):                                             # data/sample_images of the demo (README.md:100-104)
+        Image.fromarray((rng.random((300, 420, 3)) * 255).astype(np.uint8)).save(j('data/sample_images', f'im{i}.png'))
     with open(j('data/spec/checkpoints/spec_config.yaml'), 'w') as f:
         yaml.safe_dump({'METHOD': 'hmr_cam', 'LOG_DIR': 'logs/eval_standin',
                         'DATASET': {'BATCH_SIZE': 4, 'VAL_DS': dataset, 'IMG_RES': 224},
@@ -309,4 +316,4 @@ def write_standin_data_tree(root: str, n_images: int = 6, seed: int = 7, dataset
         import joblib
         joblib.dump(torch.from_numpy(Rgt), j(f'data/camcalib/{dataset}_cam_rotmat.pkl'))
     np.savez(j(DATASET_FILES[dataset]), **ann)
-    return {'annotations': ann, 'smpl_model': model, 'hmr_state': hs, 'frame_hw': (H, W)}
+    return {'annotations': ann, 'smpl_model': model, 'hmr_state': hs, 'camcalib_state': cs, 'frame_hw': (H, W)}

@@ -1,0 +1,161 @@
+"""``SPECTester`` on MI355X - the class ``scripts/spec_demo.py`` of the reference drives (``spec/tester.py:39-176``),
+with the same constructor argument (an argparse namespace: ``cfg``, ``ckpt``, ``no_save``, ...), attributes (``model``,
+``model_cfg``, ``device``) and methods (``run_camcalib``, ``run_detector``, ``run_on_image_folder``) and the same files on
+disk (``<out>/camcalib/<image name>.pkl``, ``<out>/spec_results/<stem>.pkl``).
+
+Differences by design: ``run_camcalib`` runs CamCalib in this process on the GPU instead of spawning
+``python scripts/camcalib_demo.py`` (tester.py:86-88) - the drop-in ``scripts/camcalib_demo.py`` wraps the same function; the
+crops of ``run_on_image_folder`` are cut on the device (``specmi_crop_normalize``); the person detector (multi-person-tracker /
+YOLOv3, tester.py:73-84) and the OpenGL renderer (:165-200) are outside the path: ``run_detector`` reads boxes from
+``args.detections`` (joblib: list or ``{image name: (n,4) [cx, cy, w, h]}``) and rendering is skipped with a notice."""
+from __future__ import annotations
+
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import assets, cam_utils, io_formats
+from .checkpoint import load_pretrained_model, read_checkpoint
+from .modules import HMR, CameraRegressorNetwork
+from .preprocess import camcalib_transform, crop_detections
+
+CAMCALIB_CKPT = 'data/camcalib/checkpoints/camcalib_sa_biased_l2.ckpt'     # scripts/camcalib_demo.py:39
+IMG_EXT = ('.png', '.jpg', '.jpeg')
+
+
+def _log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def _ns(d):
+    return SimpleNamespace(**{k: _ns(v) if isinstance(v, dict) else v for k, v in d.items()})
+
+
+def update_hparams(cfg_file):
+    """``spec/config.py: update_hparams`` for the keys the tester reads (HMR.BACKBONE, HMR.USE_CAM_FEATS, DATASET.IMG_RES,
+    TRAINING.PRETRAINED): the yacs YAML merged over the reference's defaults, attribute access like a CfgNode."""
+    from .evaluation import load_config
+    hp = load_config(cfg_file if cfg_file and os.path.exists(cfg_file) else None)
+    hp['TRAINING'].setdefault('PRETRAINED', None)
+    return _ns(hp)
+
+
+def _read_rgb(path):
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.array(im.convert('RGB'))
+
+
+def list_images(image_folder):
+    return sorted(os.path.join(image_folder, x) for x in os.listdir(image_folder) if x.endswith(IMG_EXT))
+
+
+@torch.no_grad()
+def run_camcalib_folder(img_folder, out_folder, ckpt=CAMCALIB_CKPT, loss_type='softargmax_l2', model=None, device='cuda', log=_log):
+    """The loop of ``scripts/camcalib_demo.py:95-174`` for an image folder: full frame -> Resize(600) transform on the
+    device -> CamCalib -> ``convert_preds_to_angles`` -> ``f_pix = h/2/tan(vfov/2)`` -> one ``<name>.pkl`` per image with
+    ``{'vfov', 'f_pix', 'pitch', 'roll'}``.  Returns {image path: record}."""
+    import joblib
+    dev = torch.device(device)
+    if model is None:
+        model = CameraRegressorNetwork(backbone='resnet50', num_fc_layers=1, num_fc_channels=1024).to(dev)
+        model = load_pretrained_model(model, read_checkpoint(ckpt)['state_dict'], remove_lightning=True, strict=True)
+        log('Loaded pretrained model')
+    model.eval()
+    os.makedirs(out_folder, exist_ok=True)
+    log('Running CamCalib')
+    results = {}
+    for img_fname in [f for f in list_images(img_folder) if not os.path.basename(f).startswith('.')]:
+        frame = torch.from_numpy(_read_rgb(img_fname)).to(dev)
+        orig_h = frame.shape[0]
+        preds = model(camcalib_transform(frame, 600))
+        if loss_type in ('kl', 'ce'):
+            vfov, pitch, roll = (np.asarray(a).squeeze() for a in cam_utils.convert_preds_to_angles(*preds, loss_type=loss_type, return_type='np'))
+        else:
+            vfov, pitch, roll = (a.detach().cpu().numpy().squeeze() for a in cam_utils.convert_preds_to_angles(*preds, loss_type=loss_type))
+        rec = {'vfov': vfov, 'f_pix': orig_h / 2. / np.tan(vfov / 2.), 'pitch': pitch, 'roll': roll}
+        joblib.dump(rec, os.path.join(out_folder, os.path.basename(img_fname) + '.pkl'))
+        results[img_fname] = rec
+    return results
+
+
+class SPECTester:
+    def __init__(self, args):
+        self.args = args
+        self.model_cfg = update_hparams(getattr(args, 'cfg', None))
+        if not torch.cuda.is_available():
+            raise RuntimeError('spec_amd runs on an AMD GPU (torch device "cuda"); there is no CPU path')
+        self.device = torch.device('cuda')
+        if getattr(args, 'synthetic_assets', False):
+            assets.use_synthetic_assets(1003)
+        self.model = self._build_model()
+        self._load_pretrained_model()
+        self.model.eval()
+        self._camcalib = getattr(args, 'camcalib_model', None)
+
+    def _build_model(self):
+        c = self.model_cfg
+        return HMR(backbone=c.HMR.BACKBONE, img_res=c.DATASET.IMG_RES, pretrained=c.TRAINING.PRETRAINED,
+                   use_cam_feats=c.HMR.USE_CAM_FEATS, use_cam=True).to(self.device)
+
+    def _load_pretrained_model(self):
+        if self.args.ckpt == 'spin':
+            _log('CKPT file is not provided, using SPIN weights')
+        elif isinstance(self.args.ckpt, dict):                       # an in-memory state dict (tests, synthetic demo)
+            load_pretrained_model(self.model, self.args.ckpt, overwrite_shape_mismatch=True, remove_lightning=True)
+        else:
+            _log(f'Loading pretrained model from {self.args.ckpt}')
+            ckpt = read_checkpoint(self.args.ckpt)['state_dict']
+            load_pretrained_model(self.model, ckpt, overwrite_shape_mismatch=True, remove_lightning=True)
+            _log(f'Loaded pretrained weights from "{self.args.ckpt}"')
+
+    def run_detector(self, image_folder):
+        det = getattr(self.args, 'detections', None)
+        if det is None:
+            raise NotImplementedError('the person detector / tracker (multi-person-tracker, YOLOv3: spec/tester.py:73-84) is '
+                                      'outside the hot path; pass --detections <joblib file> with the boxes ([cx, cy, w, h] per person)')
+        import joblib
+        boxes = joblib.load(det) if isinstance(det, str) else det
+        if isinstance(boxes, dict):
+            return [np.asarray(boxes.get(os.path.basename(f), boxes.get(f, [])), np.float32).reshape(-1, 4) for f in list_images(image_folder)]
+        return [np.asarray(b, np.float32).reshape(-1, 4) for b in boxes]
+
+    def run_camcalib(self, image_folder, output_folder):
+        return run_camcalib_folder(image_folder, f'{output_folder}/camcalib', ckpt=getattr(self.args, 'camcalib_ckpt', None) or CAMCALIB_CKPT,
+                                   model=self._camcalib, device=self.device)
+
+    @torch.no_grad()
+    def run_on_image_folder(self, image_folder, detections, output_path, output_img_folder, bbox_scale=1.0):
+        image_file_names = list_images(image_folder)
+        res = self.model_cfg.DATASET.IMG_RES
+        n_done = 0
+        for img_idx, img_fname in enumerate(image_file_names):
+            dets = detections[img_idx]
+            if len(dets) < 1:
+                continue
+            frame = torch.from_numpy(_read_rgb(img_fname)).to(self.device)
+            orig_height, orig_width = frame.shape[:2]
+            batch_size = len(dets)
+            crops = crop_detections(frame, np.asarray(dets, np.float32), scale=1.0, crop_size=res)     # tester.py:116-128
+            img_h = torch.full((batch_size,), float(orig_height), device=self.device)
+            img_w = torch.full((batch_size,), float(orig_width), device=self.device)
+            cam_rotmat, cam_intrinsics, cam_vfov, cam_pitch, cam_roll, cam_focal_length = \
+                io_formats.read_cam_params(output_path, img_fname, (orig_height, orig_width), device=self.device)
+            output = self.model(crops['inp_images'],
+                                cam_rotmat=cam_rotmat.unsqueeze(0).repeat(batch_size, 1, 1),
+                                cam_intrinsics=cam_intrinsics.unsqueeze(0).repeat(batch_size, 1, 1),
+                                bbox_scale=crops['bbox_scale'], bbox_center=crops['bbox_center'], img_w=img_w, img_h=img_h)
+            output = {k: v.cpu().numpy() for k, v in output.items()}
+            if not getattr(self.args, 'no_save', False):
+                import joblib
+                os.makedirs(os.path.join(output_path, 'spec_results'), exist_ok=True)
+                save_f = os.path.join(output_path, 'spec_results',
+                                      os.path.basename(img_fname).replace(img_fname.split('.')[-1], 'pkl'))
+                joblib.dump(output, save_f)
+            if not getattr(self.args, 'no_render', True) and n_done == 0:
+                _log('rendering (pyrender / OpenGL, spec/tester.py:165-200) is outside the hot path: skipped')
+            n_done += 1
+        return n_done

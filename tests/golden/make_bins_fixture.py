@@ -7,7 +7,7 @@ drop-in modules -- run ONLY in the build container (needs /root/reference).
     bins2roll / bins2horizon`` and ``convert_preds_to_angles(loss_type='kl')`` return for them.
 (2) ``import_surface.json``: every name the reference's own files import from the modules the build replaces
     (``spec.models``, ``spec.models.hmr``, ``spec.constants``, ``camcalib.model``, ``camcalib.cam_utils``,
-    ``spec.utils.cam_params``, ``spec.utils.compute_error``), found by parsing the reference with ``ast`` (import
+    ``spec.utils.cam_params``, ``spec.utils.compute_error``, ``spec.tester``), found by parsing the reference with ``ast`` (import
     statements and ``constants.X`` attribute uses).  Only names and arrays are stored, no reference source.
 """
 import ast
@@ -27,7 +27,7 @@ from spec_amd import synth  # noqa: E402
 from oracle import refshim  # noqa: E402
 
 TARGETS = {'spec.models', 'spec.models.hmr', 'spec.constants', 'camcalib.model', 'camcalib.cam_utils',
-           'spec.utils.cam_params', 'spec.utils.compute_error'}
+           'spec.utils.cam_params', 'spec.utils.compute_error', 'spec.tester'}
 
 
 def resolve(module, level, pkg):

@@ -85,3 +85,35 @@ def test_spec_eval_cli_standin(tmp_path):
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     assert 'W-MPJPE-24:' in r.stdout and 'PA-MPJPE-24:' in r.stdout and 'W-V2V:' in r.stdout and 'README 74.9' in r.stdout
+
+
+def test_reference_demo_commands_on_standin_tree(tmp_path):
+    """The reference's two demo commands with their DEFAULT paths, run from a directory that holds a ``data/`` tree in the
+    real formats: ``scripts/camcalib_demo.py --img_folder ... --out_folder ...`` and ``scripts/spec_demo.py --image_folder
+    data/sample_images --output_folder ...`` (README.md:100-104) - SPECTester, read_cam_params, result pickles."""
+    import joblib
+    from spec_amd import evaluation
+    d = str(tmp_path)
+    evaluation.write_standin_data_tree(d, n_images=2)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'camcalib_demo.py'), '--img_folder', 'data/sample_images',
+                        '--out_folder', 'out_cc', '--no_save'], cwd=d, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = joblib.load(os.path.join(d, 'out_cc', 'im0.png.pkl'))
+    assert set(rec) == {'vfov', 'f_pix', 'pitch', 'roll'} and 0.2617 <= float(rec['vfov']) <= 2.1
+    assert abs(float(rec['f_pix']) - 300 / 2. / np.tan(float(rec['vfov']) / 2.)) < 1e-3
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'spec_demo.py'), '--image_folder', 'data/sample_images',
+                        '--output_folder', 'logs/demo', '--exp', 'x'], cwd=d, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = os.path.join(d, 'logs/demo', 'sample_images_x')
+    cam = joblib.load(os.path.join(out, 'camcalib', 'im1.png.pkl'))
+    assert abs(float(cam['vfov']) - float(joblib.load(os.path.join(d, 'out_cc', 'im1.png.pkl'))['vfov'])) < 1e-6
+    res = joblib.load(os.path.join(out, 'spec_results', 'im1.pkl'))
+    assert res['smpl_vertices'].shape == (1, 6890, 3) and res['smpl_joints2d'].shape == (1, 49, 2)
+    assert set(res) == {'smpl_vertices', 'smpl_joints3d', 'smpl_joints2d', 'pred_cam_t', 'pred_pose', 'pred_cam', 'pred_shape',
+                        'pred_pose_6d'}
+    # kl-trained CamCalib variants decode through the arg-max tables
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'camcalib_demo.py'), '--img_folder', 'data/sample_images',
+                        '--out_folder', 'out_kl', '--loss', 'kl', '--no_save'], cwd=d, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    from spec_amd import cam_utils as CU
+    assert float(joblib.load(os.path.join(d, 'out_kl', 'im0.png.pkl'))['pitch']) in set(CU.pitch_bins_centers.tolist())
