@@ -518,6 +518,32 @@ def main():
         except Exception as e:
             log('[bench] small-batch latency failed:', repr(e))
 
+    # ---- host hand-over: what the step costs when the crops arrive in (pinned) host memory instead of HBM ----------------
+    # informational only - `value` is measured with the inputs resident in HBM, as the contract requires
+    pcie = None
+    if rank == 0 and not args.no_profile:
+        try:
+            host = torch.empty(x.shape, dtype=x.dtype).pin_memory()
+            host.copy_(x)
+            dst = torch.empty_like(x)
+            dst.copy_(host, non_blocking=True)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                dst.copy_(host, non_blocking=True)
+            e1.record()
+            torch.cuda.synchronize()
+            h2d_ms = e0.elapsed_time(e1) / 5
+            nbytes = x.numel() * 4
+            pcie = {'h2d_batch_MB': round(nbytes / 1e6, 1), 'h2d_ms': round(h2d_ms, 3), 'h2d_GBps': round(nbytes / h2d_ms / 1e6, 1),
+                    'images_per_s_if_serial': round(B * 1e3 / (ms_per_step + h2d_ms), 1),
+                    'note': 'fp32 crops from pinned host memory; serial = copy then step, no overlap (a double-buffered '
+                            'copy on its own stream hides it: h2d_ms < ms_per_step)'}
+            del host, dst
+        except Exception as e:
+            log('[bench] pcie measurement failed:', repr(e))
+
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         try:
@@ -538,7 +564,7 @@ def main():
                        'streams': 1 if args.no_overlap else 2, 'launch': launch_mode,
                        'parallelism': (f'images sharded over {n_gpus} GPUs (one process per GPU), 1 asynchronous RCCL '
                                        f'all-gather of the packed records per step') if n_gpus > 1 else 'single GPU'},
-            'roofline': roof, 'cpu_baseline': cpu, 'sustained': sustained, 'c2': c2, 'small_batch': small, 'comm': comm,
+            'roofline': roof, 'cpu_baseline': cpu, 'sustained': sustained, 'c2': c2, 'small_batch': small, 'pcie': pcie, 'comm': comm,
             'stages': stages,
         }
         print(json.dumps(line), flush=True)

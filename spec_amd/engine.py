@@ -149,6 +149,8 @@ class Engine:
         for _ in range(3):
             fh, fw = o(fh, 3, 2, 1), o(fw, 3, 2, 1)
         feat = torch.empty(B, fh, fw, self.feat_channels, device=self.device, dtype=torch.float32)
+        if B == 0:
+            return feat
         _lib.check(self.h, self.lib.specmi_trunk_forward(self.h, _ptr(x), B, H, W, _ptr(feat), self._stream()))
         return feat
 
@@ -156,6 +158,8 @@ class Engine:
         x = self._images(images)
         B, _, H, W = x.shape
         out = torch.empty(3, B, self.nbins, device=self.device, dtype=torch.float32)
+        if B == 0:                      # an empty batch gives empty outputs, as the reference's torch modules do
+            return [out[0], out[1], out[2]]
         _lib.check(self.h, self.lib.specmi_camcalib_forward(
             self.h, _ptr(x), B, H, W, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), self._stream()))
         return [out[0], out[1], out[2]]
@@ -227,6 +231,8 @@ class Engine:
         R, K, sc, ce, iw, ih = self._cam_args(B, cam_rotmat, cam_intrinsics, bbox_scale, bbox_center, img_w, img_h)
         views = self._out_for(B, record)
         out = views if views is not None else (out if out is not None else self._hmr_outputs(B))
+        if B == 0:
+            return out
         o = _lib.HmrOutputs(**{k: out[k].data_ptr() for k, _ in _lib.HmrOutputs._fields_})
         _lib.check(self.h, self.lib.specmi_hmr_forward(
             self.h, _ptr(x), B, H, W, _ptr(R), _ptr(K), _ptr(sc), _ptr(ce), _ptr(iw), _ptr(ih),

@@ -213,6 +213,16 @@ def test_collapsed_regressor_trained_like_weights():
         assert err < 1e-4, (k, err)
 
 
+def test_empty_batch_returns_empty_outputs(models):
+    """len(dets) == 0 style inputs: empty tensors out, like the reference's torch modules (no launch, no error)."""
+    cc, hm = models
+    lg = cc(torch.empty(0, 3, 224, 224, device=DEV))
+    assert len(lg) == 3 and all(l.shape == (0, 256) for l in lg)
+    e = lambda *s: torch.empty(*s, device=DEV)
+    out = hm(e(0, 3, 224, 224), cam_rotmat=e(0, 3, 3), cam_intrinsics=e(0, 3, 3), bbox_scale=e(0), bbox_center=e(0, 2), img_w=e(0), img_h=e(0))
+    assert out['smpl_vertices'].shape == (0, 6890, 3) and out['pred_pose'].shape == (0, 24, 3, 3)
+
+
 def test_batch1_latency_path(models):
     """B = 1 through the collapsed head: same results as the row of a larger batch (batch invariance)."""
     from spec_amd.pipeline import SpecPipeline
