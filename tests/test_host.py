@@ -147,3 +147,32 @@ def test_unsupported_variants_raise():
         CameraRegressorNetwork(num_fc_layers=4)
     with pytest.raises(NotImplementedError):
         HMR(backbone='resnet34')
+
+
+def test_bench_stage_table_formulae():
+    """bench.py's per-stage roofline: frac = max(bytes / 8 TB/s, executed flops / 157.3 TF/s) / t, Winograd entries count
+    16/36 of their algorithmic flops, stages are grouped over both trunks."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    e = lambda kernel, label, ms, flops, by, n=1: {'kernel': kernel, 'label': label, 'ms': ms, 'flops': flops, 'bytes': by, 'launches': n}
+    entries = [
+        e('conv_igemm_f32<64x64,2x2>', 'backbone.layer3.1.conv1', 0.25, 26.3e9, 0.3e9),
+        e('conv_igemm_f32<64x64,2x2>', 'backbone.layer3.2.conv1', 0.25, 26.3e9, 0.3e9),
+        e('conv_wino_f32<32t x64,F(2x2,3x3)>', 'backbone.layer3.1.conv2', 0.25, 59.2e9, 0.1e9),
+        e('conv_igemm_f32<128x128,4x2>', 'backbone.layer1.1.conv3', 0.35, 26.3e9, 1.85e9),
+        e('maxpool3x3s2_f32', 'backbone.maxpool', 0.23, 0.0, 1.03e9),
+        e('conv_igemm_f32<64x64,2x2,splitK>', 'head.ief_collapsed', 0.02, 0.18e9, 4e6),
+    ]
+    rows = {r['stage']: r for r in bench.stage_table(entries)}
+    assert rows['layer3.conv1']['launches'] == 2 and rows['layer3.conv1']['bound'] == 'mfma'
+    assert abs(rows['layer3.conv1']['frac'] - (52.6e9 / 157.3e12) / 0.5e-3) < 1e-3
+    assert abs(rows['layer3.conv2']['TFLOPs'] - 59.2e9 * 16 / 36 / 0.25e-3 / 1e12) < 0.01          # executed, not algorithmic
+    assert rows['layer1.conv3']['bound'] == 'hbm' and abs(rows['layer1.conv3']['frac'] - (1.85e9 / 8e12) / 0.35e-3) < 1e-3
+    assert rows['stem.maxpool']['bound'] == 'hbm' and rows['hmr.regressor']['launches'] == 1
+    assert all(0 < r['frac'] <= 1.0 for r in rows.values())
+    roof = bench.roofline_from_profile(entries)
+    igemm_ms = 0.25 + 0.25 + 0.35 + 0.02
+    assert abs(roof['achieved'] - (26.3e9 * 3 + 0.18e9) / (igemm_ms * 1e-3) / 1e12) < 0.01
+    assert roof['second_kernel']['executed_mfma_TFLOPs'] == round(59.2e9 / 0.25e-3 / 1e12 * 16 / 36, 2)
