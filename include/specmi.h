@@ -26,6 +26,8 @@
  *     the caller's HIP stream (`stream` is a hipStream_t passed as void*; NULL = default
  *     stream); no call synchronises the device except specmi_commit, specmi_destroy and
  *     specmi_profile_read.
+ *   - every call runs on the device the handle was created for and restores the caller's current HIP device before
+ *     it returns (a second device in the same process is fine; kernel attributes are set per device).
  *   - one handle per model instance; a handle is not thread-safe (the reference is
  *     single-threaded), distinct handles are independent.
  *   - all arithmetic is IEEE fp32 (reference inference never enables AMP:

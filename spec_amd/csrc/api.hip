@@ -21,6 +21,20 @@ int fail(specmi_handle* h, int code, const char* fmt, ...) {
     return code;
 }
 
+// Every entry point runs on the handle's device and puts the caller's current device back on return (the caller -
+// PyTorch - reads hipGetDevice to decide where its next allocation goes; a library must not move it).
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t enter(int dev) {
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) { prev = -1; return e; }
+        if (prev == dev) { prev = -1; return hipSuccess; }
+        return hipSetDevice(dev);
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+
 int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // ------------------------------------------------------------------------------------------
@@ -725,7 +739,8 @@ int specmi_create(specmi_handle** out, int device_id, int model_kind) {
 
 int specmi_destroy(specmi_handle* h) {
     if (!h) return SPECMI_OK;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard;
+    (void)guard.enter(h->device);
     (void)hipDeviceSynchronize();
     for (auto& r : h->prof.log) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     free_pool(h->ws_allocs);
@@ -775,7 +790,8 @@ int specmi_set_tensor_i32(specmi_handle* h, const char* name, const int32_t* d, 
 
 int specmi_commit(specmi_handle* h) {
     if (!h) return SPECMI_ERR_ARG;
-    HIPCHK(h, hipSetDevice(h->device));
+    DeviceGuard guard;
+    HIPCHK(h, guard.enter(h->device));
     HIPCHK(h, hipDeviceSynchronize());
     free_pool(h->param_allocs);
     h->committed = false;
@@ -855,7 +871,8 @@ int specmi_commit(specmi_handle* h) {
 
 #define ENTER(h)                                                                   \
     if (!(h)) return SPECMI_ERR_ARG;                                               \
-    HIPCHK(h, hipSetDevice((h)->device));
+    DeviceGuard dev_guard__;                                                       \
+    HIPCHK(h, dev_guard__.enter((h)->device));
 
 #define NEED_COMMIT(h) \
     if (!(h)->committed) return fail(h, SPECMI_ERR_STATE, "specmi_commit has not succeeded on this handle");
