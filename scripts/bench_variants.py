@@ -6,7 +6,6 @@ import argparse
 import json
 import os
 import sys
-import time
 
 import numpy as np
 import torch

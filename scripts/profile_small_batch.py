@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per-kernel time of one whole step at a small batch (library HIP-event profiler, one stream, eager)."""
-import argparse, json, os, sys
-import numpy as np, torch
+import argparse, os, sys
+import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench

@@ -32,7 +32,6 @@ def main():
                                   f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1', '--master-port', str(port),
                                   os.path.abspath(__file__)] + sys.argv[1:], env=env))
 
-    import numpy as np
     import torch
     import torch.distributed as dist
     from spec_amd import synth

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from spec_amd import synth
-from tests.util import golden, gpu_models, oracle_models, rel_err, smpl_model, t
+from tests.util import golden, gpu_models, rel_err, smpl_model, t
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
