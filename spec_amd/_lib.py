@@ -102,6 +102,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own libamdhip64.so; libspecmi.so links the HIP runtime by SONAME.  Whichever copy the
+    # process loads first serves both, and tensors / streams must come from the SAME runtime as the kernels that use
+    # them - so torch's goes first (loading /opt/rocm's before torch left the process without a visible device).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f'{LIB_PATH} not found: build it with `python -m spec_amd.build` '
