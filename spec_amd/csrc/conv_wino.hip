@@ -314,8 +314,10 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
+                    // the SAME association as the two-wave layout below ((S0 + S1) + S2 and ((-S2) - S3) + S1), so both
+                    // layouts give bit-identical outputs and the launcher may pick either one by grid size
                     emit(Sx[i][0] + Sx[i][1] + Sx[i][2], to[2 * i]);
-                    emit(Sx[i][1] - Sx[i][2] - Sx[i][3], to[2 * i + 1]);
+                    emit((-Sx[i][2] - Sx[i][3]) + Sx[i][1], to[2 * i + 1]);
                 }
             }
         } else {
@@ -421,7 +423,13 @@ static int wino_pick(const ConvArgs& a) {
     // Measured on MI355X at B=256 (tools/wino_bench): two 128-accumulator waves per SIMD cover each other's
     // prologue / epilogue and win by ~10 % up to Cin = 256; from Cin = 512 (32 stages per tile) the
     // 128-channel workgroup (half the A traffic per MFMA) is ahead.
-    return (a.Cout % 128 == 0 && a.Cin >= 512) ? 16 : 8;
+    if (!(a.Cout % 128 == 0 && a.Cin >= 512)) return 8;
+    // Small batches: a 32t x 128 grid of a few workgroups walks its 32+ stages alone (layer4 at B = 1: 4 workgroups,
+    // 132 us); the 64-channel layout has twice the workgroups and half the serial MFMA chain.  The two layouts are
+    // bit-identical (same k order, same output-transform association), so the choice never changes a result.
+    const long tiles = (long)a.B * ((a.H + 1) / 2) * ((a.W + 1) / 2);
+    const long wgs16 = ((tiles + 31) / 32) * (a.Cout / 128);
+    return wgs16 < 128 ? 8 : 16;
 }
 
 template <int NF>

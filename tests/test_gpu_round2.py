@@ -213,6 +213,29 @@ def test_collapsed_regressor_trained_like_weights():
         assert err < 1e-4, (k, err)
 
 
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(1, 7, 7, 512, 512), (3, 9, 5, 64, 128), (2, 14, 14, 256, 256), (5, 7, 7, 512, 128)])
+def test_winograd_wave_layouts_bit_identical(B, H, W, Cin, Cout):
+    """The launcher picks the Winograd wave layout (8 or 16 frequencies per wave) by grid size, i.e. by batch: the two
+    layouts must therefore agree bit for bit (same k order, same output-transform association)."""
+    from spec_amd.engine import Engine
+    eng = Engine('camcalib', torch.device(DEV))
+    g = torch.Generator().manual_seed(B * 1000 + Cin)
+    x = torch.randn(B, H, W, Cin, generator=g).relu().to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).numpy()
+    sc = (1.0 + 0.1 * torch.randn(Cout, generator=g)).numpy()
+    sh = (0.1 * torch.randn(Cout, generator=g)).numpy()
+    outs = {}
+    for v in (8, 16):
+        eng.set_option('force_wino_variant', v)
+        outs[v] = eng.conv2d(x, w, sc, sh, 1, 1, relu=True).clone()
+    eng.set_option('force_wino_variant', 0)
+    auto = eng.conv2d(x, w, sc, sh, 1, 1, relu=True)
+    assert torch.equal(outs[8], outs[16]) and torch.equal(auto, outs[8])
+    ref = torch.nn.functional.conv2d(x.cpu().permute(0, 3, 1, 2), torch.from_numpy(w), padding=1)
+    ref = (ref * torch.from_numpy(sc).view(1, -1, 1, 1) + torch.from_numpy(sh).view(1, -1, 1, 1)).relu().permute(0, 2, 3, 1)
+    assert rel_err(outs[8].cpu().numpy(), ref.numpy()) < 2e-5
+
+
 def test_empty_batch_returns_empty_outputs(models):
     """len(dets) == 0 style inputs: empty tensors out, like the reference's torch modules (no launch, no error)."""
     cc, hm = models
