@@ -33,5 +33,5 @@ for tag, e in engs:
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print(f'B={args.batch}: {tot:.1f} us of kernel time per step over {sum(r[1] for r in rows)} launches')
-for us, nl, tag, lab, k in rows[:40]:
+for us, nl, tag, lab, k in rows:
     print(f'{us:8.1f} us x{nl} {tag:8s} {lab:40s} {k}')

@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) smpl_skin_kernel(const float* __restrict_
         for (int i = 0; i < IT; ++i) off[i][0] = off[i][1] = off[i][2] = 0.f;
         const float* pd = posedirs + (size_t)vv * 3;
         const size_t ldp = (size_t)V * 3;
-#pragma unroll 3
+#pragma unroll 9
         for (int k = 0; k < 207; ++k) {
             const float p0 = pd[k * ldp + 0], p1 = pd[k * ldp + 1], p2 = pd[k * ldp + 2];
 #pragma unroll
@@ -208,6 +208,7 @@ __global__ void __launch_bounds__(256) smpl_joints_kernel(const JointArgs a) {
     float acc[9][3];
 #pragma unroll
     for (int e = 0; e < 9; ++e) acc[e][0] = acc[e][1] = acc[e][2] = 0.f;
+#pragma unroll 4   // 12 independent loads per iteration: keep several iterations in flight (one workgroup per image is latency-bound)
     for (int v = t; v < a.V; v += 256) {
         const float x = vb[v * 3 + 0], y = vb[v * 3 + 1], z = vb[v * 3 + 2];
 #pragma unroll
