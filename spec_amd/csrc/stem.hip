@@ -228,6 +228,7 @@ __global__ void __launch_bounds__(256) avgpool_kernel(const float* __restrict__ 
     const int c4 = i % C4, b = i / C4;
     const f32x4* src = reinterpret_cast<const f32x4*>(x) + (size_t)b * HW * C4 + c4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 7   // independent loads, one accumulation order: several rows in flight (latency-bound at small batch)
     for (int p = 0; p < HW; ++p) {
         const f32x4 v = src[(size_t)p * C4];
         s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
