@@ -109,7 +109,7 @@ class HMROracle(nn.Module):
             backbone, use_conv = backbone.split('-')                                  # :45
             self.backbone = getattr(hrnet, backbone)(pretrained=True, downsample=True, use_conv=(use_conv == 'conv'))
         else:
-            self.backbone = ResNet50Trunk()
+            self.backbone = ResNet50Trunk() if backbone == 'resnet50' else ResNet34Trunk()
         self.use_cam_feats = use_cam_feats
         self.head = HMRHead(num_input_features=get_backbone_info(backbone)['n_output_channels'],
                             backbone=backbone, use_cam_feats=use_cam_feats)

@@ -807,8 +807,6 @@ int specmi_commit(specmi_handle* h) {
     const int depth = opt_i(h, "backbone", 50);
     if (depth != 50 && depth != 34 && depth != 32 && depth != 48)
         return fail(h, SPECMI_ERR_ARG, "backbone %d: resnet50 (50), resnet34 (34), hrnet_w32 (32) and hrnet_w48 (48) are built", depth);
-    if (depth == 34 && h->kind != SPECMI_MODEL_CAMCALIB)
-        return fail(h, SPECMI_ERR_ARG, "the reference builds HMR on resnet50 or hrnet_w32 / w48 (spec/models/hmr.py:44-53)");
     if ((depth == 32 || depth == 48) && h->kind != SPECMI_MODEL_HMR)
         return fail(h, SPECMI_ERR_ARG, "the HRNet trunks belong to HMR (camcalib/model.py:33 builds resnet trunks only)");
     if (h->hrnet) { hrnet_free(h->hrnet); h->hrnet = nullptr; }

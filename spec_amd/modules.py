@@ -367,11 +367,11 @@ class HMR(_EngineModule):
             self.backbone = (hrnet_w32 if backbone == 'hrnet_w32' else hrnet_w48)(pretrained=True, downsample=True,
                                                                                   use_conv=(use_conv == 'conv'))
             self._backbone_id = 32 if backbone == 'hrnet_w32' else 48
-        elif backbone == 'resnet50':
-            self.backbone = resnet50(pretrained=True)
-            self._backbone_id = 50
+        elif backbone in ('resnet50', 'resnet34'):               # eval(backbone)(pretrained=True), hmr.py:53
+            self.backbone = resnet50(pretrained=True) if backbone == 'resnet50' else resnet34(pretrained=True)
+            self._backbone_id = 50 if backbone == 'resnet50' else 34
         else:
-            raise NotImplementedError(f'backbone {backbone!r}: resnet50, hrnet_w32-(conv|interp), hrnet_w48-(conv|interp) are built')
+            raise NotImplementedError(f'backbone {backbone!r}: resnet50, resnet34, hrnet_w32-(conv|interp), hrnet_w48-(conv|interp) are built')
         self.use_cam_feats = use_cam_feats
         self.head = HMRHeadParams(get_backbone_info(backbone)['n_output_channels'], use_cam_feats)
         self.use_cam = use_cam

@@ -219,6 +219,9 @@ def hmr_state(seed: int = 1002, use_cam_feats: bool = True, dec_gain: float = 1.
         width = 32 if name == 'hrnet_w32' else 48
         sd = hrnet_state(seed, width, mode == 'conv', 'backbone.')
         feat = width * 15
+    elif backbone == 'resnet34':
+        sd = resnet34_state(seed, 'backbone.')
+        feat = 512
     else:
         sd = resnet50_state(seed, 'backbone.')
         feat = 2048

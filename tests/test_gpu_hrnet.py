@@ -62,7 +62,7 @@ def test_hrnet_rejects_sizes_the_reference_cannot_fuse():
 
 
 @pytest.mark.parametrize('backbone,use_cam,ucf', [('hrnet_w32-conv', True, True), ('hrnet_w32-interp', True, False),
-                                                  ('hrnet_w48-conv', False, False)])
+                                                  ('hrnet_w48-conv', False, False), ('resnet34', True, True)])
 def test_hmr_hrnet_end_to_end_vs_oracle(backbone, use_cam, ucf):
     hm, ohm = _models(backbone, use_cam, ucf)
     B = 3
