@@ -43,7 +43,7 @@ def test_resnet_trunk_vs_hf_transformers(depth):
         sd, trunk = synth.resnet34_state(1001), ResNet34Trunk().eval()
     hf = tr.ResNetModel(cfg).eval()
     mapped = {_hf_name(k): torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
-    assert set(mapped) == set(hf.state_dict().keys())              # 318 / 182 tensors, one to one
+    assert set(mapped) == set(hf.state_dict().keys())              # 318 / 216 tensors, one to one
     hf.load_state_dict(mapped, strict=True)
     load_numpy_state(trunk, sd)
     x = torch.from_numpy(synth.images(21, 2))[:, :, :160, :128].contiguous()
