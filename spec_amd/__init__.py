@@ -13,9 +13,16 @@ def __getattr__(name):
     if name in ('HMR', 'CameraRegressorNetwork'):
         from . import modules
         return getattr(modules, name)
-    if name in ('SpecPipeline', 'pack_outputs', 'gather_outputs', 'PACKED_KEYS'):
+    if name in ('SpecPipeline', 'GraphedPipeline', 'AsyncGather', 'pack_outputs', 'unpack_outputs', 'gather_outputs',
+                'shard_range', 'PACKED_KEYS'):
         from . import pipeline
         return getattr(pipeline, name)
+    if name == 'SPECTester':
+        from . import tester
+        return tester.SPECTester
+    if name in ('BodyModel', 'compute_error'):
+        from . import metrics
+        return getattr(metrics, name)
     if name in ('load_pretrained_model', 'read_checkpoint'):
         from . import checkpoint
         return getattr(checkpoint, name)
