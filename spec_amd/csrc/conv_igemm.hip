@@ -417,7 +417,7 @@ static int launch_variant(const KArgs& k, int M, const LaunchCtx& ctx, const cha
     if (int e = set_dyn_lds_once(once, reinterpret_cast<const void*>(&conv_igemm_f32_kernel<BM, BN, WGM, WGN, IS1X1, BK, DUAL, SPLITK, BDIR>), (int)smem))
         return e;
     KArgs kk = k;
-    kk.nbn = k.Npad / BN;
+    kk.nbn = BN < 64 ? (k.Cout + BN - 1) / BN : k.Npad / BN;   // 32-wide tiles skip the all-padding half of a 64-padded weight panel
     const int nbm = (M + BM - 1) / BM;
     const int grid = nbm * kk.nbn;
     ProfScope ps(ctx, name, flops, bytes);
@@ -440,10 +440,11 @@ static const char* kVariantNames[] = {"", "conv_igemm_f32<128x128,2x2>", "conv_i
                                       "conv_igemm_f32<64x64,2x2>", "conv_igemm_f32<128x128,4x2>",
                                       "conv_igemm_f32<128x64,4x2>", "conv_igemm_f32<64x128,2x4>", "conv_igemm_f32<64x64,2x2,bk16>",
                                       "conv_igemm_f32<64x64,2x2,ldsB>", "conv_igemm_f32<128x128,4x2,bdir>",
-                                      "conv_igemm_f32<64x128,2x2,bdir>", "conv_igemm_f32<128x64,2x2,bdir>", "conv_igemm_f32<64x64,2x2,bdir,bk64>"};
+                                      "conv_igemm_f32<64x128,2x2,bdir>", "conv_igemm_f32<128x64,2x2,bdir>", "conv_igemm_f32<64x64,2x2,bdir,bk64>",
+                                      "conv_igemm_f32<128x32,4x1>"};
 
-static int pick_variant(int M, int Npad, bool is1x1, int K, int force) {
-    if (force >= 1 && force <= 12) {
+static int pick_variant(int M, int Npad, bool is1x1, int K, int force, int Cout) {
+    if (force >= 1 && force <= 13) {
         const bool needs128 = (force == 1 || force == 4 || force == 6 || force == 9 || force == 10);
         if (!needs128 || Npad % 128 == 0) return force;
     }
@@ -452,11 +453,14 @@ static int pick_variant(int M, int Npad, bool is1x1, int K, int force) {
     // the large-M expand convs with K <= 128 (layer1/layer2 conv3 + residual) that sit on the HBM
     // roofline - there the 8-wave 128x128 tile with both operands staged moves half the L2 traffic.
     if (is1x1 && Npad % 128 == 0 && M >= 131072 && K <= 128) return 4;
+    // <= 32 output channels (HRNet-W32's full-resolution branch): a 64-wide tile would spend half its MFMAs on the zero
+    // padding of the weight panel; 128 rows x 32 columns keeps every matrix-core cycle on real outputs
+    if (Cout <= 32) return 13;
     return 3;
 }
 
 const char* conv_igemm_variant(const ConvArgs& a) {
-    return kVariantNames[pick_variant(a.B * a.OH * a.OW, a.Npad, a.KH == 1 && a.KW == 1 && a.pad == 0, a.Cin + a.Cin2, a.force_variant)];
+    return kVariantNames[pick_variant(a.B * a.OH * a.OW, a.Npad, a.KH == 1 && a.KW == 1 && a.pad == 0, a.Cin + a.Cin2, a.force_variant, a.Cout)];
 }
 
 static int dispatch_dual(int v, const KArgs& k, int M, const LaunchCtx& ctx, double flops, double bytes) {
@@ -480,6 +484,7 @@ static int dispatch(int v, const KArgs& k, int M, const LaunchCtx& ctx, double f
         case 11: return launch_variant<128, 64, 2, 2, IS1X1, 32, false, false, true>(k, M, ctx, kVariantNames[v], flops, bytes);
         case 12: return launch_variant<64, 64, 2, 2, IS1X1, 64, false, false, true>(k, M, ctx, kVariantNames[v], flops, bytes);
 #endif
+        case 13: return launch_variant<128, 32, 4, 1, IS1X1, 32, false, false, true>(k, M, ctx, kVariantNames[v], flops, bytes);
         default: return launch_variant<64, 64, 2, 2, IS1X1, 32, false, false, true>(k, M, ctx, kVariantNames[3], flops, bytes);
     }
 }
@@ -526,7 +531,7 @@ static int launch_one(const ConvArgs& a, const LaunchCtx& ctx) {
     const double bytes = 4.0 * ((double)a.B * a.H * a.W * a.Cin + (dual ? (double)M * a.Cin2 : 0.0) +
                                 (double)M * a.Cout * (a.res ? 2.0 : 1.0) + Kd * a.Cout);
     const bool is1x1 = (a.KH == 1 && a.KW == 1 && a.pad == 0);
-    const int v = pick_variant(M, a.Npad, is1x1, a.Cin + (dual ? a.Cin2 : 0), a.force_variant);
+    const int v = pick_variant(M, a.Npad, is1x1, a.Cin + (dual ? a.Cin2 : 0), a.force_variant, a.Cout);
     if (dual) return dispatch_dual(v, k, M, ctx, flops, bytes);
     return is1x1 ? dispatch<true>(v, k, M, ctx, flops, bytes) : dispatch<false>(v, k, M, ctx, flops, bytes);
 }
