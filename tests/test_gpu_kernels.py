@@ -42,6 +42,40 @@ RESNET_SHAPES = [
 ]
 
 
+# (Cin, Cout, k, stride, H, W, residual): the <= 32-output-channel layers of HRNet-W32's full-resolution branch run on the
+# 128x32 tile (tile variant 13, picked automatically); the last two force it on wider layers (several 32-column tiles)
+TILE_128x32_SHAPES = [(32, 32, 3, 1, 56, 56, True), (32, 32, 3, 1, 13, 9, False), (64, 32, 1, 1, 28, 28, False),
+                      (256, 32, 3, 1, 10, 12, False), (32, 32, 3, 2, 15, 15, False), (64, 96, 1, 1, 14, 14, True),
+                      (128, 256, 3, 2, 14, 14, False)]
+
+
+@pytest.mark.parametrize('shape', TILE_128x32_SHAPES, ids=lambda s: 'c%d_%d_k%d_s%d_%dx%d_r%d' % s)
+def test_conv_128x32_tile_parity(eng, shape):
+    cin, cout, k, stride, H, W, use_res = shape
+    g = torch.Generator().manual_seed(cin * 3 + cout + k + H)
+    B = 3
+    x = torch.randn(B, H, W, cin, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    sc = torch.rand(cout, generator=g) + 0.5
+    sh = torch.randn(cout, generator=g) * 0.1
+    pad = 1 if k == 3 else 0
+    oh, ow = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(B, oh, ow, cout, generator=g) if use_res else None
+    eng.set_option('winograd', 0)
+    eng.set_option('force_conv_variant', 13 if cout > 32 else 0)
+    eng.profile(True)
+    y = eng.conv2d(x.to(DEV), w.numpy(), sc.numpy(), sh.numpy(), stride, pad,
+                   residual=None if res is None else res.to(DEV), relu=True).cpu()
+    kernels = [e['kernel'] for e in eng.profile_read()]
+    eng.profile(False)
+    eng.set_option('force_conv_variant', 0)
+    eng.set_option('winograd', 1)
+    assert any('128x32' in kname for kname in kernels), kernels
+    ref = _conv_ref(x, w, sc, sh, stride, pad, res, True)
+    assert y.shape == ref.shape
+    assert rel_err(y.numpy(), ref.numpy()) < 2e-5
+
+
 @pytest.mark.parametrize('variant', [0, 1, 2, 3])
 @pytest.mark.parametrize('shape', RESNET_SHAPES, ids=lambda s: 'c%d_%d_k%d_s%d_h%d' % s)
 def test_conv_layer_parity(eng, shape, variant):
