@@ -236,6 +236,14 @@ int specmi_crop_normalize(specmi_handle* h, const uint8_t* frame_rgb_hwc, int H,
                           const float* bboxes, int n, float scale, int crop_size, float* out_nchw,
                           uint8_t* raw_hwc, float* bbox_scale, float* bbox_center, void* stream);
 
+/* The evaluation dataset's image path (spec/dataset/cam_dataset.py:253-287 rgb_processing with flip 0 / rot 0 / pn 1, :367-377):
+ * pare `crop(img, center, scale, [res, res])` = copy of the integer box [ul, br) (zero outside the frame) scaled to res x res
+ * with cv2.resize (bilinear, half-pixel centres, replicated border), clip to [0, 255], float32 / 255, ImageNet Normalize.
+ * boxes: (n,4) int32 device [ul_x, ul_y, br_x, br_y] as the reference's `transform(..., invert=1)` yields them (computed on
+ * the host: spec_amd.preprocess.pare_crop_boxes); frame uint8 RGB HWC device; out (n,3,S,S) fp32 NCHW. */
+int specmi_crop_resize_normalize(specmi_handle* h, const uint8_t* frame_rgb_hwc, int H, int W, const int32_t* boxes, int n,
+                                 int crop_size, float* out_nchw, void* stream);
+
 /* The CamCalib frame transform (camcalib/pano_dataset.py:156-162, scripts/camcalib_demo.py:100): torchvision
  * Resize(600) on a PIL image = Pillow's antialiased bilinear resample (Image.resize((OW, OH), BILINEAR): separable
  * triangle filter, 22-bit fixed-point coefficients, uint8 between the passes) + ToTensor + ImageNet Normalize, from a

@@ -226,3 +226,86 @@ def camcalib_transform(frame_u8, min_size=600):
     H, W = frame_u8.shape[:2]
     ow, oh = resize_output_size(W, H, min_size)
     return to_tensor_normalize(pil_resize_bilinear_u8(frame_u8, ow, oh))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# evaluation-dataset crop: pare / SPIN `crop` + cv2.resize + rgb_processing + Normalize
+# (spec/dataset/cam_dataset.py:253-287,367-377; `crop` / `transform` / `get_transform` restated from the published SPIN
+# image utilities that pare copies; cv2.resize INTER_LINEAR on float64 restated: parity unpinned vs the OpenCV binary)
+# ------------------------------------------------------------------------------------------------------------------
+def get_transform(center, scale, res, rot=0):
+    h = 200 * scale
+    t = np.zeros((3, 3))
+    t[0, 0] = float(res[1]) / h
+    t[1, 1] = float(res[0]) / h
+    t[0, 2] = res[1] * (-float(center[0]) / h + .5)
+    t[1, 2] = res[0] * (-float(center[1]) / h + .5)
+    t[2, 2] = 1
+    assert rot == 0
+    return t
+
+
+def transform(pt, center, scale, res, invert=0, rot=0):
+    t = get_transform(center, scale, res, rot=rot)
+    if invert:
+        t = np.linalg.inv(t)
+    new_pt = np.array([pt[0] - 1, pt[1] - 1, 1.]).T
+    new_pt = np.dot(t, new_pt)
+    return new_pt[:2].astype(int) + 1
+
+
+def cv2_resize_linear_f64(src, dst_w, dst_h):
+    """cv2.resize(src (h,w,c) float64, (dst_w, dst_h)) with INTER_LINEAR: half-pixel centres, replicated border, float
+    coefficients, double accumulation (horizontal pass then vertical pass)."""
+    h, w = src.shape[:2]
+
+    def coeffs(ssize, dsize):
+        scale = float(ssize) / dsize
+        idx, a = np.zeros(dsize, np.int64), np.zeros(dsize, np.float32)
+        for d in range(dsize):
+            f = np.float32((d + 0.5) * scale - 0.5)
+            s_ = int(np.floor(f))
+            f = np.float32(f - np.float32(s_))
+            if s_ < 0:
+                f, s_ = np.float32(0), 0
+            if s_ >= ssize - 1:
+                f, s_ = np.float32(0), ssize - 1
+            idx[d], a[d] = s_, f
+        return idx, a
+    xi, xa = coeffs(w, dst_w)
+    yi, ya = coeffs(h, dst_h)
+    xi1 = np.minimum(xi + 1, w - 1)
+    yi1 = np.minimum(yi + 1, h - 1)
+    a1 = xa.astype(np.float64)[None, :, None]
+    a0 = (np.float32(1) - xa).astype(np.float64)[None, :, None]
+    rows = src[:, xi] * a0 + src[:, xi1] * a1                          # (h, dst_w, c)
+    b1 = ya.astype(np.float64)[:, None, None]
+    b0 = (np.float32(1) - ya).astype(np.float64)[:, None, None]
+    return rows[yi] * b0 + rows[yi1] * b1
+
+
+def pare_crop(img, center, scale, res):
+    """SPIN / pare ``crop(img, center, scale, res, rot=0)``: integer box copy (zero padded) + cv2.resize."""
+    ul = np.array(transform([1, 1], center, scale, res, invert=1)) - 1
+    br = np.array(transform([res[0] + 1, res[1] + 1], center, scale, res, invert=1)) - 1
+    new_shape = [br[1] - ul[1], br[0] - ul[0]]
+    if len(img.shape) > 2:
+        new_shape += [img.shape[2]]
+    new_img = np.zeros(new_shape)
+    new_x = max(0, -ul[0]), min(br[0], len(img[0])) - ul[0]
+    new_y = max(0, -ul[1]), min(br[1], len(img)) - ul[1]
+    old_x = max(0, ul[0]), min(len(img[0]), br[0])
+    old_y = max(0, ul[1]), min(len(img), br[1])
+    new_img[new_y[0]:new_y[1], new_x[0]:new_x[1]] = img[old_y[0]:old_y[1], old_x[0]:old_x[1]]
+    return cv2_resize_linear_f64(new_img, res[0], res[1])
+
+
+def dataset_crop(img_u8, center, scale, res=224):
+    """rgb_processing (flip 0, rot 0, pn = 1) + Normalize: (H,W,3) uint8 -> (3,res,res) fp32."""
+    rgb = pare_crop(img_u8, center, scale, [res, res])
+    for c in range(3):
+        rgb[:, :, c] = np.minimum(255.0, np.maximum(0.0, rgb[:, :, c] * 1.0))
+    x = np.transpose(rgb.astype('float32'), (2, 0, 1)) / 255.0
+    mean = np.array([0.485, 0.456, 0.406], np.float32).reshape(3, 1, 1)
+    std = np.array([0.229, 0.224, 0.225], np.float32).reshape(3, 1, 1)
+    return ((x - mean) / std).astype(np.float32)

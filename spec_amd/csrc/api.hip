@@ -1137,6 +1137,15 @@ int specmi_crop_normalize(specmi_handle* h, const uint8_t* frame, int H, int W, 
     return SPECMI_OK;
 }
 
+int specmi_crop_resize_normalize(specmi_handle* h, const uint8_t* frame, int H, int W, const int32_t* boxes, int n,
+                                 int crop_size, float* out, void* stream) {
+    ENTER(h);
+    if (!frame || !boxes || !out || H <= 0 || W <= 0 || n <= 0 || crop_size <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
+    LaunchCtx ctx{(hipStream_t)stream, &h->prof, "preprocess.dataset_crop"};
+    LAUNCHCHK(h, launch_crop_resize_normalize(frame, H, W, boxes, n, crop_size, out, ctx), "crop_resize_normalize");
+    return SPECMI_OK;
+}
+
 int specmi_eval_mesh(specmi_handle* h, const float* pred, const float* gt, int B, int V, const float* Jr, int J,
                      const int32_t* sel, int nsel, float* mpjpe, float* pampjpe, float* v2v, void* stream) {
     ENTER(h);

@@ -74,6 +74,62 @@ int launch_crop_normalize(const unsigned char* frame, int H, int W, const float*
 }
 
 // ------------------------------------------------------------------------------------------------
+// Evaluation-dataset crop (spec/dataset/cam_dataset.py:253-287,367-377: rgb_processing -> pare `crop` -> ToTensor ->
+// Normalize).  PARE / SPIN `crop(img, center, scale, res)` copies the integer box [ul, br) (200*scale pixels around the
+// centre, zero outside the frame) and scales it to res x res with cv2.resize (INTER_LINEAR on a float64 array: half-pixel
+// centres, replicated border, float coefficients, double accumulation); rgb_processing clips to [0, 255], converts to
+// float32 / 255 and the dataset normalises with the ImageNet mean / std.  The integer boxes come from the host (the
+// reference computes them with a 3x3 float64 inverse; spec_amd/preprocess.py restates that), everything per pixel runs here.
+__global__ void __launch_bounds__(256) crop_resize_normalize_kernel(const unsigned char* __restrict__ frame, int H, int W,
+                                                                     const int* __restrict__ boxes, int S,
+                                                                     float* __restrict__ out) {
+    const int d = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= S * S) return;
+    const int ulx = boxes[d * 4 + 0], uly = boxes[d * 4 + 1], brx = boxes[d * 4 + 2], bry = boxes[d * 4 + 3];
+    const int bw = brx - ulx, bh = bry - uly;
+    const int dy = idx / S, dx = idx - dy * S;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    if (bw <= 0 || bh <= 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[((size_t)(d * 3 + c) * S + dy) * S + dx] = (0.0f - mean[c]) / stdv[c];
+        return;
+    }
+    // cv::resize INTER_LINEAR: fx = (float)((dx + 0.5) * scale - 0.5), sx = floor(fx), fx -= sx, clamped to the box
+    const double scale_x = (double)bw / (double)S, scale_y = (double)bh / (double)S;
+    float fx = (float)(((double)dx + 0.5) * scale_x - 0.5), fy = (float)(((double)dy + 0.5) * scale_y - 0.5);
+    int sx = (int)floorf(fx), sy = (int)floorf(fy);
+    fx -= (float)sx; fy -= (float)sy;
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= bw - 1) { fx = 0.f; sx = bw - 1; }
+    if (sy < 0) { fy = 0.f; sy = 0; }
+    if (sy >= bh - 1) { fy = 0.f; sy = bh - 1; }
+    const int sx1 = sx + 1 < bw ? sx + 1 : sx, sy1 = sy + 1 < bh ? sy + 1 : sy;
+    const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+    auto px = [&](int by, int bx, int c) -> double {   // box pixel (zero where the box leaves the frame)
+        const int iy = uly + by, ix = ulx + bx;
+        return ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? (double)frame[((size_t)iy * W + ix) * 3 + c] : 0.0;
+    };
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        // separate multiplies and adds (no fma contraction): the reference rounds each product
+        const double r0 = __dadd_rn(__dmul_rn(px(sy, sx, c), (double)a0), __dmul_rn(px(sy, sx1, c), (double)a1));     // horizontal pass
+        const double r1 = __dadd_rn(__dmul_rn(px(sy1, sx, c), (double)a0), __dmul_rn(px(sy1, sx1, c), (double)a1));
+        double v = __dadd_rn(__dmul_rn(r0, (double)b0), __dmul_rn(r1, (double)b1));                                     // vertical pass
+        v = fmin(255.0, fmax(0.0, v));                                                  // rgb_processing: pn = 1, clip
+        const float t = (float)v / 255.0f;                                              // astype('float32') / 255.0
+        out[((size_t)(d * 3 + c) * S + dy) * S + dx] = (t - mean[c]) / stdv[c];
+    }
+}
+
+int launch_crop_resize_normalize(const unsigned char* frame, int H, int W, const int* boxes, int n, int S, float* out,
+                                 const LaunchCtx& ctx) {
+    ProfScope ps(ctx, "crop_resize_normalize", 0.0, (double)n * S * S * 24.0);
+    hipLaunchKernelGGL(crop_resize_normalize_kernel, dim3((S * S + 255) / 256, n), dim3(256), 0, ctx.stream, frame, H, W, boxes, S, out);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // CamCalib frame transform (camcalib/pano_dataset.py:156-162): torchvision Resize(600) on a PIL image =
 // Pillow's separable triangle-filter resample (support grows with the down-scale factor, 22-bit fixed-point
 // coefficients, horizontal pass -> uint8 -> vertical pass -> uint8), then ToTensor + Normalize.

@@ -209,6 +209,10 @@ int launch_rotate_points(const float* R, const float* x, int B, int N, float* ou
 int launch_crop_normalize(const unsigned char* frame, int H, int W, const float* bboxes, int n, float scale, int S,
                           float* out, unsigned char* raw, float* bbox_scale, float* bbox_center, const LaunchCtx& ctx);
 
+// dataset crop: integer boxes (n,4) [ulx, uly, brx, bry] -> cv2.resize-style bilinear to S x S + ToTensor + Normalize
+int launch_crop_resize_normalize(const unsigned char* frame, int H, int W, const int* boxes, int n, int S, float* out,
+                                 const LaunchCtx& ctx);
+
 // Pillow-exact bilinear resize + ToTensor + Normalize (CamCalib frame transform)
 int pillow_coeffs(int in_size, int out_size, std::vector<int>& bounds, std::vector<int>& kk);
 int launch_resize_normalize(const unsigned char* frame, int H, int W, int OH, int OW, const int* hb, const int* hk, int ksh,

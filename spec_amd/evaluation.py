@@ -13,8 +13,8 @@ reading the reference's files in their real container formats:
   camcalib_vfov camcalib_f_pix``, spec/dataset/cam_dataset.py:56-146).
 
 Images are decoded with Pillow on the host (the reference uses cv2.imread), uploaded as uint8 frames and cropped /
-normalised on the device (``specmi_crop_normalize``; the reference dataset uses PARE's ``crop`` = box copy + cv2.resize,
-same box geometry, different resampling - see DESIGN.md).  Everything after that stays in HBM: forward, metrics.
+normalised on the device the way the reference dataset does it (``specmi_crop_resize_normalize``: PARE's ``crop`` = integer box
+copy + cv2.resize bilinear, clip, / 255, Normalize).  Everything after that stays in HBM: forward, metrics.
 """
 from __future__ import annotations
 
@@ -27,7 +27,7 @@ import torch
 from . import assets, io_formats, metrics
 from .cam_utils import cam_params_from_angles
 from .checkpoint import load_pretrained_model, read_checkpoint
-from .preprocess import crop_detections
+from .preprocess import dataset_crops
 
 # spec/config.py:34-56
 DATASET_FOLDERS = {'spec-mtp': 'data/dataset_folders/spec-mtp', 'spec-syn': 'data/dataset_folders/spec-syn',
@@ -100,9 +100,7 @@ class EvalDataset:
         for i in idx:
             frame = torch.from_numpy(read_image_rgb(os.path.join(self.img_dir, str(self.imgname[i])))).to(device)
             H, W = frame.shape[:2]
-            s = float(d['scale'][i])
-            box = np.array([[d['center'][i][0], d['center'][i][1], 200.0 * s, 200.0 * s]], np.float32)
-            crops.append(crop_detections(frame, box, scale=1.0, crop_size=img_res)['inp_images'])
+            crops.append(dataset_crops(frame, d['center'][i:i + 1], d['scale'][i:i + 1], img_res))   # cam_dataset.py:367-377
             shapes.append((H, W))
         shapes = np.asarray(shapes, np.float32)
         f = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32).to(device)

@@ -39,6 +39,51 @@ def crop_detections(frame_rgb_u8, dets, scale: float = 1.0, crop_size: int = 224
     return res
 
 
+def pare_crop_boxes(centers, scales, res: int = 224):
+    """Integer crop boxes of pare's ``crop(img, center, scale, [res, res])`` (SPIN / PARE image_utils): ``ul = transform([1, 1],
+    ..., invert=1) - 1``, ``br = transform([res + 1, res + 1], ..., invert=1) - 1`` with ``transform`` = 3x3 float64 matrix
+    (``h = 200 * scale``), ``np.linalg.inv``, ``.astype(int)`` (truncation toward zero) - restated with the same NumPy calls.
+    -> (n,4) int32 [ul_x, ul_y, br_x, br_y]."""
+    import numpy as np
+    out = []
+    for c, sc in zip(np.asarray(centers, dtype=np.float64).reshape(-1, 2), np.asarray(scales, dtype=np.float64).reshape(-1)):
+        h = 200 * sc
+        t = np.zeros((3, 3))
+        t[0, 0] = float(res) / h
+        t[1, 1] = float(res) / h
+        t[0, 2] = res * (-float(c[0]) / h + .5)
+        t[1, 2] = res * (-float(c[1]) / h + .5)
+        t[2, 2] = 1
+        ti = np.linalg.inv(t)
+
+        def tr(pt):
+            new_pt = np.dot(ti, np.array([pt[0] - 1, pt[1] - 1, 1.]).T)
+            return new_pt[:2].astype(int) + 1
+        ul = np.array(tr([1, 1])) - 1
+        br = np.array(tr([res + 1, res + 1])) - 1
+        out.append([ul[0], ul[1], br[0], br[1]])
+    return np.asarray(out, dtype=np.int32).reshape(-1, 4)
+
+
+@torch.no_grad()
+def dataset_crops(frame_rgb_u8, centers, scales, crop_size: int = 224):
+    """The evaluation dataset's image path on the device (spec/dataset/cam_dataset.py:253-287,367-377): pare ``crop`` (integer
+    box copy + cv2.resize bilinear) + clip + ``/ 255`` + ImageNet Normalize.  frame (H,W,3) uint8 device tensor, centers (n,2),
+    scales (n,) (bbox height / 200) -> (n,3,S,S) fp32."""
+    if not isinstance(frame_rgb_u8, torch.Tensor) or frame_rgb_u8.device.type != 'cuda':
+        raise RuntimeError('dataset_crops needs a device tensor (no CPU path in spec_amd)')
+    if frame_rgb_u8.dtype != torch.uint8 or frame_rgb_u8.dim() != 3 or frame_rgb_u8.shape[2] != 3:
+        raise ValueError('frame must be (H,W,3) uint8 RGB')
+    eng = _engine(frame_rgb_u8.device)
+    frame = frame_rgb_u8.contiguous()
+    boxes = torch.from_numpy(pare_crop_boxes(centers, scales, crop_size)).to(eng.device)
+    n, (H, W) = boxes.shape[0], frame.shape[:2]
+    out = torch.empty(n, 3, crop_size, crop_size, device=eng.device, dtype=torch.float32)
+    _lib.check(eng.h, eng.lib.specmi_crop_resize_normalize(eng.h, _ptr(frame), H, W, _ptr(boxes), n, crop_size, _ptr(out),
+                                                           eng._stream()))
+    return out
+
+
 def resize_output_size(w: int, h: int, min_size: int = 600):
     """``torchvision.transforms.Resize(min_size)`` geometry: shorter side -> min_size, longer ->
     ``int(min_size * long / short)``.  Returns (ow, oh)."""

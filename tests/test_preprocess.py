@@ -148,3 +148,45 @@ def test_gpu_resize_demo_sizes_and_camcalib():
         np.testing.assert_array_equal(x[0].cpu().numpy(), P.camcalib_transform(img, 600))
         lg = cc(x)
         assert all(torch.isfinite(l).all() and l.shape == (1, 256) for l in lg)
+
+
+# ---- evaluation-dataset crop (pare `crop` + cv2.resize + rgb_processing + Normalize) ---------------------------------------
+def test_dataset_crop_oracle_closed_form():
+    """cv2.resize-style bilinear (half-pixel centres) reproduces a linear ramp exactly where no border clamp applies, the box
+    arithmetic equals the reference's transform(), and a box that leaves the frame is zero padded."""
+    from oracle import preprocess as OP
+    from spec_amd.preprocess import pare_crop_boxes
+    ramp = np.tile((np.arange(90, dtype=np.float64) * 2.0 + 5.0)[None, :, None], (60, 1, 3))
+    out = OP.cv2_resize_linear_f64(ramp, 224, 224)
+    d = np.arange(224)
+    expect = 2.0 * ((d + 0.5) * (90 / 224) - 0.5) + 5.0
+    inner = (expect >= 5.0) & (expect <= 2.0 * 89 + 5.0)
+    assert np.abs(out[10, inner, 0] - expect[inner]).max() < 1e-4          # float coefficients, double accumulation
+    rng = np.random.default_rng(0)
+    centers, scales = rng.uniform(-20, 300, (50, 2)), rng.uniform(0.2, 2.5, 50)
+    boxes = pare_crop_boxes(centers, scales, 224)
+    for c, sc, b in zip(centers, scales, boxes):
+        ul = np.array(OP.transform([1, 1], c, sc, [224, 224], invert=1)) - 1
+        br = np.array(OP.transform([225, 225], c, sc, [224, 224], invert=1)) - 1
+        assert list(b) == [ul[0], ul[1], br[0], br[1]]
+        assert abs((b[2] - b[0]) - 200 * sc) <= 1.5 and abs((b[0] + b[2]) / 2 - c[0]) <= 1.0
+    img = np.full((40, 50, 3), 200, np.uint8)
+    x = OP.dataset_crop(img, [0.0, 0.0], 0.3, 224)                          # box [-30, 30)^2: three quarters outside
+    assert x.shape == (3, 224, 224) and abs(float(x[0, 10, 10]) - (0 - 0.485) / 0.229) < 1e-6
+    assert abs(float(x[0, 200, 200]) - (200 / 255 - 0.485) / 0.229) < 1e-6
+
+
+@pytest.mark.gpu
+def test_dataset_crop_gpu_bit_exact_vs_oracle():
+    import torch
+    from oracle import preprocess as OP
+    from spec_amd.preprocess import dataset_crops
+    rng = np.random.default_rng(3)
+    for (H, W) in ((360, 480), (97, 131), (720, 1280)):
+        img = (rng.random((H, W, 3)) * 255).astype(np.uint8)
+        centers = np.array([[W / 2, H / 2], [5.5, 7.25], [W - 3.0, H - 10.0], [W * 0.3, H * 0.8], [-40.0, H / 2]])
+        scales = np.array([min(H, W) / 200.0, 0.35, 1.7, 224 / 200.0, 0.9])
+        out = dataset_crops(torch.from_numpy(img).to('cuda:0'), centers, scales, 224).cpu().numpy()
+        for i in range(len(scales)):
+            ref = OP.dataset_crop(img, centers[i], scales[i], 224)
+            assert np.array_equal(out[i], ref), (H, W, i, np.abs(out[i] - ref).max())
