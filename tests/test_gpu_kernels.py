@@ -365,3 +365,37 @@ def test_winograd_and_stem_batch_split_beyond_2gib(eng):
     del ys
     ref = F.relu(F.conv2d(xs[idx], ws, stride=2, padding=3) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
     assert rel_err(got.numpy(), ref.numpy()) < 2e-5
+
+
+def _fuzz_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for _ in range(n):
+        k = int(rng.choice([1, 3]))
+        stride = int(rng.choice([1, 2]))
+        cin = int(rng.choice([32, 64, 96, 160, 256]))
+        cout = int(rng.choice([1, 3, 17, 32, 33, 48, 64, 100, 157, 192, 256]))
+        H, W = int(rng.integers(1 if k == 1 else 2, 23)), int(rng.integers(1 if k == 1 else 2, 23))
+        B = int(rng.integers(1, 5))
+        cases.append((B, H, W, cin, cout, k, stride, bool(rng.integers(0, 2)), bool(rng.integers(0, 2))))
+    return cases
+
+
+@pytest.mark.parametrize('case', _fuzz_cases(36, 20260926), ids=lambda c: 'b%d_%dx%d_c%d_%d_k%d_s%d_r%d_a%d' % c)
+def test_conv_random_shapes(eng, case):
+    """Seeded sweep over shapes no network here uses: odd spatial sizes down to 1x1, output channel counts that are not a
+    multiple of 4 / 32 / 64 (partial tiles, scalar epilogue path), both strides, with and without residual / ReLU."""
+    B, H, W, cin, cout, k, stride, use_res, relu = case
+    g = torch.Generator().manual_seed(B * 131 + H * 17 + W + cin + cout)
+    x = torch.randn(B, H, W, cin, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    sc = torch.rand(cout, generator=g) + 0.5
+    sh = torch.randn(cout, generator=g) * 0.1
+    pad = 1 if k == 3 else 0
+    oh, ow = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(B, oh, ow, cout, generator=g) if use_res else None
+    y = eng.conv2d(x.to(DEV), w.numpy(), sc.numpy(), sh.numpy(), stride, pad,
+                   residual=None if res is None else res.to(DEV), relu=relu).cpu()
+    ref = _conv_ref(x, w, sc, sh, stride, pad, res, relu)
+    assert y.shape == ref.shape
+    assert rel_err(y.numpy(), ref.numpy()) < 2e-5
