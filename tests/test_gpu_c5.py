@@ -117,3 +117,30 @@ def test_reference_demo_commands_on_standin_tree(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     from spec_amd import cam_utils as CU
     assert float(joblib.load(os.path.join(d, 'out_kl', 'im0.png.pkl'))['pitch']) in set(CU.pitch_bins_centers.tolist())
+
+
+@pytest.mark.parametrize('nv,B', [(1000, 3), (257, 9), (6890, 17)])
+def test_body_model_other_sizes_vs_oracle(nv, B):
+    """The SMPL-only handle (SPECMI_MODEL_SMPL) on body models of other vertex counts (partial 256-vertex workgroups, batch
+    sizes that are not a multiple of the 8-image skinning tile): native outputs and the 49-joint / projection head."""
+    from oracle import heads
+    from oracle.smpl import SMPLOracle, batch_rodrigues
+    from spec_amd import metrics, synth
+    model = synth.smpl_model(77, nv)
+    body = metrics.BodyModel(model, device=DEV)
+    rng = np.random.default_rng(nv + B)
+    pose = (rng.standard_normal((B, 72)) * 0.3).astype(np.float32)
+    betas = (rng.standard_normal((B, 10)) * 0.7).astype(np.float32)
+    v, j = body.native(t(pose).to(DEV), t(betas).to(DEV))
+    ov, oj = SMPLOracle(model).native_axis_angle(t(betas), t(pose))
+    assert v.shape == (B, nv, 3)
+    assert np.abs(v.cpu().numpy() - ov.numpy()).max() < 5e-6 and np.abs(j.cpu().numpy() - oj[:, :24].numpy()).max() < 5e-6
+    # SMPLHead (weak perspective) through the same handle: specmi_smpl_forward without a trunk
+    heads.set_assets(smpl_model=model)
+    R = batch_rodrigues(t(pose).reshape(-1, 3)).view(B, 24, 3, 3)
+    cam = torch.tensor([[0.9, 0.05, -0.02]]).repeat(B, 1)
+    ref = heads.SMPLHead(focal_length=5000., img_res=224)(R, t(betas), cam, normalize_joints2d=True)
+    out = body.engine.smpl(R.to(DEV), t(betas).to(DEV), cam.to(DEV))
+    for k in ('smpl_vertices', 'smpl_joints3d', 'smpl_joints2d', 'pred_cam_t'):
+        err = float(np.abs(out[k].cpu().numpy() - ref[k].numpy()).max() / np.abs(ref[k].numpy()).max())
+        assert err < 1e-5, (k, err)
