@@ -63,15 +63,10 @@ def main():
     rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())
     print(f'{"1x1 convs computed as":34s} {"trunk features vs fp64":>24s}')
     for terms, name in ((0, 'fp32 (the build)'), (6, '6 x bf16 products'), (3, '3 x bf16 products'), (1, '1 x bf16 product')):
-        F.conv2d = make_conv(terms)
-        torch.conv2d_backup = None
+        F.conv2d = make_conv(terms)          # nn.Conv2d.forward resolves F.conv2d at call time
         try:
-            import torch.nn.modules.conv as C
-            orig = C.F.conv2d
-            C.F.conv2d = make_conv(terms)
             y = trunk(x)
         finally:
-            C.F.conv2d = orig
             F.conv2d = _conv2d
         print(f'{name:34s} {rel(y, ref64):24.2e}')
     # one layer in isolation: layer3.*.conv1 shape (K = 1024 -> 256) on post-ReLU activations
