@@ -36,10 +36,26 @@ __global__ void __launch_bounds__(256) hr_stem3x3_kernel(const float* __restrict
     const long pix = (long)blockIdx.x * 64 + (threadIdx.x >> 2);
     const int g = threadIdx.x & 3;
     if (pix >= npix) return;
-    const int ox = (int)(pix % OW);
-    const long r = pix / OW;
-    const int oy = (int)(r % OH);
-    const long b = r / OH;
+    const unsigned upix = (unsigned)pix;                 // 32-bit index arithmetic (the launcher checks npix < 2^31)
+    const int ox = (int)(upix % (unsigned)OW);
+    const unsigned r = upix / (unsigned)OW;
+    const int oy = (int)(r % (unsigned)OH);
+    const unsigned b = r / (unsigned)OH;
+    // all 27 taps are loaded unconditionally from clamped coordinates and zeroed afterwards where they fall into the padding
+    // (a predicated load compiles to its own exec-masked branch + s_waitcnt: 27 memory latencies in a row)
+    const float* img = x + (size_t)b * 3 * H * W;
+    float tap[27];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - 1 + ky, cy = min(max(iy, 0), H - 1);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - 1 + kx, cx = min(max(ix, 0), W - 1);
+                tap[(c * 3 + ky) * 3 + kx] = img[(unsigned)((c * H + cy) * W + cx)];
+            }
+        }
     float acc[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -52,7 +68,7 @@ __global__ void __launch_bounds__(256) hr_stem3x3_kernel(const float* __restrict
             for (int kx = 0; kx < 3; ++kx) {
                 const int ix = ox * 2 - 1 + kx;
                 const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-                const float v = ok ? x[((b * 3 + c) * H + iy) * (long)W + ix] : 0.f;
+                const float v = ok ? tap[(c * 3 + ky) * 3 + kx] : 0.f;
                 const float* wk = ws + ((c * 3 + ky) * 3 + kx) * 64 + g * 16;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[e] = fmaf(v, wk[e], acc[e]);
@@ -81,22 +97,30 @@ struct FuseArgs {
 __global__ void __launch_bounds__(256) hr_fuse_sum_kernel(const FuseArgs a) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= a.total) return;
-    const int c4 = (int)(i % a.C4);
-    long pix = i / a.C4;
-    const int x = (int)(pix % a.W);
-    pix /= a.W;
-    const int y = (int)(pix % a.H);
-    const long b = pix / a.H;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < a.n; ++k) {
-        const int sh = a.sh[k];
-        const long src = ((b * (a.H >> sh) + (y >> sh)) * (long)(a.W >> sh) + (x >> sh)) * a.ld[k] + c4 * 4;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(a.p[k] + src);
-        if (k == 0) s = v;
-        else { s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3]; }
+    const unsigned ui = (unsigned)i;                     // 32-bit index arithmetic (the launcher checks the sizes)
+    const unsigned c4 = ui % (unsigned)a.C4;
+    unsigned pix = ui / (unsigned)a.C4;
+    const unsigned x = pix % (unsigned)a.W;
+    pix /= (unsigned)a.W;
+    const unsigned y = pix % (unsigned)a.H;
+    const unsigned b = pix / (unsigned)a.H;
+    // the (up to) four terms are loaded together; absent terms re-read term 0 and are dropped by the select below
+    f32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool has = k < a.n;                        // constant indices only: the argument struct stays in SGPRs
+        const int sh = has ? a.sh[k] : a.sh[0];
+        const unsigned ld = (unsigned)(has ? a.ld[k] : a.ld[0]);
+        const float* p = has ? a.p[k] : a.p[0];
+        const size_t src = ((size_t)(b * (unsigned)(a.H >> sh) + (y >> sh)) * (unsigned)(a.W >> sh) + (x >> sh)) * ld + c4 * 4;
+        v[k] = *reinterpret_cast<const f32x4*>(p + src);
     }
+    f32x4 s = v[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (k < a.n) { s[0] += v[k][0]; s[1] += v[k][1]; s[2] += v[k][2]; s[3] += v[k][3]; }
     if (a.relu) { s[0] = fmaxf(s[0], 0.f); s[1] = fmaxf(s[1], 0.f); s[2] = fmaxf(s[2], 0.f); s[3] = fmaxf(s[3], 0.f); }
-    *reinterpret_cast<f32x4*>(a.out + ((b * a.H + y) * (long)a.W + x) * a.ldo + c4 * 4) = s;
+    *reinterpret_cast<f32x4*>(a.out + ((size_t)(b * (unsigned)a.H + y) * (unsigned)a.W + x) * (unsigned)a.ldo + c4 * 4) = s;
 }
 
 // ---- F.interpolate(mode='bilinear', align_corners=True) on NHWC ------------------------------------------------------
@@ -331,6 +355,7 @@ struct Runner {
         for (int k = 0; k < 4; ++k) { a.p[k] = k < nt ? terms[k].p : nullptr; a.ld[k] = k < nt ? ld[k] : 0; a.sh[k] = k < nt ? sh[k] : 0; }
         a.n = nt; a.C4 = C / 4; a.H = hh[lvl]; a.W = ww[lvl]; a.relu = relu; a.out = out; a.ldo = ldo;
         a.total = (long)B * a.H * a.W * a.C4;
+        if (a.total >= (1L << 31)) return err = fail(h, SPECMI_ERR_ARG, "hrnet: %s has too many elements for 32-bit indexing", label);
         LaunchCtx ctx{s, &h->prof, label};
         ProfScope ps(ctx, "hrnet_fuse_sum", 0.0, 4.0 * a.total * 4 * (nt + 1));
         hipLaunchKernelGGL(hr_fuse_sum_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, s, a);
@@ -387,6 +412,7 @@ int hrnet_forward(specmi_handle* h, const float* images, int B, int H, int W, fl
     // ---- stem ------------------------------------------------------------------------------------------------------
     {
         const long npix = (long)B * oh1 * ow1;
+        if (npix >= (1L << 31) || (long)3 * H * W >= (1L << 31)) return fail(h, SPECMI_ERR_ARG, "hrnet stem: batch too large for 32-bit indexing");
         LaunchCtx ctx{s, &h->prof, "backbone.conv1"};
         ProfScope ps(ctx, "hrnet_stem3x3_f32", 2.0 * npix * 64 * 27, 4.0 * ((double)B * 3 * H * W + (double)npix * 64));
         hipLaunchKernelGGL(hr_stem3x3_kernel, dim3((unsigned)((npix + 63) / 64)), dim3(256), 0, s, images, n->conv1.w,

@@ -185,38 +185,48 @@ int launch_stem(const float* x, const float* w, const float* scale, const float*
 }
 
 // ------------------------------------------------------------------------------------------
+// One lane per (output pixel, 4 channels).  The 9 taps are loaded UNCONDITIONALLY from coordinates clamped into the image
+// (a clamped tap repeats a tap that is already in the window, so the maximum is unchanged): `if (outside) continue;`
+// compiles to one exec-masked branch and one s_waitcnt per load, i.e. nine memory latencies in a row.  Index arithmetic
+// is 32-bit (the launcher checks the sizes).  Workgroups are renumbered so that each XCD (workgroup id mod 8, the
+// dispatch order) owns one contiguous eighth of the output: the 3x3 / stride-2 windows of neighbouring output rows share
+// input rows, and that re-use then hits the XCD's own L2 instead of fetching the row again through another one.
 __global__ void __launch_bounds__(256) maxpool3x3s2_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                            int H, int W, int C4, int OH, int OW, long total) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % C4);
-        long pix = i / C4;
-        const int ox = (int)(pix % OW); pix /= OW;
-        const int oy = (int)(pix % OH);
-        const int b = (int)(pix / OH);
-        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                                                            int H, int W, int C4, int OH, int OW, unsigned total) {
+    const unsigned nb = gridDim.x, per = nb >> 3;
+    const unsigned blk = blockIdx.x < per * 8 ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : blockIdx.x;
+    const unsigned i = blk * 256u + threadIdx.x;
+    if (i >= total) return;
+    const unsigned c4 = i % (unsigned)C4;
+    unsigned pix = i / (unsigned)C4;
+    const int ox = (int)(pix % (unsigned)OW); pix /= (unsigned)OW;
+    const int oy = (int)(pix % (unsigned)OH);
+    const unsigned b = pix / (unsigned)OH;
+    const f32x4* img = reinterpret_cast<const f32x4*>(x) + (size_t)b * H * W * C4 + c4;
+    f32x4 v[9];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = oy * 2 - 1 + ky;
-            if ((unsigned)iy >= (unsigned)H) continue;
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = min(max(oy * 2 - 1 + ky, 0), H - 1);
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int ix = ox * 2 - 1 + kx;
-                if ((unsigned)ix >= (unsigned)W) continue;
-                const f32x4 v = reinterpret_cast<const f32x4*>(x)[((size_t)(b * H + iy) * W + ix) * C4 + c4];
-                m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
-            }
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = min(max(ox * 2 - 1 + kx, 0), W - 1);
+            v[ky * 3 + kx] = img[(unsigned)(iy * W + ix) * (unsigned)C4];
         }
-        reinterpret_cast<f32x4*>(out)[i] = m;
     }
+    f32x4 m = v[0];
+#pragma unroll
+    for (int k = 1; k < 9; ++k) { m[0] = fmaxf(m[0], v[k][0]); m[1] = fmaxf(m[1], v[k][1]); m[2] = fmaxf(m[2], v[k][2]); m[3] = fmaxf(m[3], v[k][3]); }
+    reinterpret_cast<f32x4*>(out)[i] = m;
 }
 
 int launch_maxpool3x3s2(const float* x, float* out, int B, int H, int W, int C, int OH, int OW, const LaunchCtx& ctx) {
     if (C % 4) return (int)hipErrorInvalidValue;
     const long total = (long)B * OH * OW * (C / 4);
-    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (total >= (1L << 31) - 256 || (long)H * W * (C / 4) >= (1L << 31)) return (int)hipErrorInvalidValue;   // 32-bit indices
     const double bytes = 4.0 * ((double)B * H * W * C + (double)B * OH * OW * C);
     ProfScope ps(ctx, "maxpool3x3s2_f32", 0.0, bytes);
-    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid), dim3(256), 0, ctx.stream, x, out, H, W, C / 4, OH, OW, total);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx.stream, x, out, H, W, C / 4, OH, OW,
+                       (unsigned)total);
     return (int)hipGetLastError();
 }
 
