@@ -151,7 +151,7 @@ int commit_conv(specmi_handle* h, const std::string& prefix, ConvW& c) {
     if ((rc = dev_upload(h, scale.data(), scale.size() * 4, (void**)&c.scale, h->param_allocs))) return rc;
     if ((rc = dev_upload(h, shift.data(), shift.size() * 4, (void**)&c.shift, h->param_allocs))) return rc;
     c.wino = nullptr;
-    if (c.k == 3 && c.stride == 1 && c.pad == 1 && cin % 16 == 0 && cout % 64 == 0) {
+    if (c.k == 3 && c.stride == 1 && c.pad == 1 && cin % 16 == 0 && (cout % 64 == 0 || (cout % 32 == 0 && cout > 64))) {
         std::vector<float> u;
         pack_wino_weights(wsrc, cout, cin, u);
         if ((rc = dev_upload(h, u.data(), u.size() * 4, (void**)&c.wino, h->param_allocs))) return rc;
@@ -1043,7 +1043,7 @@ int specmi_conv2d(specmi_handle* h, const float* x, int B, int H, int W, int Cin
     std::memcpy(sh.data(), shift_host, (size_t)Cout * 4);
     // option "winograd": 1 (default) = F(2x2,3x3) where the shape allows it, 0 = always the direct implicit GEMM
     const bool wino = !stem && opt_i(h, "winograd", 1) && KH == 3 && stride == 1 && pad == 1 && Cin % 16 == 0 &&
-                      Cout % 64 == 0 && !residual;
+                      (Cout % 64 == 0 || (Cout % 32 == 0 && Cout > 64));
     if (stem) pack_stem_weights(w_host, packed);
     else if (wino) pack_wino_weights(w_host, Cout, Cin, packed);
     else {

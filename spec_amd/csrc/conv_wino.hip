@@ -47,6 +47,7 @@ struct WArgs {
     const float* scale;
     const float* shift;
     float* out;
+    const float* res;      // residual added after BN, same layout as out (two-wave layout only), or nullptr
     unsigned x_bytes, u_bytes, out_bytes;
     int H, W, ldx, Cout, ldo;
     int TH, TW, THW, Mt;   // 2x2 output tiles per column / row / image / launch
@@ -85,8 +86,13 @@ __device__ __forceinline__ int wino_div(int n, int d, unsigned mg, unsigned sh) 
 // column, and the (tile, stage) sequence is one continuous software pipeline - the raw loads, the input
 // transform and the U / A fragments of the next tile's first stages are issued under the MFMAs of the
 // current tile's last stages, so only the first tile of a workgroup pays a prologue.
-template <int NF>
+// RES: out = [ReLU](BN(conv) + residual) - the BasicBlock tail of ResNet-34 / HRNet (pare BasicBlock.forward: out += identity
+// before the ReLU).  Two-wave layout only: its 32 residual values per lane are fetched between the two halves of the output
+// transform, when the 128 accumulator registers have just died, and before the first store (loads and stores retire in
+// order on one counter: a load issued after a store would wait for it).
+template <int NF, bool RES = false>
 __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(const WArgs p) {
+    static_assert(!(RES && NF == 16), "the residual epilogue exists for the two-wave layout only");
     constexpr int NWN = NF == 16 ? 4 : 2;          // co blocks (of 32) per workgroup
     constexpr bool TRIPLE = NF == 16;
     constexpr int SPS = 16 / NF;                    // loader pieces per MFMA step
@@ -110,6 +116,7 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(RES ? p.res : p.x), 0, RES ? p.out_bytes : 0, 0x00020000);
 
     // ---- loader role: thread = (tile tl, channel pair c2l) ------------------------------------
     const int c2l = tid & 7, tl = tid >> 3;
@@ -204,9 +211,13 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
     };
     const int co = nb * 32 + l31;
     const float sc = p.scale[co], sh = p.shift[co];
-    const unsigned co_b = (unsigned)(co * 4);
-    auto emit = [&](float v, unsigned off) {
+    // channels past Cout (last co column of a Cout % 64 == 32 layer: zero U block, see pack_wino_weights) are never stored:
+    // 2^30 added to any offset of a <= 2^30-byte output (launch_conv_wino guarantees that for such layers) is out of
+    // range, and added to kOOB it stays out of range (no wrap to a valid address)
+    const unsigned co_b = co < p.Cout ? (unsigned)(co * 4) : 0x40000000u;
+    auto emit = [&](float v, unsigned off, float resid = 0.f) {
         v = fmaf(v, sc, sh);
+        if (RES) v += resid;
         if (p.relu) v = fmaxf(v, 0.f);
         if (!WABL(32)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ors, off + co_b, 0, 0);
     };
@@ -344,13 +355,24 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
                     *reinterpret_cast<float*>(xw + (r * 2 + a) * 256) = fh == 0 ? Sx[a][1] : Sx[a][0];
                 }
             }
+            float rv[RES ? 16 : 1][2];
+            if (RES) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const u32x4 to = *reinterpret_cast<const u32x4*>(tab + ((r & 3) + 8 * (r >> 2)) * 16);
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)   // out-of-range tile / channel: the offset is out of range and reads 0
+                        rv[r][a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, (fh == 0 ? to[2 * a] : to[2 * a + 1]) + co_b, 0, 0));
+                }
+            }
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const u32x4 to = *reinterpret_cast<const u32x4*>(tab + ((r & 3) + 8 * (r >> 2)) * 16);
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
-                    emit(mine[r][a] + *reinterpret_cast<const float*>(xr + (r * 2 + a) * 256), fh == 0 ? to[2 * a] : to[2 * a + 1]);
+                    emit(mine[r][a] + *reinterpret_cast<const float*>(xr + (r * 2 + a) * 256), fh == 0 ? to[2 * a] : to[2 * a + 1],
+                         RES ? rv[r][a] : 0.f);
             }
             if (has_next) __syncthreads();   // the next tile's stage 0 transforms into this buffer
         }
@@ -383,8 +405,11 @@ static void wino_magic(unsigned d, unsigned* mg, unsigned* sh) {
 }
 
 bool conv_wino_supported(const ConvArgs& a) {
-    return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Cin % 16 == 0 && a.Cout % 64 == 0 &&
-           a.ldx % 2 == 0 && !a.res && a.OH == a.H && a.OW == a.W;
+    // Cout % 64 == 32 runs the 64-channel layout with half of its last co column idle: worth it from 96 channels
+    // (<= 25 % idle MFMAs against the direct kernel's 2.25x flops), not for 32
+    return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Cin % 16 == 0 &&
+           (a.Cout % 64 == 0 || (a.Cout % 32 == 0 && a.Cout > 64)) && a.ldx % 2 == 0 && a.OH == a.H && a.OW == a.W &&
+           (!a.res || (reinterpret_cast<uintptr_t>(a.res) & 3) == 0);
 }
 
 // OIHW (cout, cin, 3, 3) -> U = G g G^T packed [cout/32][cin/4][f/2][lane = h*32+n][(f&1)*2 + jj], f = 4i+j, ci = 4*mu + 2*h + jj
@@ -418,7 +443,7 @@ void conv_wino_set_persistent(int v) { g_wino_persistent = v; }
 
 static int wino_pick(const ConvArgs& a) {
     // ConvArgs::wino_variant (per handle): 0 auto, 16 / 8 = force the frequencies-per-wave variant
-    if (a.wino_variant == 8) return 8;
+    if (a.wino_variant == 8 || a.res) return 8;    // the residual epilogue exists in the two-wave layout only
     if (a.wino_variant == 16 && a.Cout % 128 == 0) return 16;
     // Measured on MI355X at B=256 (tools/wino_bench): two 128-accumulator waves per SIMD cover each other's
     // prologue / epilogue and win by ~10 % up to Cin = 256; from Cin = 512 (32 stages per tile) the
@@ -432,27 +457,27 @@ static int wino_pick(const ConvArgs& a) {
     return wgs16 < 128 ? 8 : 16;
 }
 
-template <int NF>
+template <int NF, bool RES = false>
 static int wino_launch_variant(WArgs k, int Cout, const LaunchCtx& ctx, double flops, double bytes) {
     constexpr int NT = NF == 16 ? 128 : 64;
     constexpr int smem = (NF == 16 ? 3 : 2) * WINO_BUF + 2 * WINO_TAB;
     static DevOnce once;
-    if (int e = set_dyn_lds_once(once, reinterpret_cast<const void*>(&conv_wino_f32_kernel<NF>), smem)) return e;
-    k.nbn = Cout / NT;
+    if (int e = set_dyn_lds_once(once, reinterpret_cast<const void*>(&conv_wino_f32_kernel<NF, RES>), smem)) return e;
+    k.nbn = (Cout + NT - 1) / NT;
     k.nbm = (k.Mt + 31) / 32;
     // persistent grid: as many workgroups as the chip holds at once (256 CUs x 1 or 2), split evenly over the
     // co columns; a single 16-channel stage cannot pipeline across tiles (the loads run two stages ahead)
     int G = (256 * (NF == 16 ? 1 : 2)) / k.nbn;
     if (G < 1) G = 1;
     if (G > k.nbm || k.nstage < 2 || g_wino_persistent == 0) G = k.nbm;
-    ProfScope ps(ctx, NF == 16 ? "conv_wino_f32<32t x128,F(2x2,3x3)>" : "conv_wino_f32<32t x64,F(2x2,3x3)>", flops, bytes);
-    hipLaunchKernelGGL(conv_wino_f32_kernel<NF>, dim3(G * k.nbn), dim3(256), smem, ctx.stream, k);
+    ProfScope ps(ctx, NF == 16 ? "conv_wino_f32<32t x128,F(2x2,3x3)>" : RES ? "conv_wino_f32<32t x64,F(2x2,3x3),res>" : "conv_wino_f32<32t x64,F(2x2,3x3)>", flops, bytes);
+    hipLaunchKernelGGL((conv_wino_f32_kernel<NF, RES>), dim3(G * k.nbn), dim3(256), smem, ctx.stream, k);
     return (int)hipGetLastError();
 }
 
 static int wino_launch_one(const ConvArgs& a, const LaunchCtx& ctx) {
     WArgs k;
-    k.x = a.x; k.u = a.w; k.scale = a.scale; k.shift = a.shift; k.out = a.out;
+    k.x = a.x; k.u = a.w; k.scale = a.scale; k.shift = a.shift; k.out = a.out; k.res = a.res;
     k.H = a.H; k.W = a.W; k.ldx = a.ldx; k.Cout = a.Cout; k.ldo = a.ldo;
     k.TH = (a.H + 1) / 2; k.TW = (a.W + 1) / 2; k.THW = k.TH * k.TW;
     k.Mt = a.B * k.THW;
@@ -469,7 +494,8 @@ static int wino_launch_one(const ConvArgs& a, const LaunchCtx& ctx) {
 #endif
     const double M = (double)a.B * a.H * a.W;
     const double flops = 2.0 * M * a.Cout * 9.0 * a.Cin;   // algorithmic (direct-convolution) flops
-    const double bytes = 4.0 * (M * a.Cin + M * a.Cout + 9.0 * a.Cin * a.Cout);
+    const double bytes = 4.0 * (M * a.Cin + M * a.Cout * (a.res ? 2.0 : 1.0) + 9.0 * a.Cin * a.Cout);
+    if (a.res) return wino_launch_variant<8, true>(k, a.Cout, ctx, flops, bytes);
     return wino_pick(a) == 16 ? wino_launch_variant<16>(k, a.Cout, ctx, flops, bytes)
                               : wino_launch_variant<8>(k, a.Cout, ctx, flops, bytes);
 }
@@ -478,14 +504,15 @@ int launch_conv_wino(const ConvArgs& a, const LaunchCtx& ctx) {
     if (!conv_wino_supported(a) || (reinterpret_cast<uintptr_t>(a.x) & 7)) return (int)hipErrorInvalidValue;
     const size_t in_bytes = (size_t)a.H * a.W * a.ldx * 4, o_bytes = (size_t)a.H * a.W * a.ldo * 4;
     const size_t img_bytes = in_bytes > o_bytes ? in_bytes : o_bytes;   // both sides use 32-bit buffer offsets
-    const size_t limit = (size_t)1 << 31;
-    if (img_bytes >= limit || (size_t)16 * a.Cin * a.Cout * 4 >= limit) return (int)hipErrorInvalidValue;
+    const size_t limit = (size_t)1 << (a.Cout % 64 ? 30 : 31);   // see co_b in the kernel
+    if (img_bytes >= limit || (size_t)16 * a.Cin * a.Cout * 4 >= ((size_t)1 << 31)) return (int)hipErrorInvalidValue;
     const int max_b = (int)((limit - 1) / img_bytes);
     for (int b0 = 0; b0 < a.B; b0 += max_b) {
         ConvArgs s = a;
         s.B = (a.B - b0 < max_b) ? a.B - b0 : max_b;
         s.x = a.x + (size_t)b0 * a.H * a.W * a.ldx;
         s.out = a.out + (size_t)b0 * a.OH * a.OW * a.ldo;
+        if (a.res) s.res = a.res + (size_t)b0 * a.OH * a.OW * a.ldo;
         const int rc = wino_launch_one(s, ctx);
         if (rc) return rc;
     }

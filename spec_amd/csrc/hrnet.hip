@@ -339,7 +339,7 @@ struct Runner {
         a.wino_variant = opt_i(h, "force_wino_variant", 0);
         LaunchCtx ctx{s, &h->prof, label};
         int rc;
-        if (c.wino && !res && out_c % 64 == 0 && opt_i(h, "winograd", 1) && conv_wino_supported(a)) {
+        if (c.wino && opt_i(h, "winograd", 1) && conv_wino_supported(a)) {
             a.w = c.wino;
             rc = launch_conv_wino(a, ctx);
         } else {

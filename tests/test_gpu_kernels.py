@@ -122,7 +122,8 @@ def test_conv_ragged_sizes_and_tiles(eng, B, H, W):
 
 
 @pytest.mark.parametrize('B,H,W', [(1, 7, 7), (3, 7, 9), (5, 5, 3), (2, 14, 14), (1, 56, 40), (7, 1, 1), (2, 2, 33)])
-@pytest.mark.parametrize('cin,cout,nf', [(16, 128, 16), (48, 384, 8), (128, 128, 0), (32, 64, 0), (64, 192, 0), (512, 128, 0)])
+@pytest.mark.parametrize('cin,cout,nf', [(16, 128, 16), (48, 384, 8), (128, 128, 0), (32, 64, 0), (64, 192, 0), (512, 128, 0),
+                                        (96, 96, 0), (48, 160, 0)])   # Cout % 64 == 32: half of the last co column is masked
 def test_conv_winograd_ragged(eng, B, H, W, cin, cout, nf):
     """Fused Winograd F(2x2,3x3) path: odd sizes (half-empty edge tiles), tile count not a multiple of
     the 32-tile workgroup, one and several 16-channel stages, several co blocks, both wave layouts; against the fp32
@@ -147,6 +148,32 @@ def test_conv_winograd_ragged(eng, B, H, W, cin, cout, nf):
             assert rel_err(y.numpy(), yd.numpy()) < 2e-5
 
 
+@pytest.mark.parametrize('B,H,W', [(1, 7, 7), (3, 9, 5), (2, 14, 14), (1, 56, 40), (5, 1, 3)])
+@pytest.mark.parametrize('cin,cout', [(64, 64), (128, 128), (96, 96), (32, 192), (512, 512)])
+def test_conv_winograd_residual(eng, B, H, W, cin, cout):
+    """BasicBlock tail (ResNet-34, HRNet branches): out = ReLU(BN(conv3x3(x)) + identity) on the Winograd kernel's residual
+    epilogue - against PyTorch-CPU fp32 and against this library's direct kernel; ragged tiles, masked co column (96)."""
+    g = torch.Generator().manual_seed(B * 977 + H * 31 + W + cin + cout)
+    x = torch.randn(B, H, W, cin, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    sc = torch.rand(cout, generator=g) + 0.5
+    sh = torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(B, H, W, cout, generator=g)
+    for relu in (True, False):
+        eng.profile(True)
+        y = eng.conv2d(x.to(DEV), w.numpy(), sc.numpy(), sh.numpy(), 1, 1, residual=res.to(DEV), relu=relu).cpu()
+        names = [e['kernel'] for e in eng.profile_read()]
+        eng.profile(False)
+        assert names == ['conv_wino_f32<32t x64,F(2x2,3x3),res>'], names
+        ref = _conv_ref(x, w, sc, sh, 1, 1, res, relu)
+        assert rel_err(y.numpy(), ref.numpy()) < 2e-5
+        if cin % 32 == 0:
+            eng.set_option('winograd', 0)
+            yd = eng.conv2d(x.to(DEV), w.numpy(), sc.numpy(), sh.numpy(), 1, 1, residual=res.to(DEV), relu=relu).cpu()
+            eng.set_option('winograd', 1)
+            assert rel_err(y.numpy(), yd.numpy()) < 2e-5
+
+
 def test_conv_winograd_kernel_is_used(eng):
     """The profiler names the kernel each launch ran: 3x3/s1 with Cout % 128 == 0 must hit conv_wino."""
     x = torch.randn(1, 8, 8, 32)
@@ -157,8 +184,14 @@ def test_conv_winograd_kernel_is_used(eng):
     eng.conv2d(x.to(DEV), w.numpy(), np.ones(128, np.float32), np.zeros(128, np.float32), 1, 1, relu=False)
     eng.set_option('winograd', 1)
     names = [e['kernel'] for e in eng.profile_read()]
-    eng.profile(False)
     assert any('conv_wino' in n for n in names) and any('conv_igemm' in n for n in names), names
+    # HRNet-W48's 96-channel branch: Winograd with a half-idle last column; 32 channels stay on the direct 128x32 tile
+    for cout, want in ((96, 'conv_wino'), (32, 'conv_igemm')):
+        w = torch.randn(cout, 32, 3, 3) * 0.05
+        eng.conv2d(x.to(DEV), w.numpy(), np.ones(cout, np.float32), np.zeros(cout, np.float32), 1, 1, relu=False)
+        names = [e['kernel'] for e in eng.profile_read()]
+        assert len(names) == 1 and want in names[0], (cout, names)
+    eng.profile(False)
 
 
 def test_conv_identity_asymmetric(eng):
