@@ -321,7 +321,9 @@ int launch_smpl_native(const SmplDev& m, const SmplArgs& a, float* joints24, con
     }
     if (a.vertices) {
         const double flops = 2.0 * (double)B * V * (3.0 * 207 + 30 + 288 + 9);
-        const double bytes = 4.0 * ((double)B * V * 3 + (double)tiles * V * (3.0 * 207 + 3 + 30 + 24));
+        // algorithmic HBM bytes: the body model once + every output once (the kernel re-reads its model slice once per
+        // tile of IT images - that re-use is served by L2, PMC: 251 MB read per launch at B = 256 - and is not counted)
+        const double bytes = 4.0 * ((double)B * V * 3 + (double)V * (3.0 * 207 + 3 + 30 + 24) + (double)B * (207 + 10 + 288));
         ProfScope ps(ctx, "smpl_skin_lbs", flops, bytes);
         hipLaunchKernelGGL(smpl_skin_kernel, dim3((V + 255) / 256, tiles), dim3(256), 0, ctx.stream, m.v_template,
                            m.shapedirs, m.posedirs, m.lbs_weights, betas_t, pf_t, a.A, a.vertices, ld_verts, V, B);
@@ -343,7 +345,9 @@ int launch_smpl(const SmplDev& m, const SmplArgs& a, const LaunchCtx& ctx) {
     }
     {
         const double flops = 2.0 * (double)B * V * (3.0 * 207 + 30 + 288 + 9);
-        const double bytes = 4.0 * ((double)B * V * 3 + (double)tiles * V * (3.0 * 207 + 3 + 30 + 24));
+        // algorithmic HBM bytes: the body model once + every output once (the kernel re-reads its model slice once per
+        // tile of IT images - that re-use is served by L2, PMC: 251 MB read per launch at B = 256 - and is not counted)
+        const double bytes = 4.0 * ((double)B * V * 3 + (double)V * (3.0 * 207 + 3 + 30 + 24) + (double)B * (207 + 10 + 288));
         ProfScope ps(ctx, "smpl_skin_lbs", flops, bytes);
         hipLaunchKernelGGL(smpl_skin_kernel, dim3((V + 255) / 256, tiles), dim3(256), 0, ctx.stream, m.v_template,
                            m.shapedirs, m.posedirs, m.lbs_weights, betas_t, pf_t, a.A, a.vertices, ld_verts, V, B);
