@@ -360,7 +360,8 @@ int launch_smpl(const SmplDev& m, const SmplArgs& a, const LaunchCtx& ctx) {
         j.joints3d = a.joints3d; j.joints2d = a.joints2d; j.cam_t = a.cam_t;
         j.ld_verts = ld_verts; j.ld_j3d = a.ld_j3d; j.ld_j2d = a.ld_j2d; j.ld_camt = a.ld_camt;
         j.V = V; j.mode = a.mode; j.normalize = a.normalize_joints2d; j.focal = a.focal_length; j.img_res = a.img_res;
-        ProfScope ps(ctx, "smpl_joints_project", 2.0 * B * V * 27.0, 4.0 * B * ((double)V * 3 + 9.0 * V + 49 * 5));
+        // algorithmic bytes: every mesh once + the 9 x V extra-joint regressor once (its per-image re-reads are L2 hits) + outputs
+        ProfScope ps(ctx, "smpl_joints_project", 2.0 * B * V * 27.0, 4.0 * ((double)B * V * 3 + 9.0 * V + (double)B * 49 * 5));
         hipLaunchKernelGGL(smpl_joints_kernel, dim3(B), dim3(256), 0, ctx.stream, j);
     }
     return (int)hipGetLastError();
