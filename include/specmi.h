@@ -230,7 +230,8 @@ int specmi_avgpool(specmi_handle* h, const float* x, int B, int HW, int C, float
  * get_single_image_crop_demo(frame, bbox, scale, crop_size) - 3-point affine (rot 0) +
  * cv2.warpAffine(INTER_LINEAR, BORDER_CONSTANT) fixed-point bilinear + ToTensor + ImageNet
  * Normalize (spec/constants.py:20-21) - from a uint8 RGB HWC frame in device memory to
- * (n,3,S,S) fp32 NCHW.  Optional outputs: raw (n,S,S,3) uint8 crop, bbox_scale = w/200 (n),
+ * (n,3,S,S) fp32 NCHW (frames of 4 GiB or more, or with a side of 2^24 pixels, are refused: 32-bit offsets).
+ * Optional outputs: raw (n,S,S,3) uint8 crop, bbox_scale = w/200 (n),
  * bbox_center (n,2). */
 int specmi_crop_normalize(specmi_handle* h, const uint8_t* frame_rgb_hwc, int H, int W,
                           const float* bboxes, int n, float scale, int crop_size, float* out_nchw,
