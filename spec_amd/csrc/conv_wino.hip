@@ -95,13 +95,18 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
     static_assert(!(RES && NF == 16), "the residual epilogue exists for the two-wave layout only");
     constexpr int NWN = NF == 16 ? 4 : 2;          // co blocks (of 32) per workgroup
     constexpr bool TRIPLE = NF == 16;
+#ifdef WINO_LATE_BARRIER
+    constexpr bool EARLYB = TRIPLE;                 // (measurement only) the old placement: the barrier closes the stage
+#else
+    constexpr bool EARLYB = true;
+#endif
     constexpr int SPS = 16 / NF;                    // loader pieces per MFMA step
     constexpr int UD = NF == 16 ? 1 : 2;            // U prefetch distance in micro-chunks (NF MFMA pairs each)
     constexpr int TAB0 = (TRIPLE ? 3 : 2) * WINO_BUF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef WINO_PROF
     const long long t_start = __builtin_amdgcn_s_memtime();
-    long long t_epi_sum = 0;
+    long long t_epi_sum = 0, t_seg[5] = {0, 0, 0, 0, 0};   // epilogue: transform + send, barrier, finish + stores, barrier; stage barriers
 #endif
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -124,6 +129,11 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
     // decode tile row tm: the 16 patch offsets of this thread's tile and, for the epilogue, the byte
     // offsets of the tile's 2x2 outputs (table slot `slot`; out-of-range offset = no load / no store)
     auto decode_tile = [&](int tm, int slot) {
+        // everything here is derived from an opaque copy of tid: values the compiler could recognise as loop invariants
+        // (tid >> 3, tid & 7, ...) would be hoisted out of the tile loop and, with no register to spare, spilled to scratch
+        int tid_ = tid;
+        asm volatile("" : "+v"(tid_));
+        const int c2l = tid_ & 7, tl = tid_ >> 3;
         const int t = tm * 32 + tl;
         const bool ok = t < p.Mt;
         const int tt = ok ? t : 0;
@@ -210,14 +220,15 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
         return *reinterpret_cast<const f32x2*>(vr + f_of(fl) * WINO_F_STRIDE + u * 2 * WINO_C2_STRIDE);
     };
     const int co = nb * 32 + l31;
-    const float sc = p.scale[co], sh = p.shift[co];
+    // the two-wave layout has no register to spare across the K loop: it re-reads these two in every epilogue
+    float sc = 0.f, sh = 0.f;
+    if (NF == 16) { sc = p.scale[co]; sh = p.shift[co]; }
     // channels past Cout (last co column of a Cout % 64 == 32 layer: zero U block, see pack_wino_weights) are never stored:
     // 2^30 added to any offset of a <= 2^30-byte output (launch_conv_wino guarantees that for such layers) is out of
     // range, and added to kOOB it stays out of range (no wrap to a valid address)
     const unsigned co_b = co < p.Cout ? (unsigned)(co * 4) : 0x40000000u;
-    auto emit = [&](float v, unsigned off, float resid = 0.f) {
+    auto emit = [&](float v, unsigned off) {   // one-wave layout
         v = fmaf(v, sc, sh);
-        if (RES) v += resid;
         if (p.relu) v = fmaxf(v, 0.f);
         if (!WABL(32)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ors, off + co_b, 0, 0);
     };
@@ -250,9 +261,11 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
     //   u == 2     : raw patch loads of the stage after that
     // "next stage" runs on into the next tile of this workgroup: its patch offsets replace the current
     // ones before stage S-2 (whose loads are the first that need them).
-    // TRIPLE: the single barrier of a stage sits after u == 2, so micro-chunk 3 already prefetches the
-    // first fragments of the next stage and no wave waits on LDS after a barrier.  Otherwise (two
-    // workgroups per CU cover for each other) the barrier closes the stage.
+    // The single barrier of a stage sits after u == 2: by then every wave has issued its last reads of this stage's
+    // buffer (micro-chunk 3's fragments are fetched during u == 2) and finished the next stage's V (written during
+    // u == 1), so micro-chunk 3 already prefetches the first fragments of the next stage and no wave waits on LDS after
+    // a barrier.  Two buffers are enough for that (the writes of stage st + 1 go to the buffer whose last reads preceded
+    // this barrier); the one-wave layout keeps a third so that a fast wave may run a whole stage ahead.
 #ifdef WINO_PROF
     const long long t_loop = __builtin_amdgcn_s_memtime();
 #endif
@@ -286,7 +299,7 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
                     if (!WABL(1) && (fl & 1)) load_u(u % UD, mu1, fl >> 1);
                     if (!WABL(8)) {
                     if (u < 3) af[fl] = read_a(vr_cur, u + 1, fl);   // rolling: consumed NF steps from now
-                    else if (TRIPLE) af[fl] = read_a(vr_nxt, 0, fl);
+                    else if (EARLYB) af[fl] = read_a(vr_nxt, 0, fl);
                     }
                     if (u == 1 && !WABL(4)) transform_step(fl, vw_nxt);
                     if (u == 2 && !WABL(2)) {
@@ -295,10 +308,16 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (TRIPLE && u == 2) __syncthreads();
+                if (EARLYB && u == 2 && !WABL(16)) __syncthreads();
             }
-            if (!TRIPLE) {
+            if (!EARLYB) {
+#if defined(WINO_PROF) && WINO_PROF > 1
+                const long long t_b0 = __builtin_amdgcn_s_memtime();
                 if (!WABL(16)) __syncthreads();
+                t_seg[4] += __builtin_amdgcn_s_memtime() - t_b0;
+#else
+                if (!WABL(16)) __syncthreads();
+#endif
 #pragma unroll
                 for (int fl = 0; fl < NF; ++fl) af[fl] = read_a(vr_nxt, 0, fl);
             }
@@ -312,8 +331,10 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
 #ifdef WINO_PROF
         const long long t_e0 = __builtin_amdgcn_s_memtime();
 #endif
-        const char* tab = smem + TAB0 + (it & 1) * WINO_TAB + hh * 64;
         if (NF == 16) {
+            int lane_ = tid & 63;                           // opaque copy, see decode_tile
+            asm volatile("" : "+v"(lane_));
+            const char* tab = smem + TAB0 + (it & 1) * WINO_TAB + (lane_ >> 5) * 64;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const u32x4 to = *reinterpret_cast<const u32x4*>(tab + ((r & 3) + 8 * (r >> 2)) * 16);
@@ -337,6 +358,13 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
             // output column 0 and needs S[a][2] from its partner; the fh = 1 wave finishes column 1 and
             // needs S[a][1].  32 floats per lane cross through the stage buffer that the last stage just
             // released (the other one already holds the next tile's first stage).
+            int lane = tid & 63;                            // opaque copy, see decode_tile
+            asm volatile("" : "+v"(lane));
+            const int l31 = lane & 31, hh = lane >> 5;
+            const int co = nb * 32 + l31;
+            sc = p.scale[co]; sh = p.shift[co];
+            const int coq = nb * 32 + (lane & 7) * 4;      // first of the four channels this lane stores
+            const unsigned cq_b = coq < p.Cout ? (unsigned)(coq * 4) : 0x40000000u;
             char* const xw = smem + o_nxt + wave * 8192 + lane * 4;               // this wave's 8 KB: [r][a][lane]
             const char* const xr = smem + o_nxt + (wave ^ NWN) * 8192 + lane * 4;   // the partner's
             float mine[16][2];
@@ -355,26 +383,62 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
                     *reinterpret_cast<float*>(xw + (r * 2 + a) * 256) = fh == 0 ? Sx[a][1] : Sx[a][0];
                 }
             }
-            float rv[RES ? 16 : 1][2];
-            if (RES) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const u32x4 to = *reinterpret_cast<const u32x4*>(tab + ((r & 3) + 8 * (r >> 2)) * 16);
-#pragma unroll
-                    for (int a = 0; a < 2; ++a)   // out-of-range tile / channel: the offset is out of range and reads 0
-                        rv[r][a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, (fh == 0 ? to[2 * a] : to[2 * a + 1]) + co_b, 0, 0));
-                }
-            }
+#ifdef WINO_PROF
+            const long long t_e1 = __builtin_amdgcn_s_memtime();
+#endif
             __syncthreads();
+#ifdef WINO_PROF
+            const long long t_e2 = __builtin_amdgcn_s_memtime();
+#endif
+            // Finish this wave's 32 outputs per lane (BN scale / shift applied here, where a lane owns one channel), then turn
+            // them by 90 degrees through LDS so that a lane holds FOUR consecutive channels of one pixel: 8 x 16-byte stores per
+            // lane instead of 32 dword stores.  The vector-memory unit of a CU takes store instructions one after the other
+            // whatever their width, and it is shared with the co-resident workgroup's K loop loads, so the dword version held
+            // up both workgroups.  The turn goes through the PARTNER's 8 KB (this wave is its only reader and has just read it;
+            // one wave's LDS instructions execute in order, so the reads above precede the writes below).
+            char* const tw = smem + o_nxt + (wave ^ NWN) * 8192;   // [tile][a][32 channels]
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const u32x4 to = *reinterpret_cast<const u32x4*>(tab + ((r & 3) + 8 * (r >> 2)) * 16);
+            for (int r = 0; r < 16; ++r)
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
-                    emit(mine[r][a] + *reinterpret_cast<const float*>(xr + (r * 2 + a) * 256), fh == 0 ? to[2 * a] : to[2 * a + 1],
-                         RES ? rv[r][a] : 0.f);
+                    mine[r][a] = fmaf(mine[r][a] + *reinterpret_cast<const float*>(xr + (r * 2 + a) * 256), sc, sh);
+            // (all 32 reads of the region are issued before the first write into it)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    *reinterpret_cast<float*>(tw + ((((r & 3) + 8 * (r >> 2) + 4 * hh) * 2 + a) * 32 + l31) * 4) = mine[r][a];
+            // lane -> (tile t = 4 i + lane / 16, pixel row a = (lane / 8) & 1, channel quad q = lane & 7); pixel column b = fh
+            const char* const tabw = smem + TAB0 + (it & 1) * WINO_TAB + (lane >> 4) * 16 + ((lane >> 3) & 1) * 8 + fh * 4;
+            f32x4 y[8];
+            unsigned yo[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                y[i] = *reinterpret_cast<const f32x4*>(tw + (i * 64 + lane) * 16);
+                yo[i] = *reinterpret_cast<const unsigned*>(tabw + i * 64) + cq_b;
             }
+            if (RES) {
+                f32x4 rv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)   // out-of-range tile / channel quad: the offset is out of range and reads 0
+                    rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, yo[i], 0, 0));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) y[i] += rv[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (p.relu)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) y[i][c] = fmaxf(y[i][c], 0.f);
+                if (!WABL(32)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y[i]), ors, yo[i], 0, 0);
+            }
+#ifdef WINO_PROF
+            const long long t_e3 = __builtin_amdgcn_s_memtime();
+#endif
             if (has_next) __syncthreads();   // the next tile's stage 0 transforms into this buffer
+#ifdef WINO_PROF
+            t_seg[0] += t_e1 - t_e0; t_seg[1] += t_e2 - t_e1; t_seg[2] += t_e3 - t_e2; t_seg[3] += __builtin_amdgcn_s_memtime() - t_e3;
+#endif
         }
         // a two-stage tile rewrites the store table before its first barrier
         if (NF == 16 && has_next && S <= 2) __syncthreads();
@@ -391,6 +455,7 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
         atomicAdd(p.tprof + 1, (unsigned long long)(t_end - t_loop - t_epi_sum));
         atomicAdd(p.tprof + 2, (unsigned long long)t_epi_sum);
         atomicAdd(p.tprof + 3, 1ull);
+        for (int i = 0; i < 5; ++i) atomicAdd(p.tprof + 4 + i, (unsigned long long)t_seg[i]);
     }
 #endif
 }
@@ -468,6 +533,9 @@ static int wino_launch_variant(WArgs k, int Cout, const LaunchCtx& ctx, double f
     // persistent grid: as many workgroups as the chip holds at once (256 CUs x 1 or 2), split evenly over the
     // co columns; a single 16-channel stage cannot pipeline across tiles (the loads run two stages ahead)
     int G = (256 * (NF == 16 ? 1 : 2)) / k.nbn;
+#ifdef WINO_PROF
+    if (const char* e = getenv("WINO_WG_PER_CU")) G = (256 * atoi(e)) / k.nbn;
+#endif
     if (G < 1) G = 1;
     if (G > k.nbm || k.nstage < 2 || g_wino_persistent == 0) G = k.nbm;
     ProfScope ps(ctx, NF == 16 ? "conv_wino_f32<32t x128,F(2x2,3x3)>" : RES ? "conv_wino_f32<32t x64,F(2x2,3x3),res>" : "conv_wino_f32<32t x64,F(2x2,3x3)>", flops, bytes);

@@ -100,7 +100,7 @@ int main(int argc, char** argv) {
             CK(hipFree(dref));
         }
         float ms = 0;
-        unsigned long long* dtp; CK(hipMalloc(&dtp, 64)); CK(hipMemset(dtp, 0, 64));
+        unsigned long long* dtp; CK(hipMalloc(&dtp, 128)); CK(hipMemset(dtp, 0, 128));
         if (L.count) {
             hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
             for (int i = 0; i < 60; ++i) launch_conv_wino(a, ctx);
@@ -115,7 +115,9 @@ int main(int argc, char** argv) {
             launch_conv_wino(a, ctx);
             CK(hipDeviceSynchronize());
             conv_wino_set_tprof(nullptr);
-            unsigned long long tp[4]; CK(hipMemcpy(tp, dtp, 32, hipMemcpyDeviceToHost));
+            unsigned long long tp[9]; CK(hipMemcpy(tp, dtp, 72, hipMemcpyDeviceToHost));
+            if (tp[3]) printf("    epilogue split: transform+send %.0f  barrier %.0f  finish+stores %.0f  barrier %.0f | stage barriers %.0f\n", (double)tp[4] / tp[3],
+                              (double)tp[5] / tp[3], (double)tp[6] / tp[3], (double)tp[7] / tp[3], (double)tp[8] / tp[3]);
             if (tp[3]) printf("    per-WG ticks(10ns): prologue %.0f  loop %.0f  epilogue %.0f   (n=%llu)\n", (double)tp[0] / tp[3], (double)tp[1] / tp[3], (double)tp[2] / tp[3], tp[3]);
         }
         const double fl = 2.0 * b * L.h * L.w * (double)L.cout * 9.0 * L.cin;
