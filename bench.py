@@ -296,6 +296,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='launch the ~120 kernels of a step eagerly')
     ap.add_argument('--dist', action='store_true', help='run the N > 1 code path (torch.distributed.run launch, RCCL process '
                                                         'group, asynchronous all-gather, two record buffers) even with --gpus 1')
+    ap.add_argument('--gather', choices=('full', 'joints'), default='full',
+                    help='N > 1 all-gather payload: the full 85,176-byte record per image, or the 2,496 bytes without vertices')
     ap.add_argument('--subbatch', type=int, default=-1, help='trunk sub-batch for the early stages (0 = off, -1 = library default)')
     ap.add_argument('--subbatch-layers', type=int, default=-1)
     args = ap.parse_args()
@@ -344,7 +346,7 @@ def main():
     # while the kernels of step s+1 run (at most 2 in flight; everything is drained inside the timed region).  The
     # kernels write the record in place; under graph replay two record buffers alternate so that step s+1 never
     # writes the buffer the collective of step s still reads.
-    gather = AsyncGather(depth=2) if use_dist else None
+    gather = AsyncGather(depth=2, payload=args.gather) if use_dist else None
 
     run = pipe
     launch_mode = 'eager launches'
@@ -359,22 +361,23 @@ def main():
             log('[bench] hipGraph capture failed, launching eagerly:', repr(e))
             run = pipe
 
-    def step():
-        if gather is not None:
+    def step(collect=True):
+        if gather is not None and collect:
             gather.reserve()        # the buffer this step writes must not be read by a pending collective
         out = run(x, scale, center, img_w, img_h)
-        if gather is not None:
-            return gather.submit(out)
+        if gather is not None and collect:
+            # zero-copy send of the record the kernels wrote: legal because two graph buffers alternate and reserve() ran
+            return gather.submit(out, inplace=True)
         return out
 
-    def timed(nsteps):
+    def timed(nsteps, collect=True):
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(nsteps):
-            step()
+            step(collect)
         if gather is not None:
             gather.drain()
         torch.cuda.synchronize()
@@ -426,9 +429,19 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ag_ms = e0.elapsed_time(e1) / 5
-        comm = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
+        # the same K steps with no collective at all: what the asynchronous gather costs on top of the compute
+        el_nc = timed(args.steps, collect=False)
+        tt = torch.tensor([el_nc], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ms_nc = float(tt.item()) / args.steps * 1e3
+        comm = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(), 'payload': args.gather,
                 'record_bytes_per_image': int(out['record'].shape[1] * 4),
-                'all_gather_ms_blocking': round(ag_ms, 3), 'gathered_MB_per_rank': round(full.numel() * 4 / 1e6, 1),
+                'sent_bytes_per_image': 2496 if args.gather == 'joints' else int(out['record'].shape[1] * 4),
+                'all_gather_ms_blocking_full_record': round(ag_ms, 3),
+                'gathered_MB_per_rank_full_record': round(full.numel() * 4 / 1e6, 1),
+                'ms_per_step_without_gather': round(ms_nc, 3), 'ms_per_step_with_async_gather': round(ms_per_step, 3),
+                'overlap_efficiency': round(ms_nc / ms_per_step, 4),
+                'receive_buffers': 'persistent x2', 'send': 'in place (record written by the kernels)' if args.gather == 'full' else '624-float slice copy',
                 'per_rank_images_per_s': per_rank}
 
     roof, stages, c2 = None, None, None

@@ -8,14 +8,10 @@ mkdir -p $OUT
 cd $R
 L=$OUT/wino_$TAG.txt
 : > $L
-echo "== check" >> $L
-timeout 120 tools/bin/wino_bench_a0 256 1 -1 0 1 0 >> $L 2>&1
-echo "== check B=8" >> $L
-timeout 120 tools/bin/wino_bench_a0 8 1 -1 0 1 0 >> $L 2>&1
-echo "== late barrier" >> $L
-timeout 120 tools/bin/wino_bench_late 256 0 -1 0 1 0 >> $L 2>&1
-echo "== 1 WG per CU" >> $L
-WINO_WG_PER_CU=1 timeout 120 tools/bin/wino_bench_a0 256 0 -1 0 1 0 >> $L 2>&1
-echo "== again" >> $L
-timeout 120 tools/bin/wino_bench_a0 256 0 -1 0 1 0 >> $L 2>&1
-grep -v "^odd.*-1 " $L
+for A in "" _a1 _a2 _a3; do
+for W in 1 2; do
+echo "== bench$A  WG per CU $W" >> $L
+WINO_WG_PER_CU=$W timeout 120 tools/bin/wino_bench$A 256 0 -1 0 1 >> $L 2>&1
+done
+done
+grep -v "^odd" $L

@@ -13,7 +13,7 @@ def __getattr__(name):
     if name in ('HMR', 'CameraRegressorNetwork'):
         from . import modules
         return getattr(modules, name)
-    if name in ('SpecPipeline', 'GraphedPipeline', 'AsyncGather', 'pack_outputs', 'unpack_outputs', 'gather_outputs',
+    if name in ('SpecPipeline', 'GraphedPipeline', 'AsyncGather', 'pack_outputs', 'unpack_outputs', 'gather_outputs', 'joints_payload', 'unpack_joints',
                 'shard_range', 'PACKED_KEYS'):
         from . import pipeline
         return getattr(pipeline, name)

@@ -93,18 +93,55 @@ class _StubDict(dict):
             self.__dict__.update(state)
 
 
-_ALLOWED_ROOTS = ('torch', 'collections', 'numpy', 'builtins', '_codecs', 'copyreg')
-_BLOCKED_BUILTINS = {'eval', 'exec', 'compile', 'open', '__import__', 'getattr', 'setattr', 'delattr', 'input', 'breakpoint'}
+def _allowed_globals():
+    """(module, name) pairs the fallback unpickler resolves for real: what tensors, storages and plain containers are
+    rebuilt from - the same set ``torch.load(weights_only=True)`` trusts, spelled out - plus the NumPy array
+    reconstructors Lightning checkpoints carry.  No package is trusted wholesale: ``torch.utils.collect_env.run``,
+    ``torch.hub.*``, ``numpy.load``, ``builtins.type`` / ``vars`` / ``map`` ... are all OUTSIDE this list and stubbed."""
+    allowed = {
+        ('collections', 'OrderedDict'), ('collections', 'Counter'), ('collections', 'defaultdict'),
+        ('builtins', 'set'), ('builtins', 'frozenset'), ('builtins', 'bytearray'), ('builtins', 'complex'),
+        ('builtins', 'dict'), ('builtins', 'list'), ('builtins', 'tuple'), ('builtins', 'int'), ('builtins', 'float'),
+        ('builtins', 'str'), ('builtins', 'bool'), ('builtins', 'bytes'), ('builtins', 'slice'), ('builtins', 'range'),
+        ('_codecs', 'encode'),
+        ('torch', 'Size'), ('torch', 'Tensor'), ('torch', 'device'), ('torch', 'dtype'),
+        ('torch.nn.parameter', 'Parameter'),
+        ('torch._utils', '_rebuild_tensor'), ('torch._utils', '_rebuild_tensor_v2'), ('torch._utils', '_rebuild_tensor_v3'),
+        ('torch._utils', '_rebuild_parameter'), ('torch._utils', '_rebuild_parameter_with_state'),
+        ('torch._utils', '_rebuild_device_tensor_from_cpu_tensor'), ('torch._utils', '_rebuild_device_tensor_from_numpy'),
+        ('torch._tensor', '_rebuild_from_type_v2'),
+        ('torch.storage', 'UntypedStorage'), ('torch.storage', 'TypedStorage'), ('torch.storage', '_load_from_bytes'),
+        ('torch.serialization', '_get_layout'),
+        ('numpy', 'ndarray'), ('numpy', 'dtype'),
+        ('numpy.core.multiarray', '_reconstruct'), ('numpy.core.multiarray', 'scalar'),
+        ('numpy._core.multiarray', '_reconstruct'), ('numpy._core.multiarray', 'scalar'),
+        ('numpy.core.numeric', '_frombuffer'), ('numpy._core.numeric', '_frombuffer'),
+    }
+    allowed.discard(('torch.storage', '_load_from_bytes'))   # unpickles a nested stream with the stock pickle: not trusted
+    for t in ('Float', 'Double', 'Half', 'BFloat16', 'Long', 'Int', 'Short', 'Char', 'Byte', 'Bool',
+              'ComplexFloat', 'ComplexDouble'):
+        allowed.add(('torch', t + 'Storage'))
+        allowed.add(('torch', t + 'Tensor'))
+    for t in ('float32', 'float64', 'float16', 'bfloat16', 'int64', 'int32', 'int16', 'int8', 'uint8', 'bool',
+              'complex64', 'complex128', 'float', 'double', 'half', 'long', 'int', 'short'):
+        allowed.add(('torch', t))
+    for t in ('float32', 'float64', 'float16', 'int64', 'int32', 'int16', 'int8', 'uint8', 'uint16', 'uint32', 'uint64',
+              'bool_', 'longlong', 'intc'):
+        allowed.add(('numpy', t))
+    return allowed
+
+
+_ALLOWED = _allowed_globals()
 
 
 class _TolerantUnpickler(pickle.Unpickler):
-    """Fallback unpickler for Lightning checkpoints: only torch / collections / numpy (and harmless builtins) are
-    resolved for real; every other global a checkpoint names (yacs CfgNode, pytorch_lightning containers, argparse
-    namespaces, arbitrary user classes) becomes an inert stub, so nothing outside that allow-list can execute."""
+    """Fallback unpickler for Lightning checkpoints.  Only the explicit (module, name) pairs of ``_allowed_globals`` -
+    tensor / storage / array reconstructors, dtypes and plain containers - are resolved for real; every other global a
+    checkpoint names (yacs CfgNode, pytorch_lightning containers, argparse namespaces, user classes, and any callable
+    of torch / numpy / builtins that is not on the list) becomes an inert stub whose call returns another stub."""
 
     def find_class(self, module, name):
-        root = module.split('.')[0]
-        if root in _ALLOWED_ROOTS and not (root == 'builtins' and name in _BLOCKED_BUILTINS):
+        if (module, name) in _ALLOWED:
             try:
                 return super().find_class(module, name)
             except (ImportError, AttributeError, ModuleNotFoundError):
@@ -119,8 +156,8 @@ _tolerant_pickle = types.SimpleNamespace(
 
 def read_checkpoint(path, map_location='cpu'):
     """torch.load of a reference checkpoint.  First ``weights_only=True``; ONLY when that fails because the pickle
-    names a class outside torch's allow-list (``pickle.UnpicklingError``) it is re-read with the restricted stubbing
-    unpickler above.  I/O errors, truncated or corrupt files propagate instead of triggering the fallback."""
+    names a class outside torch's allow-list (``pickle.UnpicklingError``) it is re-read with the allow-list
+    unpickler above (explicit reconstructor names only; everything else is stubbed).  I/O errors, truncated or corrupt files propagate instead of triggering the fallback."""
     try:
         return torch.load(path, map_location=map_location, weights_only=True)
     except pickle.UnpicklingError:

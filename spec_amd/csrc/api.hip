@@ -429,6 +429,11 @@ static int ensure_ws(specmi_handle* h, int B, int H, int W) {
     free_pool(h->ws_allocs);
     if (elems < h->act_elems) elems = h->act_elems;
     const int Bw = B > h->ws_B ? B : h->ws_B;
+    // the workspace is gone from here on: if an allocation below fails, the next call must not take the early return
+    // above on the strength of the old sizes and launch kernels on freed memory
+    h->act_elems = 0; h->ws_B = 0;
+    for (int i = 0; i < 4; ++i) h->act[i] = nullptr;
+    h->splitk_ws = nullptr; h->zeros = nullptr; h->splitk_floats = 0;
     int rc;
     for (int i = 0; i < 4; ++i)
         if ((rc = dev_alloc(h, elems * 4, (void**)&h->act[i], h->ws_allocs))) return rc;

@@ -373,6 +373,12 @@ static int hr_ensure_pool(specmi_handle* h, HrNet* n, int B, int H, int W, const
     for (void* p : n->allocs) (void)hipFree(p);
     n->allocs.clear();
     const int Bw = B > n->pool_B ? B : n->pool_B;
+    // the pool is gone from here on: a failed hipMalloc below must not leave the old geometry (and with it the early
+    // return above) pointing at freed slots
+    n->pool_B = n->pool_H = n->pool_W = 0;
+    n->feat_ws = nullptr;
+    for (int l = 0; l < 4; ++l)
+        for (int i = 0; i < HR_SLOTS; ++i) { n->slot[l][i] = nullptr; n->used[l][i] = false; }
     for (int l = 0; l < 4; ++l) {
         const size_t bytes = (size_t)Bw * hh[l] * ww[l] * n->Cp[l] * 4;
         for (int i = 0; i < HR_SLOTS; ++i) {

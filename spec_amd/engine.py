@@ -247,6 +247,8 @@ class Engine:
         R, K, sc, ce, iw, ih = self._cam_args(B, cam_rotmat, cam_intrinsics, bbox_scale, bbox_center, img_w, img_h)
         views = self._out_for(B, record)
         out = views if views is not None else self._hmr_outputs(B)
+        if B == 0:                      # empty batch: empty outputs, like hmr_forward / trunk
+            return out
         o = _lib.HmrOutputs(**{k: out[k].data_ptr() for k, _ in _lib.HmrOutputs._fields_})
         _lib.check(self.h, self.lib.specmi_hmr_regress(
             self.h, _ptr(f), B, fh, fw, _ptr(R), _ptr(K), _ptr(sc), _ptr(ce), _ptr(iw), _ptr(ih),
@@ -263,6 +265,8 @@ class Engine:
         views = self._out_for(B, record)
         out = ({k: views[k] for k in ('pred_pose', 'pred_shape', 'pred_cam', 'pred_pose_6d')} if views is not None else
                {'pred_pose': mk(B, 24, 3, 3), 'pred_shape': mk(B, 10), 'pred_cam': mk(B, 3), 'pred_pose_6d': mk(B, 144)})
+        if B == 0:
+            return out
         _lib.check(self.h, self.lib.specmi_hmr_head_forward(
             self.h, _ptr(f), B, fh, fw, _ptr(R), _ptr(K), _ptr(ih), _ptr(out['pred_pose']),
             _ptr(out['pred_shape']), _ptr(out['pred_cam']), _ptr(out['pred_pose_6d']), self._stream()))
@@ -282,6 +286,8 @@ class Engine:
                if views is not None else
                {'smpl_vertices': mk(B, self.num_verts, 3), 'smpl_joints3d': mk(B, 49, 3),
                 'smpl_joints2d': mk(B, 49, 2), 'pred_cam_t': mk(B, 3)})
+        if B == 0:
+            return out
         _lib.check(self.h, self.lib.specmi_smpl_forward(
             self.h, _ptr(rot), _ptr(be), _ptr(cm), B, _ptr(R), _ptr(K), _ptr(sc), _ptr(ce), _ptr(iw),
             _ptr(ih), _ptr(out['smpl_vertices']), _ptr(out['smpl_joints3d']), _ptr(out['smpl_joints2d']),

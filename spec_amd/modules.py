@@ -250,13 +250,25 @@ class _EngineModule(nn.Module):
         self._invalidate()
         return super()._apply(fn, *a, **k)
 
+    def __setattr__(self, name, value):
+        # assigning a new nn.Parameter / buffer tensor / submodule replaces tensors the cached list still points at
+        if isinstance(value, (torch.Tensor, nn.Module)) and '_tracked' in self.__dict__:
+            self.__dict__['_tracked'] = None
+            self.__dict__['_sig'] = None
+        super().__setattr__(name, value)
+
     # Parameters are re-uploaded when any tensor was replaced or modified in place.  The tensor list is cached
     # (walking ~330 state_dict entries per forward matters at batch 1) and rebuilt after load_state_dict / _apply;
     # the per-forward check is (data_ptr, _version) of the cached tensors.  In-place edits through ``.data`` do not
-    # bump ``_version`` and assigning a new nn.Parameter object is not seen by the cache: call ``commit()`` after either.
+    # bump ``_version``: call ``commit()`` after those.  Replaced tensors are caught: assignments on this module
+    # invalidate the list (__setattr__), and for children (``m.backbone.conv1.weight = ...``, ``child.load_state_dict(...,
+    # assign=True)``) the signature carries the identity of every parameter / buffer object as the module tree yields
+    # them now - a walk over ~330 cached-attribute lookups, far cheaper than building a state_dict.
     def _signature(self):
-        if self._tracked is None:
+        ids = tuple(id(p) for p in self.parameters()) + tuple(id(b) for b in self.buffers())
+        if self._tracked is None or self.__dict__.get('_tracked_ids') != ids:
             self._tracked = list(self.state_dict(keep_vars=True).values())
+            self.__dict__['_tracked_ids'] = ids
         return tuple((v.data_ptr(), v._version) for v in self._tracked)
 
     def _options(self):

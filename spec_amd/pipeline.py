@@ -89,8 +89,8 @@ class SpecPipeline:
         out.update({'cam_vfov': cam['vfov'], 'cam_pitch': cam['pitch'], 'cam_roll': cam['roll'],
                     'cam_f_pix': cam['f_pix'], 'cam_rotmat': cam['cam_rotmat'],
                     'cam_intrinsics': cam['cam_intrinsics']})
-        if record is not None:
-            out['record'] = record
+        if record is not None and self.hmr.use_cam:
+            out['record'] = record     # (without use_cam only the angle columns were written: no packed record to hand out)
         return out
 
 
@@ -118,6 +118,8 @@ class GraphedPipeline:
             with torch.cuda.graph(g, capture_error_mode='thread_local', **kw):
                 out = pipeline(*self.static_in)
             self.graphs.append(g)
+            if isinstance(out, dict) and out.get('record') is not None:
+                out['record'].specmi_static_buffers = max(1, buffers)   # replay overwrites this record: AsyncGather must not send it blindly
             self.static_outs.append(out)
         self.graph, self.static_out = self.graphs[0], self.static_outs[0]
 
@@ -163,23 +165,69 @@ def unpack_outputs(packed: torch.Tensor, num_verts: int) -> Dict[str, torch.Tens
     return res
 
 
-class AsyncGather:
-    """The per-step all-gather taken off the critical path: ``submit(out)`` packs the step's outputs and starts
-    the collective with ``async_op=True`` (RCCL runs it on its own stream once the packing kernel is done), so it
-    overlaps the NEXT step's kernels; at most ``depth`` collectives are in flight (the oldest is waited for before
-    a new one is queued, which also bounds memory), ``drain()`` waits for the rest.  Results come back in
-    submission order."""
+JOINT_KEYS = tuple(k for k, _ in PACKED_KEYS if k != 'smpl_vertices')
 
-    def __init__(self, depth: int = 2, group=None, keep_results: bool = False):
-        self.depth, self.group, self.keep = max(1, depth), group, keep_results
+
+def joints_payload(out: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """The record without its vertices (joints3d | joints2d | cam_t | pose | cam | shape | pose6d |
+    camera angles = 624 floats = 2,496 B per image) as a fresh contiguous (B, 624) tensor: 0.64 MB per rank at B = 256
+    instead of 21.8 MB.  Always a copy (the columns are a strided slice of the record)."""
+    rec = out.get('record')
+    B = out['pred_cam'].shape[0]
+    if rec is not None:
+        nj = sum(out[k].reshape(B, -1).shape[1] for k in JOINT_KEYS)
+        return rec[:, rec.shape[1] - nj:].contiguous()
+    return torch.cat([out[k].reshape(B, -1) for k in JOINT_KEYS], dim=1).contiguous()
+
+
+def unpack_joints(packed: torch.Tensor) -> Dict[str, torch.Tensor]:
+    B = packed.shape[0]
+    res, off = {}, 0
+    for k, shp in PACKED_KEYS:
+        if shp is None:
+            continue
+        n = 1
+        for s_ in shp:
+            n *= s_
+        res[k] = packed[:, off:off + n].reshape(B, *shp)
+        off += n
+    return res
+
+
+class AsyncGather:
+    """The per-step all-gather taken off the critical path: ``submit(out)`` starts the collective with
+    ``async_op=True`` (RCCL runs it on its own stream once the step's kernels are done), so it overlaps the NEXT
+    step's kernels; at most ``depth`` collectives are in flight (the oldest is waited for before a new one is
+    queued), ``drain()`` waits for the rest.  Results come back in submission order.
+
+    Buffers: the receive side is ``depth`` PERSISTENT tensors used round-robin (no per-step allocation: 174 MB at
+    N = 8); a result is valid until ``depth`` further submits.  The send side is safe by default:
+
+    * a record that is a fresh tensor of this step (``SpecPipeline`` called eagerly) is sent as it is and kept
+      referenced until its collective has finished;
+    * a STATIC record that the next graph replay overwrites (``GraphedPipeline`` marks its records with
+      ``specmi_static_buffers`` = number of alternating buffers) is CLONED first, unless the caller asks for
+      ``submit(out, inplace=True)`` - which is only accepted when the pipeline alternates at least ``depth`` buffers
+      and ``reserve()`` was called before the step was enqueued (so the collective that last read the buffer the
+      step wrote had finished); anything else raises instead of silently corrupting gathered results;
+    * ``payload='joints'`` sends the 2.5 KB-per-image record without vertices (always a small fresh copy).
+    """
+
+    def __init__(self, depth: int = 2, group=None, keep_results: bool = False, payload: str = 'full'):
+        if payload not in ('full', 'joints'):
+            raise ValueError("payload must be 'full' or 'joints'")
+        self.depth, self.group, self.keep, self.payload = max(1, depth), group, keep_results, payload
         self.pending = []
         self.results = []
+        self._recv = []          # persistent receive buffers
+        self._turn = 0
+        self._reserved = False   # reserve() called since the last submit
 
     def _retire(self):
-        work, full = self.pending.pop(0)
+        work, full, _send = self.pending.pop(0)
         work.wait()
         if self.keep:
-            self.results.append(full)
+            self.results.append(full.clone())     # the receive buffer itself is reused
         self.last = full
 
     def reserve(self):
@@ -188,15 +236,42 @@ class AsyncGather:
         free.  ``work.wait()`` makes the current stream wait, not the host."""
         while len(self.pending) >= self.depth:
             self._retire()
+        self._reserved = True
 
-    def submit(self, out: Dict[str, torch.Tensor]):
+    def _recv_buffer(self, rows, cols, like):
+        if len(self._recv) < self.depth or any(t.shape != (rows, cols) or t.device != like.device or t.dtype != like.dtype
+                                               for t in self._recv):
+            if self.pending:          # shape change with collectives in flight: finish them before dropping their buffers
+                self.drain()
+            self._recv = [torch.empty(rows, cols, device=like.device, dtype=like.dtype) for _ in range(self.depth)]
+            self._turn = 0
+        buf = self._recv[self._turn]
+        self._turn = (self._turn + 1) % self.depth
+        return buf
+
+    def submit(self, out: Dict[str, torch.Tensor], inplace: bool = False):
         import torch.distributed as dist
+        reserved = self._reserved
         self.reserve()
-        packed = pack_outputs(out)
+        self._reserved = False
+        if self.payload == 'joints':
+            send = joints_payload(out)
+        else:
+            send = pack_outputs(out)
+            static = getattr(send, 'specmi_static_buffers', None)
+            if static is not None:
+                if not inplace:
+                    send = send.clone()
+                elif int(static) < self.depth or not reserved:
+                    raise RuntimeError(
+                        f'AsyncGather.submit(inplace=True): the record is a static graph buffer ({int(static)} alternating '
+                        f'buffers, depth {self.depth}, reserve() before the step: {reserved}); the next replay would '
+                        'overwrite it while the collective still reads it.  Use GraphedPipeline(buffers >= depth) and call '
+                        'reserve() before every step, or submit without inplace.')
         world = dist.get_world_size(self.group)
-        full = torch.empty(world * packed.shape[0], packed.shape[1], device=packed.device, dtype=packed.dtype)
-        work = dist.all_gather_into_tensor(full, packed, group=self.group, async_op=True)
-        self.pending.append((work, full))
+        full = self._recv_buffer(world * send.shape[0], send.shape[1], send)
+        work = dist.all_gather_into_tensor(full, send, group=self.group, async_op=True)
+        self.pending.append((work, full, send))     # send stays referenced until the collective has finished
         return full
 
     def drain(self):

@@ -61,16 +61,37 @@ def main():
     ag = AsyncGather(depth=2, keep_results=True)
     for s_ in range(steps):
         ag.reserve()
-        ag.submit(gp(*mine[s_]))
+        ag.submit(gp(*mine[s_]), inplace=True)
     res = ag.drain()
+    # (3) ONE static record buffer and no reserve(): the default submit() clones, so the next replay cannot corrupt the
+    # collective; plus the joints-only payload (record without vertices)
+    gp1 = GraphedPipeline(pipe, *mine[0], buffers=1)
+    ag1 = AsyncGather(depth=2, keep_results=True)
+    agj = AsyncGather(depth=2, keep_results=True, payload='joints')
+    for s_ in range(steps):
+        o = gp1(*mine[s_])
+        ag1.submit(o)
+        agj.submit(o)
+    res1, resj = ag1.drain(), agj.drain()
+    refused = False
+    try:
+        ag1.submit(gp1(*mine[0]), inplace=True)
+    except RuntimeError:
+        refused = True
+    ag1.drain()
     torch.cuda.synchronize()
-    ok = True
+    ok = refused
+    if not refused:
+        print('inplace submit of a single static buffer was not refused')
     if rank == 0:
         for s_ in range(steps):
             ref = pipe(*[a.to(dev) for a in batches[s_]])['record']
             if not torch.equal(res[s_], ref):
                 ok = False
                 print('step', s_, 'mismatch: max abs diff', float((res[s_] - ref).abs().max()))
+            if not torch.equal(res1[s_], ref) or not torch.equal(resj[s_], ref[:, ref.shape[1] - 624:]):
+                ok = False
+                print('step', s_, 'cloned / joints-only gather mismatch')
         if not torch.equal(full0, res[0]):
             ok = False
             print('blocking gather differs from the asynchronous one')

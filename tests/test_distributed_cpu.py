@@ -10,7 +10,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from spec_amd.pipeline import PACKED_KEYS, AsyncGather, gather_outputs, pack_outputs, shard_range, unpack_outputs
+from spec_amd.pipeline import (PACKED_KEYS, AsyncGather, gather_outputs, joints_payload, pack_outputs, shard_range,
+                               unpack_joints, unpack_outputs)
 
 V = 37  # small synthetic vertex count
 
@@ -49,10 +50,43 @@ def _worker(rank, world, port, total, q):
             ag2.reserve()
             buf = bufs[step % 2]
             buf.copy_(rec0 + 100.0 * step)                 # stands for the kernels writing the record
-            got = ag2.submit({'record': buf, 'pred_cam': out['pred_cam']})
+            buf.specmi_static_buffers = 2                  # what GraphedPipeline(buffers=2) marks its records with
+            got = ag2.submit({'record': buf, 'pred_cam': out['pred_cam']}, inplace=True)
             assert got.shape[0] == world * rec0.shape[0]
         steps2 = ag2.drain()
         ok = ok and len(steps2) == 6 and all(torch.equal(s_, full + 100.0 * i) for i, s_ in enumerate(steps2))
+        # persistent receive buffers: two tensors, reused round-robin
+        ok = ok and len(ag2._recv) == 2 and len({t.data_ptr() for t in ag2._recv}) == 2
+        # a static record sent WITHOUT inplace is cloned: overwriting it right after submit must not change the result
+        ag3 = AsyncGather(depth=2, keep_results=True)
+        one = bufs[0]
+        one.specmi_static_buffers = 1
+        for step in range(4):
+            one.copy_(rec0 + 100.0 * step)
+            ag3.submit({'record': one, 'pred_cam': out['pred_cam']})
+            one.fill_(-1.0)                                # "the next replay" tramples the static buffer
+        steps3 = ag3.drain()
+        ok = ok and all(torch.equal(s_, full + 100.0 * i) for i, s_ in enumerate(steps3))
+        # ... and inplace on it is refused (one buffer < depth 2, or no reserve() before the step)
+        for nbuf, do_reserve in ((1, True), (2, False)):
+            one.specmi_static_buffers = nbuf
+            ag4 = AsyncGather(depth=2)
+            if do_reserve:
+                ag4.reserve()
+            try:
+                ag4.submit({'record': one, 'pred_cam': out['pred_cam']}, inplace=True)
+                ok = False
+            except RuntimeError:
+                pass
+        # joints-only payload (2,496 B per image)
+        agj = AsyncGather(depth=2, keep_results=True, payload='joints')
+        agj.submit(out)
+        agj.submit({'record': rec0, 'pred_cam': out['pred_cam'], **{k: out[k] for k, _ in PACKED_KEYS}})
+        js = agj.drain()
+        nj = joints_payload(out).shape[1]
+        ok = ok and nj == 624 and all(torch.equal(j, full[:, full.shape[1] - nj:]) for j in js)
+        uj = unpack_joints(js[0])
+        ok = ok and uj['smpl_joints2d'].shape == (world * rec0.shape[0], 49, 2) and 'smpl_vertices' not in uj
         q.put((rank, full.numpy() if ok else None))
     finally:
         dist.destroy_process_group()

@@ -68,6 +68,46 @@ def test_tolerant_unpickler_runs_nothing_outside_allow_list(tmp_path):
     assert not (tmp_path / 'pwned').exists() and type(out['x']).__name__ == '_AnyStub'
 
 
+def test_tolerant_unpickler_does_not_trust_whole_packages(tmp_path):
+    """Callables that live INSIDE torch / numpy / builtins but are not tensor reconstructors must be stubbed too
+    (advisor, round 2: torch.utils.collect_env.run is a shell, numpy.load can unpickle, builtins.map / type ...)."""
+    from spec_amd.checkpoint import _TolerantUnpickler, _ALLOWED
+    import io
+    import builtins
+    import torch.utils.collect_env as ce
+
+    marker = tmp_path / 'pwned2'
+
+    class ViaTorch:
+        def __reduce__(self):
+            return (ce.run, ('echo pwned > ' + str(marker),))
+
+    class ViaNumpy:
+        def __reduce__(self):
+            return (np.load, (str(tmp_path / 'x.npy'),))
+
+    class ViaBuiltins:
+        def __reduce__(self):
+            return (builtins.vars, ())
+
+    out = _TolerantUnpickler(io.BytesIO(pickle.dumps({'a': ViaTorch(), 'b': ViaNumpy(), 'c': ViaBuiltins()}))).load()
+    assert not marker.exists()
+    assert all(type(v).__name__ == '_AnyStub' for v in out.values())
+    for bad in (('torch.utils.collect_env', 'run'), ('numpy', 'load'), ('torch', 'load'), ('torch.hub', 'load'),
+                ('builtins', 'eval'), ('builtins', 'type'), ('builtins', 'map'), ('builtins', 'globals'),
+                ('torch.storage', '_load_from_bytes')):
+        assert bad not in _ALLOWED
+    # and real tensors / arrays / ordered dicts still come through
+    from collections import OrderedDict
+    good = {'w': torch.arange(6.).reshape(2, 3), 'n': np.arange(4, dtype=np.float32), 'o': OrderedDict(a=1)}
+    buf = io.BytesIO()
+    torch.save(good, buf)
+    buf.seek(0)
+    from spec_amd.checkpoint import _tolerant_pickle
+    back = torch.load(buf, weights_only=False, pickle_module=_tolerant_pickle)
+    assert torch.equal(back['w'], good['w']) and np.array_equal(back['n'], good['n']) and back['o'] == good['o']
+
+
 def test_strict_load_keeps_reference_failure_mode():
     from spec_amd.checkpoint import load_pretrained_model
     from spec_amd.modules import CameraRegressorNetwork

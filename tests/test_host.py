@@ -188,3 +188,30 @@ def test_bench_stage_table_formulae():
     igemm_ms = 0.25 + 0.25 + 0.35 + 0.02
     assert abs(roof['achieved'] - (26.3e9 * 3 + 0.18e9) / (igemm_ms * 1e-3) / 1e12) < 0.01
     assert roof['second_kernel']['executed_mfma_TFLOPs'] == round(59.2e9 / 0.25e-3 / 1e12 * 16 / 36, 2)
+
+
+def test_signature_sees_replaced_tensors():
+    """Advisor (round 2): a new nn.Parameter, a replaced submodule or a child's load_state_dict(assign=True) must change
+    the module signature, or the forward would keep running on the stale device copy of the weights."""
+    import copy
+    import torch.nn as nn
+    from spec_amd.modules import CameraRegressorNetwork
+    m = CameraRegressorNetwork()
+    s0 = m._signature()
+    assert m._signature() == s0                                   # stable when nothing changed
+    name, child = next((n, c) for n, c in m.named_modules() if n and isinstance(getattr(c, 'weight', None), nn.Parameter))
+    child.weight = nn.Parameter(child.weight.detach().clone())    # new Parameter object on a CHILD module
+    s1 = m._signature()
+    assert s1 != s0
+    top = next(n for n, _ in m.named_children())
+    setattr(m, top, copy.deepcopy(getattr(m, top)))               # replaced submodule
+    s2 = m._signature()
+    assert s2 != s1
+    name, child = next((n, c) for n, c in m.named_modules() if n and isinstance(getattr(c, 'weight', None), nn.Parameter))
+    sd = {k: v.clone() for k, v in child.state_dict().items()}
+    child.load_state_dict(sd, assign=True)                        # child-level assign: tensors swapped under the parent
+    s3 = m._signature()
+    assert s3 != s2
+    with torch.no_grad():
+        child.weight.add_(1.0)                                    # in-place edit bumps _version
+    assert m._signature() != s3
