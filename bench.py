@@ -277,8 +277,74 @@ def cpu_baseline(cs, hs, budget_s=22.0, batch=16):
             'single_thread_images_per_s': round(single, 3)}
 
 
+def _cpu_worker(idx, nthreads, t_go, seconds, batch=16):
+    """One process of the whole-host CPU baseline: pins itself to its own block of logical CPUs, builds the oracle, waits
+    for the common start time and counts the batches it completes inside the window.  Prints one JSON line."""
+    try:
+        os.sched_setaffinity(0, set(range(idx * nthreads, (idx + 1) * nthreads)))
+    except Exception:
+        pass
+    torch.set_num_threads(nthreads)
+    torch.set_grad_enabled(False)
+    from spec_amd import synth
+    from oracle import heads
+    from oracle.models import CamCalibOracle, HMROracle, load_numpy_state, full_pipeline
+    heads.set_assets(smpl_model=synth.smpl_model(1003))
+    occ = load_numpy_state(CamCalibOracle().eval(), synth.camcalib_state(1001))
+    ohm = load_numpy_state(HMROracle(use_cam=True, use_cam_feats=True).eval(), synth.hmr_state(1002, True))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    x = t(synth.images(3 + idx, batch))
+    sc, ce, iw, ih = [t(a) for a in synth.bbox_inputs(3, batch, jitter=False)]
+    full_pipeline(occ, ohm, x[:2], sc[:2], ce[:2], iw[:2], ih[:2])
+    ready = time.time()
+    while time.time() < t_go:
+        time.sleep(0.01)
+    n, t0 = 0.0, time.time()
+    last = t0
+    while True:
+        full_pipeline(occ, ohm, x, sc, ce, iw, ih)
+        now = time.time()
+        if now - t0 > seconds:
+            # the batch that straddles the end of the window counts for the part of it that lies inside
+            n += batch * max(0.0, (t0 + seconds - last) / max(now - last, 1e-9))
+            break
+        n += batch
+        last = now
+    print(json.dumps({'idx': idx, 'images': n, 'late_s': round(max(0.0, ready - t_go), 2)}), flush=True)
+
+
+def cpu_baseline_whole_host(physical, threads_per_proc=16, seconds=10.0, startup_s=45.0):
+    """P = physical_cores / 16 oracle processes x 16 threads, each pinned to its own cores, all timed over the same
+    window: the reference's CPU forward on ALL of the box's host cores (one process cannot use them: the thread sweep
+    peaks at 16)."""
+    import subprocess
+    P = max(1, physical // threads_per_proc)
+    t_go = time.time() + startup_s
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads_per_proc), MKL_NUM_THREADS=str(threads_per_proc),
+               HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', str(i), str(threads_per_proc),
+                               repr(t_go), repr(seconds)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True)
+             for i in range(P)]
+    total, late, done = 0.0, 0.0, 0
+    for p_ in procs:
+        try:
+            out, _ = p_.communicate(timeout=startup_s + seconds + 60)
+            r = json.loads(out.strip().splitlines()[-1])
+            total += r['images']; late = max(late, r['late_s']); done += 1
+        except Exception:
+            p_.kill()
+    if done == 0:
+        return None
+    return {'value': round(total / seconds, 2), 'unit': 'images/s', 'processes': done, 'threads_per_process': threads_per_proc,
+            'cores': done * threads_per_proc, 'window_s': seconds, 'pinned': f'process i -> logical CPUs [{threads_per_proc} i, {threads_per_proc} i + {threads_per_proc})',
+            'late_start_s': late}
+
+
 # ------------------------------------------------------------------------------------------------
 def main():
+    if len(sys.argv) >= 6 and sys.argv[1] == '--cpu-worker':
+        _cpu_worker(int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), float(sys.argv[5]))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
@@ -566,6 +632,20 @@ def main():
             cpu = cpu_baseline(cs, hs)
         except Exception as e:  # the baseline must never sink the bench line
             log('[bench] cpu baseline failed:', repr(e))
+        if cpu is not None:
+            try:
+                whole = cpu_baseline_whole_host(cpu['host']['physical_cores'])
+                if whole is not None:
+                    # headline = the whole host; the single-process figures stay beside it
+                    cpu['single_process'] = {'value': cpu['value'], 'cores': cpu['cores'], 'sample': cpu['sample']}
+                    cpu['whole_host'] = whole
+                    cpu['value'], cpu['cores'] = whole['value'], whole['cores']
+                    cpu['sample'] = (f"{whole['processes']} processes x {whole['threads_per_process']} threads, each pinned to its own "
+                                     f"cores, batches of 16 synthetic 224x224 images through the PyTorch-CPU fp32 oracle (full "
+                                     f"CamCalib+SPEC+SMPL forward) for {whole['window_s']:.0f} s; single process: "
+                                     + cpu['single_process']['sample'])
+            except Exception as e:
+                log('[bench] whole-host cpu baseline failed:', repr(e))
 
     if rank == 0:
         line = {

@@ -9,6 +9,7 @@ Used ONLY by ``tests/golden/make_fixtures.py`` in the build container; ``/root/r
 does not exist on the GPU box and nothing at test/bench time imports this module.
 """
 import importlib
+import importlib.util
 import sys
 import types
 
@@ -20,14 +21,39 @@ def _mod(name, **attrs):
     return m
 
 
-def install(reference_root='/root/reference'):
+def have(pkg):
+    """True when the REAL package is importable (and is not one of this shim's stub modules)."""
+    m = sys.modules.get(pkg)
+    if m is not None:
+        return getattr(m, '__file__', None) is not None
+    try:
+        return importlib.util.find_spec(pkg) is not None
+    except (ImportError, ValueError):
+        return False
+
+
+BOUND = {}   # filled by install(): leaf package -> 'upstream' | 'shim'
+
+
+def install(reference_root='/root/reference', upstream=False):
+    """``upstream=True``: wherever the reference's real leaf packages import (``pare`` needs ``smplx`` and ``loguru``
+    too), they are LEFT ALONE and the reference's modules bind to them; only what is missing is stubbed.  The
+    fixtures regenerated that way pin the upstream leaf arithmetic itself (``tests/golden/make_fixtures.py --upstream``)."""
     from . import geometry, heads, resnet
+    BOUND.clear()
+    real_pare = bool(upstream) and have('pare') and have('smplx')
+    BOUND['pare'] = 'upstream' if real_pare else 'shim'
+    BOUND['smplx'] = 'upstream' if real_pare else 'shim'
 
     class _Logger:
         def __getattr__(self, _name):
             return lambda *a, **k: None
 
-    _mod('loguru', logger=_Logger())
+    if upstream and have('loguru'):
+        BOUND['loguru'] = 'upstream'
+    else:
+        BOUND['loguru'] = 'shim'
+        _mod('loguru', logger=_Logger())
     joblib_stub = sys.modules.get('joblib')
     if joblib_stub is None:
         try:
@@ -35,6 +61,10 @@ def install(reference_root='/root/reference'):
         except Exception:
             _mod('joblib', load=lambda *a, **k: None, dump=lambda *a, **k: None)
 
+    if real_pare:
+        if reference_root not in sys.path:
+            sys.path.insert(0, reference_root)
+        return BOUND
     pare = _mod('pare')
     models = _mod('pare.models', SMPL=None)
     backbone = _mod('pare.models.backbone', resnet50=resnet.resnet50)
@@ -66,11 +96,12 @@ def install(reference_root='/root/reference'):
     utils.train_utils, utils.geometry = train_utils, geom
     if reference_root not in sys.path:
         sys.path.insert(0, reference_root)
+    return BOUND
 
 
-def import_reference(reference_root='/root/reference'):
+def import_reference(reference_root='/root/reference', upstream=False):
     """Returns the reference's modules (hmr, camcalib.model, cam_utils, cam_params, constants)."""
-    install(reference_root)
+    install(reference_root, upstream=upstream)
     # the build tree also has `spec` / `camcalib` import-path packages; make sure the
     # reference's win for this process.
     for name in [n for n in sys.modules if n == 'spec' or n.startswith('spec.')
@@ -84,7 +115,8 @@ def import_reference(reference_root='/root/reference'):
     mods['cam_params'] = importlib.import_module('spec.utils.cam_params')
     mods['constants'] = importlib.import_module('spec.constants')
     # spec/utils/compute_error.py does `from ..config import ...` (yacs-based, not importable here)
-    _mod('spec.config', DATASET_FILES=[{}, {}], SMPL_MODEL_DIR='')
+    if not (upstream and have('yacs')):
+        _mod('spec.config', DATASET_FILES=[{}, {}], SMPL_MODEL_DIR='')
     mods['compute_error'] = importlib.import_module('spec.utils.compute_error')
     for m in mods.values():
         assert m.__file__.startswith(reference_root), m.__file__

@@ -175,6 +175,12 @@ def run_evaluation(hparams: dict, data_root: str = '.', ckpt: Optional[str] = No
         if ref:
             log(f'{name}: W-MPJPE {ours[0]:.1f} (README {ref[0]})  PA-MPJPE {ours[1]:.1f} (README {ref[1]})  '
                 f'W-PVE {ours[2]:.1f} (README {ref[2]})')
+            # the number BASELINE.json asks for: |delta W-MPJPE| vs the reference's published table (README.md:155-159);
+            # meaningful only on the real assets - a stand-in tree holds synthetic weights
+            d = [ours[i] - ref[i] for i in range(3)]
+            log(f'{name}: delta vs README  W-MPJPE {d[0]:+.2f} mm  PA-MPJPE {d[1]:+.2f} mm  W-PVE {d[2]:+.2f} mm  '
+                f'(target |delta W-MPJPE| <= 0.1 mm: {"met" if abs(d[0]) <= 0.1 else "NOT met"})')
+            res['readme_delta_mm'] = {'wmpjpe': d[0], 'pampjpe': d[1], 'wpve': d[2]}
         results[name] = res
     return results
 

@@ -10,9 +10,29 @@ the vectors are produced here by importing the reference's OWN in-tree modules
 over the name shim in ``oracle/refshim.py`` (the un-vendored ``pare``/``smplx`` leaf modules
 are bound to the oracle's restatements) and running them on seeded synthetic tensors
 (``spec_amd.synth``).  Only seeds, small inputs and the expected outputs are stored; the
-reference's source never enters the repo.  Usage:  python tests/golden/make_fixtures.py
+reference's source never enters the repo.  Usage:
+
+    python tests/golden/make_fixtures.py                 # (re)write tests/golden/*.npz over the shim
+    python tests/golden/make_fixtures.py --selfcheck     # regenerate into a temp dir, diff against the committed
+                                                         # files (must be bit-identical; what CI runs)
+    python tests/golden/make_fixtures.py --upstream      # the ONE-COMMAND UPSTREAM PIN: wherever the reference's real leaf
+                                                         # packages import (pip install smplx==0.1.28 loguru yacs + the
+                                                         # pare checkout of requirements.txt:28; opencv-python for the
+                                                         # crops), bind THEM instead of oracle/refshim.py, regenerate every
+                                                         # fixture into a temp dir and print the max deviation per array
+                                                         # against the committed ones; add --write to replace them
+    python tests/golden/make_fixtures.py --upstream --data-root /path/with/data    # real SMPL assets instead of the
+                                                         # synthetic stand-in tree (outputs then differ by construction:
+                                                         # only shapes / keys are compared)
+
+With ``--upstream`` the real ``pare`` heads load the body model from ``data/body_models/smpl`` relative to the working
+directory; unless ``--data-root`` is given the script writes a stand-in tree there first (the SAME synthetic SMPL model
+the committed fixtures were made with, in the official pickle format: ``spec_amd.evaluation.write_standin_data_tree``),
+so the regenerated arrays are directly comparable: any deviation is upstream leaf arithmetic vs this build's restatement.
 """
+import argparse
 import os
+import shutil
 import sys
 import tempfile
 
@@ -21,7 +41,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-OUT = os.path.dirname(os.path.abspath(__file__))
+OUT_DIR = os.path.dirname(os.path.abspath(__file__))
 
 from spec_amd import synth  # noqa: E402
 from oracle import refshim, heads  # noqa: E402
@@ -37,10 +57,11 @@ def t(a):
     return torch.from_numpy(np.ascontiguousarray(a))
 
 
-def main():
+def generate(OUT, upstream=False):
     smpl_model = synth.smpl_model(SEED_SMPL)
     heads.set_assets(smpl_model=smpl_model)
-    ref = refshim.import_reference()
+    ref = refshim.import_reference(upstream=upstream)
+    print('leaf packages bound:', dict(refshim.BOUND))
     RC = ref['constants']
 
     # ---- (1) index tables and constants, from the reference's spec/constants.py ----------
@@ -160,8 +181,117 @@ def main():
              mpjpe=mpjpe, pampjpe=pampjpe, v2v=v2v, mpjpe24=mpjpe24, pampjpe24=pampjpe24)
 
     sz = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith('.npz'))
-    print('fixtures written, total bytes', sz)
+    print('fixtures written to', OUT, 'total bytes', sz)
+    return sorted(f for f in os.listdir(OUT) if f.endswith('.npz'))
+
+
+def compare(new_dir, old_dir, files, values=True):
+    """Per array: max |new - committed| and that over max |committed|.  Returns (worst relative deviation, problems)."""
+    worst, problems = 0.0, []
+    print(f'{"file":24s} {"array":22s} {"shape":18s} {"max abs dev":>12s} {"max rel dev":>12s}')
+    for f in files:
+        a, b = np.load(os.path.join(new_dir, f), allow_pickle=False), np.load(os.path.join(old_dir, f), allow_pickle=False)
+        if sorted(a.files) != sorted(b.files):
+            problems.append(f'{f}: array names differ: {sorted(set(a.files) ^ set(b.files))}')
+        for k in b.files:
+            if k not in a.files:
+                continue
+            x, y = a[k], b[k]
+            if x.shape != y.shape or x.dtype.kind != y.dtype.kind:
+                problems.append(f'{f}:{k}: shape / kind {x.shape} {x.dtype} vs committed {y.shape} {y.dtype}')
+                continue
+            if y.dtype.kind in 'US':
+                if not np.array_equal(x, y):
+                    problems.append(f'{f}:{k}: strings differ')
+                continue
+            if not values:
+                continue
+            x64, y64 = x.astype(np.float64), y.astype(np.float64)
+            dev = float(np.abs(x64 - y64).max()) if x.size else 0.0
+            rel = dev / max(float(np.abs(y64).max()), 1e-30) if x.size else 0.0
+            if y.dtype.kind in 'iub' and dev != 0:
+                problems.append(f'{f}:{k}: integer / index array differs')
+            worst = max(worst, rel)
+            if dev != 0 or x.size > 1:
+                print(f'{f:24s} {k:22s} {str(x.shape):18s} {dev:12.3e} {rel:12.3e}')
+    return worst, problems
+
+
+def check_opencv():
+    """When OpenCV imports: the two restated OpenCV leaves of the crop rows against the REAL binary on
+    seeded frames - cv2.warpAffine (INTER_LINEAR, fixed-point path, spec/tester.py:116-128 via pare's
+    get_single_image_crop_demo) and cv2.resize on float64 (spec/dataset/cam_dataset.py:253-287 via pare's crop)."""
+    try:
+        import cv2
+    except Exception as e:                          # noqa: BLE001
+        print(f'opencv: not importable ({type(e).__name__}) - cv2.warpAffine / cv2.resize restatements stay unpinned; '
+              'pip install opencv-python and re-run --upstream')
+        return None
+    from oracle import preprocess as P
+    rng = np.random.default_rng(99)
+    worst = 0
+    for (h, w) in ((480, 640), (1080, 1920), (333, 517)):
+        frame = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        for (cx, cy, bw, bh, sc) in ((w / 2, h / 2, 200.3, 300.7, 1.0), (20.0, 30.0, 150.0, 90.0, 1.2), (w - 5.0, h - 9.0, 400.0, 420.0, 1.0)):
+            M = np.asarray(P.gen_trans_from_patch(cx, cy, bw, bh, 224, 224, sc), dtype=np.float64)
+            ours = P.warp_affine_linear_u8(frame, M, 224, 224)
+            theirs = cv2.warpAffine(frame, M, (224, 224), flags=cv2.INTER_LINEAR, borderMode=cv2.BORDER_CONSTANT)
+            worst = max(worst, int(np.abs(ours.astype(np.int32) - theirs.astype(np.int32)).max()))
+        src = rng.random((h // 3, w // 3, 3))
+        d = np.abs(P.cv2_resize_linear_f64(src, 224, 224) - cv2.resize(src, (224, 224), interpolation=cv2.INTER_LINEAR)).max()
+        print(f'opencv {cv2.__version__}: cv2.resize float64 {src.shape[:2]} -> 224: max abs dev {d:.3e}')
+        worst = max(worst, 0 if d == 0 else 1)
+    print(f'opencv {cv2.__version__}: cv2.warpAffine u8 restatement: max grey-level deviation {worst} (0 = bit-exact)')
+    return worst
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument('--upstream', action='store_true', help='bind the real pare / smplx / loguru where they import')
+    ap.add_argument('--selfcheck', action='store_true', help='regenerate over the shim into a temp dir and diff (must be 0)')
+    ap.add_argument('--write', action='store_true', help='with --upstream / --selfcheck: replace the committed fixtures')
+    ap.add_argument('--data-root', default=None, help='directory holding the reference data/ tree (real SMPL assets)')
+    ap.add_argument('--tolerance', type=float, default=1e-4, help='relative deviation reported as a failure (--upstream)')
+    args = ap.parse_args()
+    if not (args.upstream or args.selfcheck):
+        generate(OUT_DIR)
+        return 0
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as td:
+        new_dir = os.path.join(td, 'golden')
+        os.makedirs(new_dir)
+        data_root = args.data_root
+        if args.upstream and data_root is None:
+            from spec_amd.evaluation import write_standin_data_tree
+            data_root = os.path.join(td, 'tree')
+            write_standin_data_tree(data_root, n_images=1, hmr_seed=SEED_HMR, smpl_seed=SEED_SMPL)
+        if data_root:
+            os.chdir(data_root)          # pare / smplx resolve 'data/...' against the working directory
+        try:
+            files = generate(new_dir, upstream=args.upstream)
+        finally:
+            os.chdir(cwd)
+        bound = dict(refshim.BOUND)
+        if args.upstream and 'upstream' not in bound.values():
+            print('NOTE: none of pare / smplx / loguru is importable here - every leaf is still the shim, so this run is the '
+                  'self-check.  Install them (see the module docstring) and re-run to pin the upstream leaves.')
+        worst, problems = compare(new_dir, OUT_DIR, files, values=args.data_root is None)
+        print(f'worst relative deviation over all arrays: {worst:.3e}   leaves: {bound}')
+        if args.upstream:
+            cv_dev = check_opencv()
+            if cv_dev:
+                problems.append(f'OpenCV restatement deviates from the installed binary (max {cv_dev})')
+        for p_ in problems:
+            print('PROBLEM', p_)
+        if args.write:
+            for f in files:
+                shutil.copy(os.path.join(new_dir, f), os.path.join(OUT_DIR, f))
+            print('committed fixtures replaced')
+        exact = args.selfcheck or 'upstream' not in bound.values()
+        if problems or (exact and worst != 0.0) or (not exact and worst > args.tolerance):
+            return 1
+    return 0
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())
