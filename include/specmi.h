@@ -237,6 +237,15 @@ int specmi_crop_normalize(specmi_handle* h, const uint8_t* frame_rgb_hwc, int H,
                           const float* bboxes, int n, float scale, int crop_size, float* out_nchw,
                           uint8_t* raw_hwc, float* bbox_scale, float* bbox_center, void* stream);
 
+/* The same crops for the detections of MANY frames in one launch - the loop over images of spec/tester.py:109-128 (one
+ * frame, its detections, one crop each) flattened: `frames` is a slab of nframes equal-sized uint8 RGB HWC frames in device
+ * memory (frame f at frames + f*H*W*3), crop d is cut from frame frame_index[d] (device, (n) int32, values in [0, nframes))
+ * with bbox d.  Same arithmetic, same outputs per crop as specmi_crop_normalize (bit-identical); what it removes is one
+ * launch, one host synchronisation and one small batch per frame. */
+int specmi_crop_normalize_batch(specmi_handle* h, const uint8_t* frames_rgb_hwc, int nframes, int H, int W,
+                                const int32_t* frame_index, const float* bboxes, int n, float scale, int crop_size,
+                                float* out_nchw, uint8_t* raw_hwc, float* bbox_scale, float* bbox_center, void* stream);
+
 /* The evaluation dataset's image path (spec/dataset/cam_dataset.py:253-287 rgb_processing with flip 0 / rot 0 / pn 1, :367-377):
  * pare `crop(img, center, scale, [res, res])` = copy of the integer box [ul, br) (zero outside the frame) scaled to res x res
  * with cv2.resize (bilinear, half-pixel centres, replicated border), clip to [0, 255], float32 / 255, ImageNet Normalize.

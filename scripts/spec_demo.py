@@ -106,6 +106,8 @@ if __name__ == '__main__':
     parser.add_argument('--yolo_img_size', type=int, default=416)
     parser.add_argument('--tracker_batch_size', type=int, default=12)
     parser.add_argument('--batch_size', type=int, default=16, help='batch size of SPEC')
+    parser.add_argument('--frame_batch', type=int, default=256, help='crops per SPEC forward, collected across frames (1 = one forward per frame, the reference structure; results are bit-identical)')
+    parser.add_argument('--decode_threads', type=int, default=4, help='host threads decoding frames ahead of the GPU')
     parser.add_argument('--display', action='store_true')
     parser.add_argument('--smooth', action='store_true')
     parser.add_argument('--no_render', action='store_true', help='(rendering is never done by this build)')

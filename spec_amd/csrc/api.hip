@@ -1142,6 +1142,19 @@ int specmi_crop_normalize(specmi_handle* h, const uint8_t* frame, int H, int W, 
     return SPECMI_OK;
 }
 
+int specmi_crop_normalize_batch(specmi_handle* h, const uint8_t* frames, int nframes, int H, int W, const int32_t* frame_index,
+                                const float* bboxes, int n, float scale, int crop_size, float* out, uint8_t* raw,
+                                float* bbox_scale, float* bbox_center, void* stream) {
+    ENTER(h);
+    if (!frames || !frame_index || !bboxes || !out || nframes <= 0 || H <= 0 || W <= 0 || n <= 0 || crop_size <= 0 || !(scale > 0.f))
+        return fail(h, SPECMI_ERR_ARG, "bad argument");
+    LaunchCtx ctx{(hipStream_t)stream, &h->prof, "preprocess.crop_batch"};
+    LAUNCHCHK(h, launch_crop_normalize(frames, H, W, bboxes, n, scale, crop_size, out, raw, bbox_scale, bbox_center, ctx,
+                                       frame_index, nframes),
+              "crop_normalize_batch");
+    return SPECMI_OK;
+}
+
 int specmi_crop_resize_normalize(specmi_handle* h, const uint8_t* frame, int H, int W, const int32_t* boxes, int n,
                                  int crop_size, float* out, void* stream) {
     ENTER(h);

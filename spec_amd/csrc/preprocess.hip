@@ -93,10 +93,12 @@ __global__ void __launch_bounds__(256) crop_normalize_kernel(const unsigned char
                                                               const float* __restrict__ bboxes, float scale, int S,
                                                               float* __restrict__ out, unsigned char* __restrict__ raw,
                                                               float* __restrict__ bbox_scale,
-                                                              float* __restrict__ bbox_center) {
+                                                              float* __restrict__ bbox_center,
+                                                              const int* __restrict__ frame_of, size_t frame_stride) {
     __shared__ float lut[3][256];
     __shared__ int2 tabx[TABLE ? kTabX : 1], taby[TABLE ? kTabY : 1];
     const int d = blockIdx.y, t = threadIdx.x;
+    if (frame_of) frame += (size_t)frame_of[d] * frame_stride;   // batched: crop d is cut from frame frame_of[d] of a slab of equal-sized frames
     {
         const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
 #pragma unroll
@@ -160,21 +162,23 @@ __global__ void __launch_bounds__(256) crop_normalize_kernel(const unsigned char
 
 template <bool WIDE, bool TABLE>
 static void crop_normalize_go(dim3 grid, hipStream_t st, const unsigned char* frame, int H, int W, const float* bboxes, float scale,
-                              int S, float* out, unsigned char* raw, float* bbox_scale, float* bbox_center) {
+                              int S, float* out, unsigned char* raw, float* bbox_scale, float* bbox_center, const int* frame_of,
+                              size_t frame_stride) {
     hipLaunchKernelGGL((crop_normalize_kernel<WIDE, TABLE>), grid, dim3(256), 0, st, frame, H, W, bboxes, scale, S, out, raw, bbox_scale,
-                       bbox_center);
+                       bbox_center, frame_of, frame_stride);
 }
 
 int launch_crop_normalize(const unsigned char* frame, int H, int W, const float* bboxes, int n, float scale, int S,
-                          float* out, unsigned char* raw, float* bbox_scale, float* bbox_center, const LaunchCtx& ctx) {
-    // algorithmic HBM bytes: the frame once + every output once (the 4 taps x 3 channels of a pixel come through L2)
-    ProfScope ps(ctx, "crop_normalize", 0.0, (double)H * W * 3 + (double)n * S * S * (12.0 + (raw ? 3.0 : 0.0)));
+                          float* out, unsigned char* raw, float* bbox_scale, float* bbox_center, const LaunchCtx& ctx,
+                          const int* frame_of, int nframes) {
+    // algorithmic HBM bytes: every frame once + every output once (the 4 taps x 3 channels of a pixel come through L2)
+    ProfScope ps(ctx, "crop_normalize", 0.0, (double)H * W * 3 * (frame_of ? nframes : 1) + (double)n * S * S * (12.0 + (raw ? 3.0 : 0.0)));
     if (H >= (1 << 24) || W >= (1 << 24) || (double)H * W * 3 >= 4294967296.0) return (int)hipErrorInvalidValue;   // 32-bit offsets
     const dim3 grid((S * S + 256 * kPX * kNB - 1) / (256 * kPX * kNB), n);
     const bool wide = W >= 2 && (size_t)H * W * 3 >= 8, table = S <= kTabX;
     auto go = wide ? (table ? crop_normalize_go<true, true> : crop_normalize_go<true, false>)
                    : (table ? crop_normalize_go<false, true> : crop_normalize_go<false, false>);
-    go(grid, ctx.stream, frame, H, W, bboxes, scale, S, out, raw, bbox_scale, bbox_center);
+    go(grid, ctx.stream, frame, H, W, bboxes, scale, S, out, raw, bbox_scale, bbox_center, frame_of, (size_t)H * W * 3);
     return (int)hipGetLastError();
 }
 

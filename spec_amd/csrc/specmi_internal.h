@@ -206,8 +206,10 @@ int launch_rotate_points(const float* R, const float* x, int B, int N, float* ou
 // ----------------------------------------------------------------------------------------
 // crop + normalise  (preprocess.hip)
 // ----------------------------------------------------------------------------------------
+// frame_of != nullptr: `frame` is a slab of nframes equal-sized frames and crop d is cut from frame frame_of[d] (device, (n) int32)
 int launch_crop_normalize(const unsigned char* frame, int H, int W, const float* bboxes, int n, float scale, int S,
-                          float* out, unsigned char* raw, float* bbox_scale, float* bbox_center, const LaunchCtx& ctx);
+                          float* out, unsigned char* raw, float* bbox_scale, float* bbox_center, const LaunchCtx& ctx,
+                          const int* frame_of = nullptr, int nframes = 1);
 
 // dataset crop: integer boxes (n,4) [ulx, uly, brx, bry] -> cv2.resize-style bilinear to S x S + ToTensor + Normalize
 int launch_crop_resize_normalize(const unsigned char* frame, int H, int W, const int* boxes, int n, int S, float* out,

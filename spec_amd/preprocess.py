@@ -13,9 +13,11 @@ from .engine import _dev_f32, _ptr
 
 
 @torch.no_grad()
-def crop_detections(frame_rgb_u8, dets, scale: float = 1.0, crop_size: int = 224, return_raw: bool = False):
+def crop_detections(frame_rgb_u8, dets, scale: float = 1.0, crop_size: int = 224, return_raw: bool = False, out=None):
     """frame (H,W,3) uint8 device tensor, dets (n,4) [cx, cy, w, h] ->
-    dict(inp_images (n,3,S,S) fp32, bbox_scale (n,), bbox_center (n,2)[, raw (n,S,S,3) uint8])."""
+    dict(inp_images (n,3,S,S) fp32, bbox_scale (n,), bbox_center (n,2)[, raw (n,S,S,3) uint8]).
+    ``out``: optional dict of preallocated contiguous tensors (``inp_images``, ``bbox_scale``, ``bbox_center`` - e.g. slices
+    of a larger batch buffer) to write into instead of allocating."""
     if not isinstance(frame_rgb_u8, torch.Tensor) or frame_rgb_u8.device.type != 'cuda':
         raise RuntimeError('crop_detections needs a device tensor (no CPU path in spec_amd)')
     if frame_rgb_u8.dtype != torch.uint8 or frame_rgb_u8.dim() != 3 or frame_rgb_u8.shape[2] != 3:
@@ -27,16 +29,54 @@ def crop_detections(frame_rgb_u8, dets, scale: float = 1.0, crop_size: int = 224
     if boxes.dim() != 2 or boxes.shape[1] != 4:
         raise ValueError('dets must be (n,4) [cx, cy, w, h]')
     n, (H, W) = boxes.shape[0], frame.shape[:2]
-    out = torch.empty(n, 3, crop_size, crop_size, device=dev, dtype=torch.float32)
+    img, sc, ce = _crop_outputs(out, n, crop_size, dev)
     raw = torch.empty(n, crop_size, crop_size, 3, device=dev, dtype=torch.uint8) if return_raw else None
-    sc = torch.empty(n, device=dev, dtype=torch.float32)
-    ce = torch.empty(n, 2, device=dev, dtype=torch.float32)
-    _lib.check(eng.h, eng.lib.specmi_crop_normalize(eng.h, _ptr(frame), H, W, _ptr(boxes), n, float(scale), crop_size,
-                                                    _ptr(out), _ptr(raw), _ptr(sc), _ptr(ce), eng._stream()))
-    res = {'inp_images': out, 'bbox_scale': sc, 'bbox_center': ce}
+    if n > 0:
+        _lib.check(eng.h, eng.lib.specmi_crop_normalize(eng.h, _ptr(frame), H, W, _ptr(boxes), n, float(scale), crop_size,
+                                                        _ptr(img), _ptr(raw), _ptr(sc), _ptr(ce), eng._stream()))
+    res = {'inp_images': img, 'bbox_scale': sc, 'bbox_center': ce}
     if return_raw:
         res['raw'] = raw
     return res
+
+
+def _crop_outputs(out, n, crop_size, dev):
+    if out is None:
+        return (torch.empty(n, 3, crop_size, crop_size, device=dev, dtype=torch.float32),
+                torch.empty(n, device=dev, dtype=torch.float32), torch.empty(n, 2, device=dev, dtype=torch.float32))
+    img, sc, ce = out['inp_images'], out['bbox_scale'], out['bbox_center']
+    for t_, shp in ((img, (n, 3, crop_size, crop_size)), (sc, (n,)), (ce, (n, 2))):
+        if tuple(t_.shape) != shp or t_.dtype != torch.float32 or not t_.is_contiguous() or t_.device != dev:
+            raise ValueError(f'out tensor must be a contiguous fp32 device tensor of shape {shp}, got {tuple(t_.shape)} {t_.dtype}')
+    return img, sc, ce
+
+
+@torch.no_grad()
+def crop_detections_batch(frames_u8, frame_index, dets, scale: float = 1.0, crop_size: int = 224, out=None):
+    """The detections of MANY equal-sized frames in one launch (``specmi_crop_normalize_batch``): ``frames_u8`` (F,H,W,3) uint8
+    device slab, ``frame_index`` (n,) int32 (which frame each detection belongs to), ``dets`` (n,4) [cx, cy, w, h] -> the same
+    dict as ``crop_detections`` for all n crops, bit-identical to cutting them frame by frame."""
+    if not isinstance(frames_u8, torch.Tensor) or frames_u8.device.type != 'cuda':
+        raise RuntimeError('crop_detections_batch needs a device tensor (no CPU path in spec_amd)')
+    if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.shape[3] != 3 or not frames_u8.is_contiguous():
+        raise ValueError('frames must be a contiguous (F,H,W,3) uint8 RGB slab')
+    eng = _engine(frames_u8.device)
+    dev = eng.device
+    boxes = _dev_f32(dets, dev)
+    if boxes.dim() != 2 or boxes.shape[1] != 4:
+        raise ValueError('dets must be (n,4) [cx, cy, w, h]')
+    n = boxes.shape[0]
+    fidx = frame_index if isinstance(frame_index, torch.Tensor) else torch.as_tensor(frame_index)
+    fidx = fidx.to(device=dev, dtype=torch.int32).contiguous()
+    if fidx.shape != (n,):
+        raise ValueError('frame_index must have one entry per detection')
+    F, H, W = frames_u8.shape[:3]
+    img, sc, ce = _crop_outputs(out, n, crop_size, dev)
+    if n > 0:
+        _lib.check(eng.h, eng.lib.specmi_crop_normalize_batch(eng.h, _ptr(frames_u8), F, H, W, _ptr(fidx), _ptr(boxes), n,
+                                                              float(scale), crop_size, _ptr(img), None, _ptr(sc), _ptr(ce),
+                                                              eng._stream()))
+    return {'inp_images': img, 'bbox_scale': sc, 'bbox_center': ce}
 
 
 def pare_crop_boxes(centers, scales, res: int = 224):

@@ -129,33 +129,67 @@ class SPECTester:
 
     @torch.no_grad()
     def run_on_image_folder(self, image_folder, detections, output_path, output_img_folder, bbox_scale=1.0):
+        """``spec/tester.py:90-163`` with the per-frame loop flattened: frames are decoded ahead on host threads, uploaded
+        from pinned memory without blocking, their detections are cropped on the device straight into ONE batch buffer,
+        and the model runs once per ``args.frame_batch`` crops (default 256) instead of once per frame.  An image's outputs
+        do not depend on the batch it travels in (every kernel of the path has a fixed summation order), so the per-frame
+        ``spec_results/<stem>.pkl`` files are bit-identical to ``frame_batch=1``, the reference's own structure."""
+        from concurrent.futures import ThreadPoolExecutor
         image_file_names = list_images(image_folder)
         res = self.model_cfg.DATASET.IMG_RES
-        n_done = 0
-        for img_idx, img_fname in enumerate(image_file_names):
-            dets = detections[img_idx]
-            if len(dets) < 1:
-                continue
-            frame = torch.from_numpy(_read_rgb(img_fname)).to(self.device)
-            orig_height, orig_width = frame.shape[:2]
-            batch_size = len(dets)
-            crops = crop_detections(frame, np.asarray(dets, np.float32), scale=1.0, crop_size=res)     # tester.py:116-128
-            img_h = torch.full((batch_size,), float(orig_height), device=self.device)
-            img_w = torch.full((batch_size,), float(orig_width), device=self.device)
-            cam_rotmat, cam_intrinsics, cam_vfov, cam_pitch, cam_roll, cam_focal_length = \
-                io_formats.read_cam_params(output_path, img_fname, (orig_height, orig_width), device=self.device)
-            output = self.model(crops['inp_images'],
-                                cam_rotmat=cam_rotmat.unsqueeze(0).repeat(batch_size, 1, 1),
-                                cam_intrinsics=cam_intrinsics.unsqueeze(0).repeat(batch_size, 1, 1),
-                                bbox_scale=crops['bbox_scale'], bbox_center=crops['bbox_center'], img_w=img_w, img_h=img_h)
-            output = {k: v.cpu().numpy() for k, v in output.items()}
-            if not getattr(self.args, 'no_save', False):
+        cap = max(1, int(getattr(self.args, 'frame_batch', 256) or 1))
+        per_frame = cap <= 1                                             # the reference's structure: one forward per frame
+        dev = self.device
+        todo = [(i, f) for i, f in enumerate(image_file_names) if len(detections[i]) >= 1]
+        if not todo:
+            return 0
+        cap = max(cap, max(len(detections[i]) for i, _ in todo))       # a frame's detections stay in one batch
+        buf = {'inp_images': torch.empty(cap, 3, res, res, device=dev), 'bbox_scale': torch.empty(cap, device=dev),
+               'bbox_center': torch.empty(cap, 2, device=dev)}
+        img_w, img_h = torch.empty(cap, device=dev), torch.empty(cap, device=dev)
+        R, K = torch.empty(cap, 3, 3, device=dev), torch.empty(cap, 3, 3, device=dev)
+        pending, k, n_done = [], 0, 0
+        save = not getattr(self.args, 'no_save', False)
+        if save:
+            os.makedirs(os.path.join(output_path, 'spec_results'), exist_ok=True)
+
+        def flush():
+            nonlocal k, pending
+            if k == 0:
+                return
+            output = self.model(buf['inp_images'][:k], cam_rotmat=R[:k], cam_intrinsics=K[:k], bbox_scale=buf['bbox_scale'][:k],
+                                bbox_center=buf['bbox_center'][:k], img_w=img_w[:k], img_h=img_h[:k])
+            output = {key: v.cpu().numpy() for key, v in output.items()}          # ONE device->host hand-over per batch
+            if save:
                 import joblib
-                os.makedirs(os.path.join(output_path, 'spec_results'), exist_ok=True)
-                save_f = os.path.join(output_path, 'spec_results',
-                                      os.path.basename(img_fname).replace(img_fname.split('.')[-1], 'pkl'))
-                joblib.dump(output, save_f)
-            if not getattr(self.args, 'no_render', True) and n_done == 0:
-                _log('rendering (pyrender / OpenGL, spec/tester.py:165-200) is outside the hot path: skipped')
-            n_done += 1
+                for img_fname, k0, n in pending:
+                    save_f = os.path.join(output_path, 'spec_results',
+                                          os.path.basename(img_fname).replace(img_fname.split('.')[-1], 'pkl'))
+                    joblib.dump({key: v[k0:k0 + n].copy() for key, v in output.items()}, save_f)
+            k, pending = 0, []
+
+        with ThreadPoolExecutor(max_workers=int(getattr(self.args, 'decode_threads', 4) or 1)) as ex:
+            for (img_idx, img_fname), rgb in zip(todo, ex.map(_read_rgb, [f for _, f in todo])):   # decoded ahead, in order
+                dets = np.asarray(detections[img_idx], np.float32).reshape(-1, 4)
+                n = len(dets)
+                if k + n > cap:
+                    flush()
+                frame = torch.from_numpy(rgb).pin_memory().to(dev, non_blocking=True)
+                orig_height, orig_width = frame.shape[:2]
+                crop_detections(frame, dets, scale=1.0, crop_size=res,                              # tester.py:116-128
+                                out={key: v[k:k + n] for key, v in buf.items()})
+                img_h[k:k + n] = float(orig_height)
+                img_w[k:k + n] = float(orig_width)
+                cam_rotmat, cam_intrinsics, *_ = io_formats.read_cam_params(output_path, img_fname, (orig_height, orig_width),
+                                                                            device=dev)
+                R[k:k + n] = cam_rotmat
+                K[k:k + n] = cam_intrinsics
+                pending.append((img_fname, k, n))
+                k += n
+                if per_frame:
+                    flush()
+                if not getattr(self.args, 'no_render', True) and n_done == 0:
+                    _log('rendering (pyrender / OpenGL, spec/tester.py:165-200) is outside the hot path: skipped')
+                n_done += 1
+            flush()
         return n_done
