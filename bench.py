@@ -66,7 +66,11 @@ def self_launch(n: int) -> int:
 # ------------------------------------------------------------------------------------------------
 # models / inputs
 # ------------------------------------------------------------------------------------------------
-def build_models(device):
+ERR_KEYS = ('smpl_vertices', 'smpl_joints3d', 'smpl_joints2d', 'pred_cam_t', 'pred_pose', 'pred_shape', 'pred_cam',
+            'cam_vfov', 'cam_pitch', 'cam_roll')
+
+
+def build_models(device, conv_precision=0):
     from spec_amd import synth, assets
     from spec_amd.modules import HMR, CameraRegressorNetwork
     t0 = time.time()
@@ -77,6 +81,7 @@ def build_models(device):
     cc.load_state_dict({k: t(v) for k, v in cs.items()})
     hm = HMR(use_cam=True, use_cam_feats=True)
     hm.load_state_dict({k: t(v) for k, v in hs.items()}, strict=False)
+    cc.conv_precision = hm.conv_precision = int(conv_precision)
     cc.to(device).eval().commit(device, freeze=True)
     hm.to(device).eval().commit(device, freeze=True)
     log(f'[bench] models built + packed in {time.time() - t0:.1f}s')
@@ -373,6 +378,7 @@ def main():
     ap.add_argument('--no-sustained', action='store_true', help='skip the >= 5 s sustained region')
     ap.add_argument('--sustained-seconds', type=float, default=5.0)
     ap.add_argument('--no-small-batch', action='store_true', help='skip the batch-1 / batch-8 latency lines')
+    ap.add_argument('--no-split-bf16', action='store_true', help='skip the labelled secondary line (1x1 convs as bf16 piece products)')
     ap.add_argument('--no-e2e', action='store_true', help='skip the real-input line (1080p frames from pinned host memory)')
     ap.add_argument('--no-c2', action='store_true', help='skip the config-2 line (CamCalib trunk only, batch 64)')
     ap.add_argument('--no-overlap', action='store_true', help='run CamCalib and SPEC back to back on one stream')
@@ -700,6 +706,47 @@ def main():
         except Exception as e:
             log('[bench] e2e_frames measurement failed:', repr(e))
 
+    # ---- labelled secondary line: the plain 1x1 convolutions as bf16 piece products on the bf16 matrix cores ----------
+    # NOT `value` (which is exact fp32 MFMA arithmetic): a different algorithm for the same contractions, reported with its
+    # deviation from the fp32 path on the same inputs (tests/test_gpu_bf16split.py holds it to the 1e-4 fixtures)
+    split = None
+    if rank == 0 and not use_dist and not args.no_split_bf16:
+        split = []
+        try:
+            ref_out = {k: v.clone() for k, v in pipe(x, scale, center, img_w, img_h).items() if k in ERR_KEYS}
+            for terms in (6, 3):
+                cc2, hm2, _, _ = build_models(device, conv_precision=terms)
+                pipe2 = SpecPipeline(cc2, hm2, overlap=not args.no_overlap)
+                out2 = pipe2(x, scale, center, img_w, img_h)
+                errs = {k: float((out2[k].double() - ref_out[k].double()).abs().max() / ref_out[k].double().abs().max())
+                        for k in ERR_KEYS}
+                run2, mode2 = pipe2, 'eager launches'
+                if not args.no_graph:
+                    try:
+                        from spec_amd.pipeline import GraphedPipeline
+                        run2, mode2 = GraphedPipeline(pipe2, x, scale, center, img_w, img_h), 'hipGraph replay'
+                    except Exception as e:
+                        log('[bench] split-bf16 graph capture failed:', repr(e))
+                for _ in range(args.warmup):
+                    run2(x, scale, center, img_w, img_h)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    run2(x, scale, center, img_w, img_h)
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t1
+                split.append({'terms': terms, 'images_per_s': round(B * args.steps / el, 1), 'ms_per_step': round(el / args.steps * 1e3, 3),
+                              'speedup_vs_value': round(B * args.steps / el / value, 3),
+                              'max_rel_err_vs_fp32_path': {k: float(f'{v:.3e}') for k, v in errs.items()},
+                              'worst_rel_err_vs_fp32_path': float(f'{max(errs.values()):.3e}'),
+                              'fixtures_within_1e-4': 'tests/test_gpu_bf16split.py (3 HMR fixtures + CamCalib fixture, both term counts)',
+                              'layers': '28 plain 1x1 / stride-1 convolutions per ResNet-50 trunk (conv1 x16, unfused conv3 x12); 3x3, '
+                                        'strided, downsample-fused and FC layers stay on the exact fp32 kernels',
+                              'launch': mode2})
+                del cc2, hm2, pipe2, run2, out2
+        except Exception as e:
+            log('[bench] split-bf16 line failed:', repr(e))
+
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         try:
@@ -745,7 +792,7 @@ def main():
                        'streams': 1 if args.no_overlap else 2, 'launch': launch_mode,
                        'parallelism': (f'images sharded over {n_gpus} GPUs (one process per GPU), 1 asynchronous RCCL '
                                        f'all-gather of the packed records per step') if n_gpus > 1 else 'single GPU'},
-            'roofline': roof, 'cpu_baseline': cpu, 'sustained': sustained, 'c2': c2, 'small_batch': small, 'pcie': pcie, 'e2e_frames': e2e, 'comm': comm,
+            'roofline': roof, 'cpu_baseline': cpu, 'sustained': sustained, 'c2': c2, 'small_batch': small, 'pcie': pcie, 'e2e_frames': e2e, 'split_bf16': split, 'comm': comm,
             'stages': stages,
         }
         print(json.dumps(line), flush=True)

@@ -9,9 +9,9 @@ OUT=$R/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-overlap --no-graph --no-sustained --no-c2 --no-e2e --no-small-batch"
+BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-overlap --no-graph --no-sustained --no-c2 --no-e2e --no-small-batch --no-split-bf16"
 if [ "$WHAT" = "stats" ] || [ "$WHAT" = "all" ]; then
-  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile --no-overlap --no-graph --no-sustained --no-c2 --no-e2e --no-small-batch > $OUT/rocprof_$TAG.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile --no-overlap --no-graph --no-sustained --no-c2 --no-e2e --no-small-batch --no-split-bf16 > $OUT/rocprof_$TAG.log 2>&1
   for db in $(find $OUT/prof_$TAG -name "*.db"); do python $R/scripts/rocprof_summary.py stats $db > $OUT/${TAG}_rocprof_kernel_stats.txt; done
   rm -rf $OUT/prof_$TAG
   head -14 $OUT/${TAG}_rocprof_kernel_stats.txt

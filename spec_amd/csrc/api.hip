@@ -156,6 +156,13 @@ int commit_conv(specmi_handle* h, const std::string& prefix, ConvW& c) {
         pack_wino_weights(wsrc, cout, cin, u);
         if ((rc = dev_upload(h, u.data(), u.size() * 4, (void**)&c.wino, h->param_allocs))) return rc;
     }
+    // optional split-bf16 path (conv_bf16s.hip): the weights of the plain 1x1 / stride-1 layers as three bf16 pieces
+    c.wsplit = nullptr;
+    if (opt_i(h, "conv_precision", 0) != 0 && c.k == 1 && c.stride == 1 && c.pad == 0 && cin % 16 == 0 && cout % 4 == 0) {
+        std::vector<unsigned short> pieces;
+        pack_bf16_split_weights(wsrc, cout, cin, c.Npad, pieces);
+        if ((rc = dev_upload(h, pieces.data(), pieces.size() * 2, &c.wsplit, h->param_allocs))) return rc;
+    }
     return SPECMI_OK;
 }
 
@@ -539,6 +546,13 @@ static int exec_op(specmi_handle* h, const TrunkOp& op, const float* images, flo
         a.w = bk.f_w; a.scale = bk.f_scale; a.shift = bk.f_shift; a.Npad = bk.f_Npad; a.res = nullptr;
         a.x2 = buf(op.in2_buf) + (size_t)b0 * op.in2_img;
         a.H2 = op.H2; a.W2 = op.W2; a.ldx2 = bk.ds.cin; a.Cin2 = bk.ds.cin; a.stride2 = bk.ds.stride;
+    }
+    if (c.wsplit && !op.fused) {
+        const int terms = opt_i(h, "conv_precision", 0);
+        if ((terms == 3 || terms == 6) && conv_bf16s_supported(a)) {
+            LAUNCHCHK(h, launch_conv_bf16s(a, c.wsplit, terms, ctx), op.label.c_str());
+            return SPECMI_OK;
+        }
     }
     if (c.wino && opt_i(h, "winograd", 1) && conv_wino_supported(a)) {
         a.w = c.wino;
@@ -1049,10 +1063,18 @@ int specmi_conv2d(specmi_handle* h, const float* x, int B, int H, int W, int Cin
     // option "winograd": 1 (default) = F(2x2,3x3) where the shape allows it, 0 = always the direct implicit GEMM
     const bool wino = !stem && opt_i(h, "winograd", 1) && KH == 3 && stride == 1 && pad == 1 && Cin % 16 == 0 &&
                       (Cout % 64 == 0 || (Cout % 32 == 0 && Cout > 64));
+    const int terms = opt_i(h, "conv_precision", 0);
+    const bool split = !stem && (terms == 3 || terms == 6) && KH == 1 && stride == 1 && pad == 0 && Cin % 16 == 0 && Cout % 4 == 0;
+    std::vector<unsigned short> pieces;
+    void* dsplit = nullptr;
+    if (split) {
+        pack_bf16_split_weights(w_host, Cout, Cin, Npad, pieces);
+        if ((rc = dev_upload(h, pieces.data(), pieces.size() * 2, &dsplit, tmp))) { free_pool(tmp); return rc; }
+    }
     if (stem) pack_stem_weights(w_host, packed);
     else if (wino) pack_wino_weights(w_host, Cout, Cin, packed);
     else {
-        if (Cin % 32) return fail(h, SPECMI_ERR_ARG, "Cin must be a multiple of 32 (got %d)", Cin);
+        if (Cin % 32) { free_pool(tmp); return fail(h, SPECMI_ERR_ARG, "Cin must be a multiple of 32 (got %d)", Cin); }
         pack_gemm_weights(w_host, Cout, Cin, KH, KW, Cin * KH * KW, Npad, packed);
     }
     if ((rc = dev_upload(h, packed.data(), packed.size() * 4, (void**)&dw, tmp)) ||
@@ -1073,7 +1095,8 @@ int specmi_conv2d(specmi_handle* h, const float* x, int B, int H, int W, int Cin
         a.ldo = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.relu = relu;
         a.force_variant = opt_i(h, "force_conv_variant", 0);
         a.wino_variant = opt_i(h, "force_wino_variant", 0);
-        lrc = wino ? launch_conv_wino(a, ctx) : launch_conv_igemm(a, ctx);
+        if (split && conv_bf16s_supported(a)) lrc = launch_conv_bf16s(a, dsplit, terms, ctx);
+        else lrc = wino ? launch_conv_wino(a, ctx) : launch_conv_igemm(a, ctx);
     }
     hipError_t se = hipStreamSynchronize(s);
     free_pool(tmp);

@@ -29,6 +29,7 @@ struct ConvW {
     int Kp = 0, Npad = 0;
     float *w = nullptr, *scale = nullptr, *shift = nullptr;  // device
     float* wino = nullptr;  // device: Winograd-domain filters (3x3 stride-1 layers only)
+    void* wsplit = nullptr; // device: bf16 pieces of the weights (1x1 stride-1 layers, only when option conv_precision != 0)
 };
 
 struct Bneck {

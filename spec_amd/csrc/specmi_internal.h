@@ -112,6 +112,15 @@ void pack_wino_weights(const float* w_oihw, int cout, int cin, std::vector<float
 int launch_conv_wino(const ConvArgs& a, const LaunchCtx& ctx);
 
 // ----------------------------------------------------------------------------------------
+// OPTIONAL: 1x1 / stride-1 convolution with fp32-class results on the bf16 matrix cores  (conv_bf16s.hip)
+// ----------------------------------------------------------------------------------------
+// w_oi (cout, cin) fp32 -> bf16 pieces w0 + w1 + w2 packed [piece][cin/8][Npad][8]
+void pack_bf16_split_weights(const float* w_oi, int cout, int cin, int Npad, std::vector<unsigned short>& out);
+bool conv_bf16s_supported(const ConvArgs& a);
+// terms = 6 (fp32-class) or 3 (~1e-5); a.w is ignored, wsplit = the packed pieces on the device
+int launch_conv_bf16s(const ConvArgs& a, const void* wsplit, int terms, const LaunchCtx& ctx);
+
+// ----------------------------------------------------------------------------------------
 // stem + pooling  (stem.hip)
 // ----------------------------------------------------------------------------------------
 // x NCHW (B,3,H,W); w = pack_stem_weights() output; out NHWC (B,OH,OW,64), BN+ReLU.

@@ -274,6 +274,19 @@ class _EngineModule(nn.Module):
     def _options(self):
         return {}
 
+    # Optional: the plain 1x1 / stride-1 convolutions of the ResNet trunk as sums of bf16 x bf16 piece products on the bf16
+    # matrix cores (conv_bf16s.hip).  0 = exact fp32 MFMA (default, what the benchmark's headline measures), 6 = three-way
+    # split, six products: fp32-class results; 3 = two-way split, three products: ~1e-5 on the trunk output.
+    conv_precision = 0
+
+    def set_conv_precision(self, terms: int):
+        if terms not in (0, 3, 6):
+            raise ValueError('conv_precision must be 0 (exact fp32), 3 or 6 (bf16 piece products)')
+        self.conv_precision = int(terms)
+        self._invalidate()
+        self._sig = ('stale',)          # forces the next forward to re-commit with the new option
+        return self
+
     def _smpl_model(self):
         return None
 
@@ -291,7 +304,7 @@ class _EngineModule(nn.Module):
             self._engine = Engine(self._kind, device)
         sd = {k: v for k, v in self.state_dict().items()
               if not k.startswith('smpl.') and v.dtype.is_floating_point}
-        self._engine.load(sd, smpl=self._smpl_model(), **self._options())
+        self._engine.load(sd, smpl=self._smpl_model(), conv_precision=int(self.conv_precision), **self._options())
         self._tracked = None
         self._sig = self._signature()
         self._frozen = freeze
