@@ -740,8 +740,8 @@ def main():
                               'max_rel_err_vs_fp32_path': {k: float(f'{v:.3e}') for k, v in errs.items()},
                               'worst_rel_err_vs_fp32_path': float(f'{max(errs.values()):.3e}'),
                               'fixtures_within_1e-4': 'tests/test_gpu_bf16split.py (3 HMR fixtures + CamCalib fixture, both term counts)',
-                              'layers': '28 plain 1x1 / stride-1 convolutions per ResNet-50 trunk (conv1 x16, unfused conv3 x12); 3x3, '
-                                        'strided, downsample-fused and FC layers stay on the exact fp32 kernels',
+                              'layers': 'the 32 1x1 convolutions of each ResNet-50 trunk (conv1 x16, conv3 x16 incl. the 4 with the downsample branch folded in); 3x3, '
+                                        'stem and FC layers stay on the exact fp32 kernels',
                               'launch': mode2})
                 del cc2, hm2, pipe2, run2, out2
         except Exception as e:

@@ -193,6 +193,12 @@ static int commit_fused_ds(specmi_handle* h, const std::string& prefix, Bneck& b
     }
     pack_gemm_weights(wcat.data(), N, K, 1, 1, K, Npad, packed);
     b.f_Npad = Npad;
+    b.f_wsplit = nullptr;
+    if (opt_i(h, "conv_precision", 0) != 0 && K1 % 16 == 0 && K2 % 16 == 0 && N % 4 == 0) {
+        std::vector<unsigned short> pieces;
+        pack_bf16_split_weights(wcat.data(), N, K, Npad, pieces);
+        if ((rc = dev_upload(h, pieces.data(), pieces.size() * 2, &b.f_wsplit, h->param_allocs))) return rc;
+    }
     if ((rc = dev_upload(h, packed.data(), packed.size() * 4, (void**)&b.f_w, h->param_allocs))) return rc;
     if ((rc = dev_upload(h, ones.data(), ones.size() * 4, (void**)&b.f_scale, h->param_allocs))) return rc;
     if ((rc = dev_upload(h, shift.data(), shift.size() * 4, (void**)&b.f_shift, h->param_allocs))) return rc;
@@ -547,10 +553,10 @@ static int exec_op(specmi_handle* h, const TrunkOp& op, const float* images, flo
         a.x2 = buf(op.in2_buf) + (size_t)b0 * op.in2_img;
         a.H2 = op.H2; a.W2 = op.W2; a.ldx2 = bk.ds.cin; a.Cin2 = bk.ds.cin; a.stride2 = bk.ds.stride;
     }
-    if (c.wsplit && !op.fused) {
+    if (const void* wsplit = op.fused ? op.fused->f_wsplit : c.wsplit) {
         const int terms = opt_i(h, "conv_precision", 0);
         if ((terms == 3 || terms == 6) && conv_bf16s_supported(a)) {
-            LAUNCHCHK(h, launch_conv_bf16s(a, c.wsplit, terms, ctx), op.label.c_str());
+            LAUNCHCHK(h, launch_conv_bf16s(a, wsplit, terms, ctx), op.label.c_str());
             return SPECMI_OK;
         }
     }

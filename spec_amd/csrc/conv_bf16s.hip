@@ -45,6 +45,11 @@ struct SArgs {
     float* out;
     unsigned x_bytes, w_piece_bytes;
     int ldx, Cout, Npad, ldo, M, nbn, nsteps, relu;
+    // optional second A source (K = Cin + Cin2: a bottleneck's downsample branch folded into its conv3, as in conv_igemm.hip):
+    // stages >= nsteps1 read x2, whose pixel of output row m is (b, oy * stride2, ox * stride2) of an (H2, W2) map
+    const float* x2;
+    unsigned x2_bytes;
+    int nsteps1, ldx2, H2, W2, stride2, OW, OHW;
 };
 
 constexpr unsigned kOOB16 = 0x80000000u;
@@ -58,7 +63,7 @@ __device__ __forceinline__ unsigned split_pair(float& a, float& b) {
     return hb;
 }
 
-template <int BN, int TERMS>
+template <int BN, int TERMS, bool DUAL = false>
 __global__ void __launch_bounds__(256) conv1x1_bf16s_kernel(const SArgs p) {
     static_assert(BN == 128 || BN == 64, "");
     static_assert(TERMS == 6 || TERMS == 3, "");
@@ -68,7 +73,7 @@ __global__ void __launch_bounds__(256) conv1x1_bf16s_kernel(const SArgs p) {
     constexpr int A_PIECE = 2 * BM * 16;          // bytes: 2 k octets x 128 rows x 16 B
     constexpr int B_PIECE = 2 * BN * 16;
     constexpr int STAGE = NP * (A_PIECE + B_PIECE);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hh = lane >> 5;
 
@@ -81,14 +86,24 @@ __global__ void __launch_bounds__(256) conv1x1_bf16s_kernel(const SArgs p) {
 
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, 3u * p.w_piece_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t x2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DUAL ? p.x2 : p.x), 0, DUAL ? p.x2_bytes : p.x_bytes, 0x00020000);
 
     // ---- loader coordinates ------------------------------------------------------------------------------------------
     const int a_kq = tid & 3, a_r = tid >> 2;                       // quad of the row's 16 k, row (and row + 64)
-    unsigned a_voff[2];
+    unsigned a_voff[2], a_voff2[DUAL ? 2 : 1];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + a_r + 64 * i;
         a_voff[i] = m < p.M ? (unsigned)(m * p.ldx * 4 + a_kq * 16) : kOOB16;
+        if (DUAL) {
+            const int mm = m < p.M ? m : 0;
+            int pix2 = mm;
+            if (p.stride2 != 1) {
+                const int b2 = mm / p.OHW, rem = mm - b2 * p.OHW, oy = rem / p.OW, ox = rem - oy * p.OW;
+                pix2 = (b2 * p.H2 + oy * p.stride2) * p.W2 + ox * p.stride2;
+            }
+            a_voff2[i] = m < p.M ? (unsigned)(pix2 * p.ldx2 * 4 + a_kq * 16) : kOOB16;
+        }
     }
     const unsigned a_lds = (unsigned)((a_kq >> 1) * (BM * 16) + a_r * 16 + (a_kq & 1) * 8);   // + 64 rows: + 1024
     const bool b_active = BN == 128 || tid < 2 * BN;
@@ -98,15 +113,17 @@ __global__ void __launch_bounds__(256) conv1x1_bf16s_kernel(const SArgs p) {
     f32x4 ra[2];
     u32x4 rb[NP];
     auto load_stage = [&](int s) {
+        const bool second = DUAL && s >= p.nsteps1;       // wave-uniform: descriptor picked with scalar selects
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, a_voff[i], (unsigned)(s * 64), 0));
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(second ? x2rs : xrs, second ? a_voff2[DUAL ? i : 0] : a_voff[i],
+                                                                                    (unsigned)((second ? s - p.nsteps1 : s) * 64), 0));
 #pragma unroll
         for (int pc = 0; pc < NP; ++pc)
             rb[pc] = __builtin_amdgcn_raw_buffer_load_b128(wrs, b_voff, (unsigned)(pc * p.w_piece_bytes + s * 2 * p.Npad * 16), 0);
     };
     auto store_stage = [&](int buf) {
-        char* const A = smem + buf * STAGE;
+        char* const A = smem_b + buf * STAGE;
         char* const B = A + NP * A_PIECE;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -143,7 +160,7 @@ __global__ void __launch_bounds__(256) conv1x1_bf16s_kernel(const SArgs p) {
         const int buf = s & 1;
         const bool more = s + 1 < p.nsteps;
         if (more) load_stage(s + 1);
-        const char* const A = smem + buf * STAGE;
+        const char* const A = smem_b + buf * STAGE;
         const char* const B = A + NP * A_PIECE;
         bf16x8 fa[NP][2], fb[NP][TN];
 #pragma unroll
@@ -176,7 +193,7 @@ __global__ void __launch_bounds__(256) conv1x1_bf16s_kernel(const SArgs p) {
     // ---- epilogue: two passes of 64 rows through LDS -> 16-byte row-contiguous traffic -----------------------------------
     constexpr int LDC = BN + 4;
     constexpr int QPR = BN / 4, RPP = 256 / QPR, NPASS = 64 / RPP;
-    float* const Cs = reinterpret_cast<float*>(smem);
+    float* const Cs = reinterpret_cast<float*>(smem_b);
     const int cq = tid % QPR, r0 = tid / QPR;
     const int n = n0 + cq * 4;
     const bool col_ok = n < p.Cout;                  // Cout % 4 == 0 (checked by the launcher): a quad is all in or all out
@@ -255,26 +272,33 @@ void pack_bf16_split_weights(const float* w, int cout, int cin, int Npad, std::v
 
 bool conv_bf16s_supported(const ConvArgs& a) {
     const size_t xb = (size_t)a.B * a.H * a.W * a.ldx * 4;
-    return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && !a.x2 && a.Cin % 16 == 0 && a.Npad % 64 == 0 &&
+    if (a.x2) {
+        const size_t x2b = (size_t)a.B * a.H2 * a.W2 * a.ldx2 * 4;
+        if (a.Cin2 % 16 || a.ldx2 % 4 || a.stride2 < 1 || x2b >= ((size_t)1 << 31) || (reinterpret_cast<uintptr_t>(a.x2) & 15) ||
+            (a.H - 1) * a.stride2 >= a.H2 || (a.W - 1) * a.stride2 >= a.W2)
+            return false;
+    }
+    return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.Cin % 16 == 0 && a.Npad % 64 == 0 &&
            a.Cout % 4 == 0 && a.ldx % 4 == 0 && a.ldo % 4 == 0 && a.OH == a.H && a.OW == a.W && xb < ((size_t)1 << 31) &&
-           (size_t)a.Cin * a.Npad * 2 < ((size_t)1 << 30) && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 &&
+           (size_t)(a.Cin + a.Cin2) * a.Npad * 2 < ((size_t)1 << 30) && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 &&
            (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 && (!a.res || (reinterpret_cast<uintptr_t>(a.res) & 15) == 0);
 }
 
-template <int BN, int TERMS>
+template <int BN, int TERMS, bool DUAL = false>
 static int bf16s_launch(SArgs k, const LaunchCtx& ctx, double flops, double bytes) {
     constexpr int NP = TERMS == 6 ? 3 : 2;
     constexpr int stage = NP * (2 * 128 * 16 + 2 * BN * 16);
     constexpr int cs = 64 * (BN + 4) * 4;
     constexpr int smem = 2 * stage > cs ? 2 * stage : cs;
     static DevOnce once;
-    if (int e = set_dyn_lds_once(once, reinterpret_cast<const void*>(&conv1x1_bf16s_kernel<BN, TERMS>), smem)) return e;
+    if (int e = set_dyn_lds_once(once, reinterpret_cast<const void*>(&conv1x1_bf16s_kernel<BN, TERMS, DUAL>), smem)) return e;
     k.nbn = BN == 64 ? (k.Cout + 63) / 64 : k.Npad / 128;
     const int grid = ((k.M + 127) / 128) * k.nbn;
-    ProfScope ps(ctx, TERMS == 6 ? (BN == 128 ? "conv1x1_bf16split<128x128,6 terms>" : "conv1x1_bf16split<128x64,6 terms>")
-                                 : (BN == 128 ? "conv1x1_bf16split<128x128,3 terms>" : "conv1x1_bf16split<128x64,3 terms>"),
+    ProfScope ps(ctx, DUAL ? (TERMS == 6 ? "conv1x1_bf16split<128xN,6 terms,2src>" : "conv1x1_bf16split<128xN,3 terms,2src>")
+                      : TERMS == 6 ? (BN == 128 ? "conv1x1_bf16split<128x128,6 terms>" : "conv1x1_bf16split<128x64,6 terms>")
+                                   : (BN == 128 ? "conv1x1_bf16split<128x128,3 terms>" : "conv1x1_bf16split<128x64,3 terms>"),
                  flops, bytes);
-    hipLaunchKernelGGL((conv1x1_bf16s_kernel<BN, TERMS>), dim3(grid), dim3(256), smem, ctx.stream, k);
+    hipLaunchKernelGGL((conv1x1_bf16s_kernel<BN, TERMS, DUAL>), dim3(grid), dim3(256), smem, ctx.stream, k);
     return (int)hipGetLastError();
 }
 
@@ -285,11 +309,19 @@ int launch_conv_bf16s(const ConvArgs& a, const void* wsplit, int terms, const La
     k.x = a.x; k.w = wsplit; k.scale = a.scale; k.shift = a.shift; k.res = a.res; k.out = a.out;
     k.M = a.B * a.H * a.W;
     k.x_bytes = (unsigned)((size_t)k.M * a.ldx * 4);
-    k.w_piece_bytes = (unsigned)((size_t)a.Cin * a.Npad * 2);
-    k.ldx = a.ldx; k.Cout = a.Cout; k.Npad = a.Npad; k.ldo = a.ldo; k.nbn = 0; k.nsteps = a.Cin / 16; k.relu = a.relu;
-    const double flops = 2.0 * k.M * (double)a.Cout * a.Cin;
-    const double bytes = 4.0 * ((double)k.M * a.Cin + (double)k.M * a.Cout * (a.res ? 2.0 : 1.0)) + 6.0 * a.Cin * (double)a.Cout;
+    const int K = a.Cin + (a.x2 ? a.Cin2 : 0);
+    k.w_piece_bytes = (unsigned)((size_t)K * a.Npad * 2);
+    k.ldx = a.ldx; k.Cout = a.Cout; k.Npad = a.Npad; k.ldo = a.ldo; k.nbn = 0; k.nsteps = K / 16; k.relu = a.relu;
+    k.x2 = a.x2; k.nsteps1 = a.Cin / 16; k.ldx2 = a.ldx2; k.H2 = a.H2; k.W2 = a.W2; k.stride2 = a.stride2; k.OW = a.W; k.OHW = a.H * a.W;
+    k.x2_bytes = a.x2 ? (unsigned)((size_t)a.B * a.H2 * a.W2 * a.ldx2 * 4) : 0;
+    const double flops = 2.0 * k.M * (double)a.Cout * K;
+    const double bytes = 4.0 * ((double)k.M * a.Cin + (a.x2 ? (double)a.B * a.H2 * a.W2 * a.Cin2 : 0.0) +
+                                (double)k.M * a.Cout * (a.res ? 2.0 : 1.0)) + 6.0 * K * (double)a.Cout;
     const bool wide = a.Npad % 128 == 0;
+    if (a.x2) {
+        if (terms == 6) return wide ? bf16s_launch<128, 6, true>(k, ctx, flops, bytes) : bf16s_launch<64, 6, true>(k, ctx, flops, bytes);
+        return wide ? bf16s_launch<128, 3, true>(k, ctx, flops, bytes) : bf16s_launch<64, 3, true>(k, ctx, flops, bytes);
+    }
     if (terms == 6) return wide ? bf16s_launch<128, 6>(k, ctx, flops, bytes) : bf16s_launch<64, 6>(k, ctx, flops, bytes);
     return wide ? bf16s_launch<128, 3>(k, ctx, flops, bytes) : bf16s_launch<64, 3>(k, ctx, flops, bytes);
 }

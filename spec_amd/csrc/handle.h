@@ -39,6 +39,7 @@ struct Bneck {
     // conv3 + bn3 and downsample conv + bn folded into ONE 1x1 GEMM over [conv2 output | block input]:
     // weights pre-multiplied by the BN scales (fp64), shift = shift3 + shift_ds, scale = 1
     float *f_w = nullptr, *f_scale = nullptr, *f_shift = nullptr;
+    void* f_wsplit = nullptr;   // bf16 pieces of the same folded matrix (option conv_precision != 0)
     int f_Npad = 0;
 };
 

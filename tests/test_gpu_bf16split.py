@@ -86,7 +86,7 @@ def test_hmr_fixtures_through_split_bf16(tag, uc, ucf, terms):
        t(g['bbox_center']).to(DEV), t(g['img_w']).to(DEV), t(g['img_h']).to(DEV)) if uc else hm(x)
     n_split = sum(e['launches'] for e in eng.profile_read() if 'bf16split' in e['kernel'])
     eng.profile(False)
-    assert n_split == 28, n_split          # 16 x conv1 + the 12 conv3 that are not fused with a downsample branch
+    assert n_split == 32, n_split          # 16 x conv1 + 16 x conv3 (4 of them with the downsample branch folded in as a second source)
     for k in out:
         assert rel_err(out[k].cpu().numpy(), g['out_' + k]) < 1e-4, (k, rel_err(out[k].cpu().numpy(), g['out_' + k]))
 
@@ -112,3 +112,22 @@ def test_default_is_exact_fp32():
     assert not any('bf16' in k for k in ks)
     with pytest.raises(ValueError):
         cc.set_conv_precision(4)
+
+
+@pytest.mark.parametrize('terms,tol', [(6, 5e-6), (3, 1e-4)])
+def test_trunk_features_split_vs_exact(terms, tol):
+    """The whole ResNet-50 trunk (incl. the four conv3 + downsample layers that read a second, strided A source) through the
+    bf16 path against the exact fp32 path on the same weights and images."""
+    cc, _ = gpu_models(True, True, DEV)
+    x = t(synth.images(77, 3)).to(DEV)
+    ref = cc.engine(torch.device(DEV)).trunk(x).clone()
+    cc2, _ = _models(terms)
+    eng = cc2.engine(torch.device(DEV))
+    eng.profile(True)
+    got = eng.trunk(x)
+    ents = eng.profile_read()
+    eng.profile(False)
+    assert sum(e['launches'] for e in ents if '2src' in e['kernel'] and 'bf16split' in e['kernel']) == 4, ents
+    assert not any('conv_igemm' in e['kernel'] and '2src' in e['kernel'] for e in ents), ents
+    err = float((got.double() - ref.double()).abs().max() / ref.double().abs().max())
+    assert err < tol, err
