@@ -600,28 +600,33 @@ def main():
               'batch': 64, 'steps': n2, 'ms_per_step': round(ms2, 3), 'images_per_s': round(64e3 / ms2, 1),
               'algorithmic_TFLOPs': round(tf2, 2), 'frac_of_mfma_peak_algorithmic': round(tf2 / PEAK_FP32_MFMA_TFLOPS, 4)}
 
-    # ---- small batches: latency of one whole step (2 streams + hipGraph replay) ------------------------------------
+    # ---- small batches: latency of one whole step (grouped launches of both trunks + hipGraph replay; two streams beside) -----
     small = None
     if rank == 0 and not args.no_small_batch and not args.no_graph:
         small = []
         try:
             from spec_amd.pipeline import GraphedPipeline
             for b in (1, 8):
-                g = GraphedPipeline(pipe, x[:b].contiguous(), scale[:b].contiguous(), center[:b].contiguous(),
-                                    img_w[:b].contiguous(), img_h[:b].contiguous())
-                ins = g.static_in
-                for _ in range(5):
-                    g(*ins)
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(50):
-                    g(*ins)
-                e1.record()
-                torch.cuda.synchronize()
-                ms = e0.elapsed_time(e1) / 50
-                small.append({'batch': b, 'ms_per_step': round(ms, 3), 'images_per_s': round(b * 1e3 / ms, 1)})
-                del g
+                row = {'batch': b}
+                for tag, pp in (('grouped', SpecPipeline(cc, hm, grouped=True)), ('two_streams', SpecPipeline(cc, hm, overlap=True, grouped=False))):
+                    g = GraphedPipeline(pp, x[:b].contiguous(), scale[:b].contiguous(), center[:b].contiguous(),
+                                        img_w[:b].contiguous(), img_h[:b].contiguous())
+                    ins = g.static_in
+                    for _ in range(5):
+                        g(*ins)
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(100):
+                        g(*ins)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    row[tag + '_ms'] = round(e0.elapsed_time(e1) / 100, 3)
+                    del g
+                ms = row['grouped_ms']
+                row.update({'ms_per_step': ms, 'images_per_s': round(b * 1e3 / ms, 1),
+                            'launch': 'both trunks per layer as one grouped launch, one stream, hipGraph replay (bit-identical to two streams)'})
+                small.append(row)
         except Exception as e:
             log('[bench] small-batch latency failed:', repr(e))
 

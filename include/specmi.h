@@ -129,6 +129,19 @@ int specmi_commit(specmi_handle* h);
 
 /* ---- forward: CamCalib ----------------------------------------------------------------- */
 
+/* The ResNet trunks of TWO committed models (CamCalib + SPEC: camcalib/model.py:73 `self.backbone(images)` and
+ * spec/models/hmr.py:92 `self.backbone(images)`, which the reference runs as two processes / two calls) walked in lockstep
+ * with every layer of both as ONE grouped launch: images_a / images_b (B,3,H,W) NCHW -> feat_a / feat_b (B, H/32, W/32, C)
+ * NHWC.  Both trunks must be ResNets of the same depth and see the same B, H, W; each keeps its own weights and workspaces.
+ * Results are bit-identical to two specmi_trunk_forward calls. */
+int specmi_trunk_forward_pair(specmi_handle* ha, specmi_handle* hb, const float* images_a, const float* images_b, int B,
+                              int H, int W, float* feat_a, float* feat_b, void* stream);
+
+/* The part of CameraRegressorNetwork.forward after the backbone (camcalib/model.py:74-80: avg-pool, flatten, the three
+ * Linear chains) from a trunk feature map (B,fh,fw,C) NHWC -> vfov / pitch / roll logits (B,nbins) each. */
+int specmi_camcalib_head_forward(specmi_handle* h, const float* feat_nhwc, int B, int fh, int fw, float* logits_vfov,
+                                 float* logits_pitch, float* logits_roll, void* stream);
+
 /* CameraRegressorNetwork.forward (camcalib/model.py:72-81): images (B,3,H,W) NCHW fp32 ->
  * three (B,256) logit tensors [vfov, pitch, roll]. */
 int specmi_camcalib_forward(specmi_handle* h, const float* images_nchw, int B, int H, int W,

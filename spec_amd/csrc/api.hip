@@ -522,22 +522,34 @@ struct TrunkOp {
     size_t in2_img = 0;
 };
 
-static int exec_op(specmi_handle* h, const TrunkOp& op, const float* images, float* feat_out, int b0, int nb,
-                   int Himg, int Wimg, hipStream_t s) {
+// What one op of the list launches: the fused-conv arguments and the kernel family they go to
+struct OpLaunch {
+    int kind = 2;             // 0 stem, 1 maxpool, 2 conv
+    ConvArgs a;
+    int family = 0;           // conv: 0 implicit GEMM, 1 Winograd, 2 split-bf16 (optional path)
+    const void* wsplit = nullptr;
+    int terms = 0;
+    const float *x = nullptr, *w = nullptr, *scale = nullptr, *shift = nullptr;   // stem / maxpool operands
+    float* out = nullptr;
+};
+
+static OpLaunch prepare_op(specmi_handle* h, const TrunkOp& op, const float* images, float* feat_out, int b0, int nb,
+                           int Himg, int Wimg) {
     auto buf = [&](int idx) -> float* { return idx == -2 ? feat_out : h->act[idx]; };
-    LaunchCtx ctx{s, &h->prof, op.label.c_str()};
+    OpLaunch L;
+    L.kind = op.kind;
     if (op.kind == 0) {
-        LAUNCHCHK(h, launch_stem(images + (size_t)b0 * 3 * Himg * Wimg, h->stem.w, h->stem.scale, h->stem.shift,
-                                 buf(op.out_buf) + (size_t)b0 * op.out_img, nb, Himg, Wimg, op.OH, op.OW, 1, ctx), "stem");
-        return SPECMI_OK;
+        L.x = images + (size_t)b0 * 3 * Himg * Wimg; L.w = h->stem.w; L.scale = h->stem.scale; L.shift = h->stem.shift;
+        L.out = buf(op.out_buf) + (size_t)b0 * op.out_img;
+        return L;
     }
     if (op.kind == 1) {
-        LAUNCHCHK(h, launch_maxpool3x3s2(buf(op.in_buf) + (size_t)b0 * op.in_img, buf(op.out_buf) + (size_t)b0 * op.out_img, nb,
-                                         op.H, op.W, 64, op.OH, op.OW, ctx), "maxpool");
-        return SPECMI_OK;
+        L.x = buf(op.in_buf) + (size_t)b0 * op.in_img;
+        L.out = buf(op.out_buf) + (size_t)b0 * op.out_img;
+        return L;
     }
     const ConvW& c = *op.c;
-    ConvArgs a;
+    ConvArgs& a = L.a;
     a.x = buf(op.in_buf) + (size_t)b0 * op.in_img;
     a.w = c.w; a.scale = c.scale; a.shift = c.shift;
     a.res = op.res_buf == -1 ? nullptr : buf(op.res_buf) + (size_t)b0 * op.out_img;
@@ -556,35 +568,61 @@ static int exec_op(specmi_handle* h, const TrunkOp& op, const float* images, flo
     if (const void* wsplit = op.fused ? op.fused->f_wsplit : c.wsplit) {
         const int terms = opt_i(h, "conv_precision", 0);
         if ((terms == 3 || terms == 6) && conv_bf16s_supported(a)) {
-            LAUNCHCHK(h, launch_conv_bf16s(a, wsplit, terms, ctx), op.label.c_str());
-            return SPECMI_OK;
+            L.family = 2; L.wsplit = wsplit; L.terms = terms;
+            return L;
         }
     }
     if (c.wino && opt_i(h, "winograd", 1) && conv_wino_supported(a)) {
         a.w = c.wino;
-        LAUNCHCHK(h, launch_conv_wino(a, ctx), op.label.c_str());
+        L.family = 1;
+    }
+    return L;
+}
+
+// partner != nullptr: the same op of a second network, launched together (one grouped launch); the caller has checked
+// that both ops have the same kind / family / shape
+static int launch_op(specmi_handle* h, const TrunkOp& op, const OpLaunch& L, const OpLaunch* partner, int nb, int Himg, int Wimg,
+                     hipStream_t s) {
+    LaunchCtx ctx{s, &h->prof, op.label.c_str()};
+    if (L.kind == 0) {
+        StemPair sp;
+        if (partner) { sp.x = partner->x; sp.w = partner->w; sp.scale = partner->scale; sp.shift = partner->shift; sp.out = partner->out; }
+        LAUNCHCHK(h, launch_stem(L.x, L.w, L.scale, L.shift, L.out, nb, Himg, Wimg, op.OH, op.OW, 1, ctx, partner ? &sp : nullptr), "stem");
         return SPECMI_OK;
     }
-    LAUNCHCHK(h, launch_conv_igemm(a, ctx), op.label.c_str());
+    if (L.kind == 1) {
+        LAUNCHCHK(h, launch_maxpool3x3s2(L.x, L.out, nb, op.H, op.W, 64, op.OH, op.OW, ctx, partner ? partner->x : nullptr,
+                                         partner ? partner->out : nullptr), "maxpool");
+        return SPECMI_OK;
+    }
+    if (L.family == 2) {
+        LAUNCHCHK(h, launch_conv_bf16s(L.a, L.wsplit, L.terms, ctx), op.label.c_str());
+        if (partner) LAUNCHCHK(h, launch_conv_bf16s(partner->a, partner->wsplit, partner->terms, ctx), op.label.c_str());
+        return SPECMI_OK;
+    }
+    if (L.family == 1) LAUNCHCHK(h, launch_conv_wino(L.a, ctx, partner ? &partner->a : nullptr), op.label.c_str());
+    else LAUNCHCHK(h, launch_conv_igemm(L.a, ctx, partner ? &partner->a : nullptr), op.label.c_str());
     return SPECMI_OK;
 }
 
-// images NCHW -> layer4 map NHWC in *feat (a workspace buffer unless feat_out given).
-// Option "trunk_subbatch" = S > 0: the stem, the max-pool and the first "trunk_subbatch_layers"
-// ResNet stages are run S images at a time (activations of a slice are <= 103 MB at S = 32 and stay
-// resident in the 256 MiB Infinity Cache between layers); later stages see the whole batch.
-static int run_trunk(specmi_handle* h, const float* images, int B, int H, int W, float* feat_out, const float** feat,
-                     int* fh, int* fw, hipStream_t s) {
-    int rc;
-    if (H < 32 || W < 32) return fail(h, SPECMI_ERR_ARG, "image size %dx%d too small", H, W);
-    if ((rc = ensure_ws(h, B, H, W))) return rc;
-    if (h->hrnet) {
-        if ((rc = hrnet_forward(h, images, B, H, W, feat_out, fh, fw, s))) return rc;
-        *feat = feat_out ? feat_out : hrnet_feat_ws(h);
-        return SPECMI_OK;
-    }
+static int exec_op(specmi_handle* h, const TrunkOp& op, const float* images, float* feat_out, int b0, int nb,
+                   int Himg, int Wimg, hipStream_t s) {
+    const OpLaunch L = prepare_op(h, op, images, feat_out, b0, nb, Himg, Wimg);
+    return launch_op(h, op, L, nullptr, nb, Himg, Wimg, s);
+}
+
+struct TrunkPlan {
     std::vector<TrunkOp> ops;
     std::vector<int> stage_of;   // resnet stage (0 = stem/pool, 1..4) of each op
+    int final_buf = 1, fh = 0, fw = 0;
+};
+
+// the trunk's op list for an (H, W) input: the stem, the max-pool and one fused conv per layer, with the ping-pong
+// buffers they read and write
+static void plan_trunk(specmi_handle* h, int H, int W, bool to_caller, TrunkPlan& P) {
+    float* const feat_out = to_caller ? reinterpret_cast<float*>(1) : nullptr;   // only its null-ness matters here
+    std::vector<TrunkOp>& ops = P.ops;
+    std::vector<int>& stage_of = P.stage_of;
     const int oh1 = conv_out(H, 7, 2, 3), ow1 = conv_out(W, 7, 2, 3);
     int ch = conv_out(oh1, 3, 2, 1), cw = conv_out(ow1, 3, 2, 1);
     ops.push_back({0, nullptr, -1, 0, -1, H, W, oh1, ow1, 1, "backbone.conv1", (size_t)3 * H * W, (size_t)oh1 * ow1 * 64});
@@ -641,6 +679,28 @@ static int run_trunk(specmi_handle* h, const float* images, int B, int H, int W,
         xi = t1;
         final_buf = out;
     }
+    P.final_buf = final_buf; P.fh = ch; P.fw = cw;
+}
+
+// images NCHW -> layer4 map NHWC in *feat (a workspace buffer unless feat_out given).
+// Option "trunk_subbatch" = S > 0: the stem, the max-pool and the first "trunk_subbatch_layers"
+// ResNet stages are run S images at a time (activations of a slice are <= 103 MB at S = 32 and stay
+// resident in the 256 MiB Infinity Cache between layers); later stages see the whole batch.
+static int run_trunk(specmi_handle* h, const float* images, int B, int H, int W, float* feat_out, const float** feat,
+                     int* fh, int* fw, hipStream_t s) {
+    int rc;
+    if (H < 32 || W < 32) return fail(h, SPECMI_ERR_ARG, "image size %dx%d too small", H, W);
+    if ((rc = ensure_ws(h, B, H, W))) return rc;
+    if (h->hrnet) {
+        if ((rc = hrnet_forward(h, images, B, H, W, feat_out, fh, fw, s))) return rc;
+        *feat = feat_out ? feat_out : hrnet_feat_ws(h);
+        return SPECMI_OK;
+    }
+    TrunkPlan P;
+    plan_trunk(h, H, W, feat_out != nullptr, P);
+    const std::vector<TrunkOp>& ops = P.ops;
+    const std::vector<int>& stage_of = P.stage_of;
+    const int final_buf = P.final_buf, ch = P.fh, cw = P.fw;
     const int S = opt_i(h, "trunk_subbatch", 0);
     const int Lsplit = opt_i(h, "trunk_subbatch_layers", 2);
     size_t first_full = 0;
@@ -656,6 +716,35 @@ static int run_trunk(specmi_handle* h, const float* images, int B, int H, int W,
         if ((rc = exec_op(h, ops[i], images, feat_out, 0, B, H, W, s))) return rc;
     *feat = final_buf == -2 ? feat_out : h->act[final_buf];
     *fh = ch; *fw = cw;
+    return SPECMI_OK;
+}
+
+
+// The two ResNet trunks of the path (CamCalib + SPEC: same depth, same input size) walked in lockstep, every layer of both
+// as ONE grouped launch (SURVEY.md 7, step 7's alternative to two streams): half the launches, no side-stream join, and the
+// last, partially filled round of workgroups of one network is filled by the other.  Each network keeps its own weights and
+// activation buffers; an image's result is bit-identical to the separate launches (same kernels, same k order).
+static int run_trunk_pair(specmi_handle* ha, specmi_handle* hb, const float* img_a, const float* img_b, int B, int H, int W,
+                          float* feat_a, float* feat_b, hipStream_t s) {
+    int rc;
+    if (H < 32 || W < 32) return fail(ha, SPECMI_ERR_ARG, "image size %dx%d too small", H, W);
+    if ((rc = ensure_ws(ha, B, H, W))) return rc;
+    if ((rc = ensure_ws(hb, B, H, W))) { ha->err = hb->err; return rc; }
+    TrunkPlan Pa, Pb;
+    plan_trunk(ha, H, W, true, Pa);
+    plan_trunk(hb, H, W, true, Pb);
+    if (Pa.ops.size() != Pb.ops.size()) return fail(ha, SPECMI_ERR_ARG, "the two trunks have different depths");
+    for (size_t i = 0; i < Pa.ops.size(); ++i) {
+        const OpLaunch La = prepare_op(ha, Pa.ops[i], img_a, feat_a, 0, B, H, W);
+        const OpLaunch Lb = prepare_op(hb, Pb.ops[i], img_b, feat_b, 0, B, H, W);
+        const TrunkOp &oa = Pa.ops[i], &ob = Pb.ops[i];
+        if (La.kind != Lb.kind || La.family != Lb.family || oa.H != ob.H || oa.W != ob.W || oa.OH != ob.OH || oa.OW != ob.OW ||
+            (La.kind == 2 && (oa.c->cin != ob.c->cin || oa.c->cout != ob.c->cout || oa.c->k != ob.c->k || oa.c->stride != ob.c->stride ||
+                              (oa.fused != nullptr) != (ob.fused != nullptr) || oa.relu != ob.relu)))
+            return fail(ha, SPECMI_ERR_ARG, "op %zu (%s) differs between the two trunks: grouped launches need identical layer shapes",
+                        i, oa.label.c_str());
+        if ((rc = launch_op(ha, oa, La, &Lb, B, H, W, s))) return rc;
+    }
     return SPECMI_OK;
 }
 
@@ -907,6 +996,31 @@ int specmi_trunk_forward(specmi_handle* h, const float* images, int B, int H, in
     return run_trunk(h, images, B, H, W, feat, &f, &fh, &fw, (hipStream_t)stream);
 }
 
+int specmi_trunk_forward_pair(specmi_handle* ha, specmi_handle* hb, const float* images_a, const float* images_b, int B, int H,
+                              int W, float* feat_a, float* feat_b, void* stream) {
+    ENTER(ha); NEED_COMMIT(ha);
+    if (!hb) return fail(ha, SPECMI_ERR_ARG, "second handle is NULL");
+    if (!hb->committed) return fail(ha, SPECMI_ERR_STATE, "second handle not committed");
+    if (hb->device != ha->device) return fail(ha, SPECMI_ERR_ARG, "the two handles live on different devices");
+    if (!images_a || !images_b || !feat_a || !feat_b || B <= 0) return fail(ha, SPECMI_ERR_ARG, "bad argument");
+    if (ha->hrnet || hb->hrnet || ha->blocks.size() != hb->blocks.size() || ha->blocks.empty() ||
+        ha->blocks[0].basic != hb->blocks[0].basic)
+        return fail(ha, SPECMI_ERR_ARG, "grouped trunk launches need two ResNet trunks of the same depth");
+    return run_trunk_pair(ha, hb, images_a, images_b, B, H, W, feat_a, feat_b, (hipStream_t)stream);
+}
+
+static int run_camcalib_head(specmi_handle* h, const float* f, int B, int fh, int fw, float* lv, float* lp, float* lr, hipStream_t s);
+
+int specmi_camcalib_head_forward(specmi_handle* h, const float* feat, int B, int fh, int fw, float* lv, float* lp, float* lr,
+                                 void* stream) {
+    ENTER(h); NEED_COMMIT(h);
+    if (h->kind != SPECMI_MODEL_CAMCALIB) return fail(h, SPECMI_ERR_STATE, "handle is not a CamCalib model");
+    if (!feat || !lv || !lp || !lr || B <= 0 || fh <= 0 || fw <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
+    int rc;
+    if ((rc = ensure_ws(h, B, 32, 32))) return rc;
+    return run_camcalib_head(h, feat, B, fh, fw, lv, lp, lr, (hipStream_t)stream);
+}
+
 int specmi_camcalib_forward(specmi_handle* h, const float* images, int B, int H, int W, float* lv, float* lp, float* lr,
                             void* stream) {
     ENTER(h); NEED_COMMIT(h);
@@ -915,6 +1029,11 @@ int specmi_camcalib_forward(specmi_handle* h, const float* images, int B, int H,
     hipStream_t s = (hipStream_t)stream;
     const float* f; int fh, fw, rc;
     if ((rc = run_trunk(h, images, B, H, W, nullptr, &f, &fh, &fw, s))) return rc;
+    return run_camcalib_head(h, f, B, fh, fw, lv, lp, lr, s);
+}
+
+static int run_camcalib_head(specmi_handle* h, const float* f, int B, int fh, int fw, float* lv, float* lp, float* lr, hipStream_t s) {
+    int rc;
     {
         LaunchCtx ctx{s, &h->prof, "avgpool"};
         LAUNCHCHK(h, launch_avgpool(f, h->xf, B, fh * fw, h->feat_ch, 2048, ctx), "avgpool");

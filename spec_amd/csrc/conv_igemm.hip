@@ -68,6 +68,10 @@ struct KArgs {
     int relu;
     long split_out_stride;   // SPLITK: blockIdx.y = K slice z of nchunks chunks; partial tile z goes to out + z * stride
     int vec_ok;  // out/res rows are 16-byte aligned: float4 epilogue traffic allowed
+    // grouped launch (gridDim.z = 2): blockIdx.z = 1 runs the SAME layer shape of a second network on its own tensors - the
+    // two ResNet-50 trunks of the path (CamCalib + SPEC) as one launch per layer: half the launches, and the partially
+    // filled last round of workgroups of one network is filled by the other
+    struct { const float *x, *w, *scale, *shift, *res, *x2; float* out; } g1;
 #ifdef SPECMI_TUNE
     int ablate;  // perf ablation bits (wrong results!): 1 no global loads in loop, 2 no LDS restage, 4 no epilogue stores
     unsigned long long* tprof;  // per-phase cycle counters (s_memtime)
@@ -103,6 +107,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
     float* Bs = smem + 2 * A_STAGE;
 
     const int tid = threadIdx.x;
+    const bool grp = blockIdx.z != 0;          // wave-uniform: scalar selects
+    const float* const px = grp ? p.g1.x : p.x;
+    const float* const pw = grp ? p.g1.w : p.w;
+    const float* const pscale = grp ? p.g1.scale : p.scale;
+    const float* const pshift = grp ? p.g1.shift : p.shift;
+    const float* const pres = grp ? p.g1.res : p.res;
+    const float* const px2 = grp ? p.g1.x2 : p.x2;
+    float* const pout = grp ? p.g1.out : p.out;
 #ifdef SPECMI_TUNE
     const long long t_start = __builtin_amdgcn_s_memtime();
     long long tp[4] = {0, 0, 0, 0};
@@ -117,9 +129,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- buffer descriptors (wave-uniform) and per-thread row offsets -----------------------
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t x2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DUAL ? p.x2 : p.x), 0, DUAL ? p.x2_bytes : p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(px), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pw), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t x2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DUAL ? px2 : px), 0, DUAL ? p.x2_bytes : p.x_bytes, 0x00020000);
     const int a_kq = tid % KQ, a_r = tid / KQ;
     unsigned a_voff[AI];   // byte offset of (row's tap-(0,0) pixel, quad a_kq); out-of-range when the row is past M (1x1)
     unsigned a_mask[AI];   // 3x3: bit t = filter tap t lies inside the image for this row
@@ -300,12 +312,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
                 if (q == 0 && s == 0) {
                     if (PF) {
                         if (!TUNE_ABLATE(1)) load_chunk(c + 1);
-                    } else if (p.res && full) {   // last chunk: fetch the residual rows of the epilogue
+                    } else if (pres && full) {   // last chunk: fetch the residual rows of the epilogue
 #pragma unroll
                         for (int ps = 0; ps < NP; ++ps) {
                             const int m = m0 + r0 + ps * RPP;
                             const size_t o = (m < p.M) ? (size_t)m * p.ldo + n : (size_t)n;
-                            rr[ps] = *reinterpret_cast<const f32x4*>(p.res + o);
+                            rr[ps] = *reinterpret_cast<const f32x4*>(pres + o);
                         }
                     }
                 }
@@ -341,7 +353,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
     // 4-byte stores at a row stride; after the transpose every lane moves 16 contiguous bytes.
     // All waves have passed the barrier above, so the A/B stages are free to reuse.
     float* Cs = smem;
-    float* const outp = SPLITK ? p.out + (size_t)blockIdx.y * p.split_out_stride : p.out;
+    float* const outp = SPLITK ? pout + (size_t)blockIdx.y * p.split_out_stride : pout;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -353,8 +365,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
             }
     __syncthreads();
 
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-    const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(pscale + n);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(pshift + n);
     if (full) {
         // the residual rows were fetched under the last chunk's MFMAs (rr)
 #pragma unroll
@@ -365,7 +377,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaf(a[e], sc[e], sh[e]);
-            if (p.res) {
+            if (pres) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] += rr[ps][e];
             }
@@ -384,7 +396,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
             for (int e = 0; e < 4; ++e) {
                 if (n + e < p.Cout) {
                     float t = fmaf(Cs[row * LDC + cq * 4 + e], sc[e], sh[e]);
-                    if (p.res) t += p.res[o + e];
+                    if (pres) t += pres[o + e];
                     if (p.relu) t = fmaxf(t, 0.f);
                     outp[o + e] = t;
                 }
@@ -409,6 +421,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
 template <int BM, int BN, int WGM, int WGN, bool IS1X1, int BK = 32, bool DUAL = false, bool SPLITK = false, bool BDIR = false>
 static int launch_variant(const KArgs& k, int M, const LaunchCtx& ctx, const char* name, double flops,
                           double bytes, int nsplit = 1) {
+    const int groups = k.g1.x ? 2 : 1;
     constexpr bool b_lds = !BDIR;   // BDIR kernels stage only A: 18 KB -> 7 workgroups per CU instead of 4
     constexpr size_t ab = (size_t)(2 * BM * (BK + 4) + (b_lds ? 2 * (BK / 4) * BN * 4 : 0)) * sizeof(float);
     constexpr size_t cb = (size_t)BM * (BN + 4) * sizeof(float);
@@ -420,10 +433,10 @@ static int launch_variant(const KArgs& k, int M, const LaunchCtx& ctx, const cha
     kk.nbn = BN < 64 ? (k.Cout + BN - 1) / BN : k.Npad / BN;   // 32-wide tiles skip the all-padding half of a 64-padded weight panel
     const int nbm = (M + BM - 1) / BM;
     const int grid = nbm * kk.nbn;
-    ProfScope ps(ctx, name, flops, bytes);
+    ProfScope ps(ctx, name, flops * groups, bytes * groups);
     kk.cpc = k.cpc * 32 / BK;
     kk.nchunks = k.nchunks * 32 / BK;
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WGM, WGN, IS1X1, BK, DUAL, SPLITK, BDIR>), dim3(grid, nsplit), dim3(64 * WGM * WGN), smem,
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WGM, WGN, IS1X1, BK, DUAL, SPLITK, BDIR>), dim3(grid, nsplit, groups), dim3(64 * WGM * WGN), smem,
                        ctx.stream, kk);
     return (int)hipGetLastError();
 }
@@ -500,9 +513,11 @@ static void magic_u32(unsigned d, unsigned* mg, unsigned* sh) {
     *sh = L - 32;
 }
 
-static int launch_one(const ConvArgs& a, const LaunchCtx& ctx) {
+static int launch_one(const ConvArgs& a, const LaunchCtx& ctx, const ConvArgs* b = nullptr) {
     KArgs k;
     k.x = a.x; k.w = a.w; k.scale = a.scale; k.shift = a.shift; k.res = a.res; k.out = a.out;
+    k.g1.x = nullptr; k.g1.w = nullptr; k.g1.scale = nullptr; k.g1.shift = nullptr; k.g1.res = nullptr; k.g1.x2 = nullptr; k.g1.out = nullptr;
+    if (b) { k.g1.x = b->x; k.g1.w = b->w; k.g1.scale = b->scale; k.g1.shift = b->shift; k.g1.res = b->res; k.g1.x2 = b->x2; k.g1.out = b->out; }
     k.H = a.H; k.W = a.W; k.ldx = a.ldx;
     k.OW = a.OW; k.OHW = a.OH * a.OW; k.Cout = a.Cout; k.Npad = a.Npad; k.ldo = a.ldo;
     k.KH = a.KH; k.KW = a.KW; k.stride = a.stride; k.pad = a.pad;
@@ -525,7 +540,8 @@ static int launch_one(const ConvArgs& a, const LaunchCtx& ctx) {
     k.tprof = g_tprof;
 #endif
     k.vec_ok = (a.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0) &&
-               (!a.res || (reinterpret_cast<uintptr_t>(a.res) & 15) == 0);
+               (!a.res || (reinterpret_cast<uintptr_t>(a.res) & 15) == 0) &&
+               (!b || (((reinterpret_cast<uintptr_t>(b->out) & 15) == 0) && (!b->res || (reinterpret_cast<uintptr_t>(b->res) & 15) == 0)));
     const double Kd = (double)a.KH * a.KW * a.Cin + (dual ? a.Cin2 : 0);
     const double flops = 2.0 * (double)M * a.Cout * Kd;
     const double bytes = 4.0 * ((double)a.B * a.H * a.W * a.Cin + (dual ? (double)M * a.Cin2 : 0.0) +
@@ -584,6 +600,7 @@ int launch_conv_igemm_splitk(const ConvArgs& a, int S, float* ws, const float* o
     KArgs k;
     const int M = a.B * a.OH * a.OW;
     k.x = a.x; k.w = a.w; k.scale = ones; k.shift = zeros; k.res = nullptr; k.out = ws;
+    k.g1.x = nullptr; k.g1.w = nullptr; k.g1.scale = nullptr; k.g1.shift = nullptr; k.g1.res = nullptr; k.g1.x2 = nullptr; k.g1.out = nullptr;
     k.H = a.H; k.W = a.W; k.ldx = a.ldx;
     k.OW = a.OW; k.OHW = a.OH * a.OW; k.Cout = a.Npad; k.Npad = a.Npad; k.ldo = a.Npad;
     k.KH = 1; k.KW = 1; k.stride = 1; k.pad = 0;
@@ -617,8 +634,15 @@ int launch_conv_igemm_splitk(const ConvArgs& a, int S, float* ws, const float* o
     return rc;
 }
 
-int launch_conv_igemm(const ConvArgs& a, const LaunchCtx& ctx) {
+// b != nullptr: the same layer shape of a second network (its own x / w / scale / shift / res / x2 / out) in the same launch
+int launch_conv_igemm(const ConvArgs& a, const LaunchCtx& ctx, const ConvArgs* b) {
     if (a.Cin % 32 != 0 || a.Npad % 64 != 0 || a.ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(a.x) & 15))
+        return (int)hipErrorInvalidValue;
+    if (b && (b->B != a.B || b->H != a.H || b->W != a.W || b->Cin != a.Cin || b->ldx != a.ldx || b->OH != a.OH || b->OW != a.OW ||
+              b->Cout != a.Cout || b->Npad != a.Npad || b->ldo != a.ldo || b->KH != a.KH || b->KW != a.KW || b->stride != a.stride ||
+              b->pad != a.pad || b->relu != a.relu || (b->res != nullptr) != (a.res != nullptr) || (b->x2 != nullptr) != (a.x2 != nullptr) ||
+              b->H2 != a.H2 || b->W2 != a.W2 || b->ldx2 != a.ldx2 || b->Cin2 != a.Cin2 || b->stride2 != a.stride2 ||
+              (reinterpret_cast<uintptr_t>(b->x) & 15) || (b->x2 && (reinterpret_cast<uintptr_t>(b->x2) & 15))))
         return (int)hipErrorInvalidValue;
     if (a.x2 && (a.KH != 1 || a.KW != 1 || a.pad != 0 || a.Cin2 % 32 != 0 || a.ldx2 % 4 != 0 ||
                  (reinterpret_cast<uintptr_t>(a.x2) & 15)))
@@ -629,7 +653,8 @@ int launch_conv_igemm(const ConvArgs& a, const LaunchCtx& ctx) {
     const size_t limit = (size_t)1 << 31;
     if (img_bytes >= limit || ((size_t)a.KH * a.KW * a.Cin + a.Cin2) * a.Npad * 4 >= limit) return (int)hipErrorInvalidValue;
     const int max_b = (int)((limit - 1) / img_bytes);
-    if (a.B <= max_b) return launch_one(a, ctx);
+    if (a.B <= max_b) return launch_one(a, ctx, b);
+    if (b) return (int)hipErrorInvalidValue;     // (the caller falls back to two launches: batches this large fill the chip anyway)
     for (int b0 = 0; b0 < a.B; b0 += max_b) {
         ConvArgs s = a;
         s.B = (a.B - b0 < max_b) ? a.B - b0 : max_b;

@@ -56,6 +56,11 @@ struct WArgs {
     int nstage;            // Cin / 16
     unsigned mg_thw, sh_thw, mg_tw, sh_tw;
     int relu;
+    // grouped launch: the second half of the (persistent) grid runs the SAME layer shape of a second network on these tensors
+    // (the CamCalib and SPEC trunks as one launch per layer): twice the tile rows to deal out, half the rounding loss of the
+    // last persistent round
+    int groups;
+    struct { const float *x, *u, *scale, *shift, *res; float* out; } g1;
 #ifdef WINO_PROF
     unsigned long long* tprof;   // [prologue, loop, epilogue, count] summed s_memtime ticks (wave 0 of each workgroup)
 #endif
@@ -114,14 +119,23 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
 
     // co column = blockIdx % nbn: with nbn in {1, 2, 4, 8} an XCD (blockIdx % 8) keeps one column, so its
     // U slice stays in that XCD's L2
-    const int tile_n = blockIdx.x % p.nbn;
-    const int G = gridDim.x / p.nbn;               // workgroups per co column
-    int tile_m = blockIdx.x / p.nbn;
+    const int nwg = p.groups == 2 ? (int)(gridDim.x >> 1) : (int)gridDim.x;   // workgroups of one network
+    const bool grp = p.groups == 2 && (int)blockIdx.x >= nwg;                   // wave-uniform: scalar selects below
+    const int bid = grp ? (int)blockIdx.x - nwg : (int)blockIdx.x;
+    const float* const px = grp ? p.g1.x : p.x;
+    const float* const pu = grp ? p.g1.u : p.u;
+    const float* const pscale = grp ? p.g1.scale : p.scale;
+    const float* const pshift = grp ? p.g1.shift : p.shift;
+    const float* const pres = grp ? p.g1.res : p.res;
+    float* const pout = grp ? p.g1.out : p.out;
+    const int tile_n = bid % p.nbn;
+    const int G = nwg / p.nbn;                     // workgroups per co column (of one network)
+    int tile_m = bid / p.nbn;
 
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(RES ? p.res : p.x), 0, RES ? p.out_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(px), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pu), 0, p.u_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(pout, 0, p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(RES ? pres : px), 0, RES ? p.out_bytes : 0, 0x00020000);
 
     // ---- loader role: thread = (tile tl, channel pair c2l) ------------------------------------
     const int c2l = tid & 7, tl = tid >> 3;
@@ -222,7 +236,7 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
     const int co = nb * 32 + l31;
     // the two-wave layout has no register to spare across the K loop: it re-reads these two in every epilogue
     float sc = 0.f, sh = 0.f;
-    if (NF == 16) { sc = p.scale[co]; sh = p.shift[co]; }
+    if (NF == 16) { sc = pscale[co]; sh = pshift[co]; }
     // channels past Cout (last co column of a Cout % 64 == 32 layer: zero U block, see pack_wino_weights) are never stored:
     // 2^30 added to any offset of a <= 2^30-byte output (launch_conv_wino guarantees that for such layers) is out of
     // range, and added to kOOB it stays out of range (no wrap to a valid address)
@@ -362,7 +376,7 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
             asm volatile("" : "+v"(lane));
             const int l31 = lane & 31, hh = lane >> 5;
             const int co = nb * 32 + l31;
-            sc = p.scale[co]; sh = p.shift[co];
+            sc = pscale[co]; sh = pshift[co];
             const int coq = nb * 32 + (lane & 7) * 4;      // first of the four channels this lane stores
             const unsigned cq_b = coq < p.Cout ? (unsigned)(coq * 4) : 0x40000000u;
             char* const xw = smem + o_nxt + wave * 8192 + lane * 4;               // this wave's 8 KB: [r][a][lane]
@@ -506,7 +520,7 @@ void conv_wino_set_tprof(unsigned long long* p) { g_wino_tprof = p; }
 static int g_wino_persistent = 1;
 void conv_wino_set_persistent(int v) { g_wino_persistent = v; }
 
-static int wino_pick(const ConvArgs& a) {
+static int wino_pick(const ConvArgs& a, int groups = 1) {
     // ConvArgs::wino_variant (per handle): 0 auto, 16 / 8 = force the frequencies-per-wave variant
     if (a.wino_variant == 8 || a.res) return 8;    // the residual epilogue exists in the two-wave layout only
     if (a.wino_variant == 16 && a.Cout % 128 == 0) return 16;
@@ -518,7 +532,7 @@ static int wino_pick(const ConvArgs& a) {
     // 132 us); the 64-channel layout has twice the workgroups and half the serial MFMA chain.  The two layouts are
     // bit-identical (same k order, same output-transform association), so the choice never changes a result.
     const long tiles = (long)a.B * ((a.H + 1) / 2) * ((a.W + 1) / 2);
-    const long wgs16 = ((tiles + 31) / 32) * (a.Cout / 128);
+    const long wgs16 = ((tiles + 31) / 32) * (a.Cout / 128) * groups;
     return wgs16 < 128 ? 8 : 16;
 }
 
@@ -532,20 +546,24 @@ static int wino_launch_variant(WArgs k, int Cout, const LaunchCtx& ctx, double f
     k.nbm = (k.Mt + 31) / 32;
     // persistent grid: as many workgroups as the chip holds at once (256 CUs x 1 or 2), split evenly over the
     // co columns; a single 16-channel stage cannot pipeline across tiles (the loads run two stages ahead)
-    int G = (256 * (NF == 16 ? 1 : 2)) / k.nbn;
+    int G = (256 * (NF == 16 ? 1 : 2)) / k.nbn / k.groups;    // per network
 #ifdef WINO_PROF
-    if (const char* e = getenv("WINO_WG_PER_CU")) G = (256 * atoi(e)) / k.nbn;
+    if (const char* e = getenv("WINO_WG_PER_CU")) G = (256 * atoi(e)) / k.nbn / k.groups;
 #endif
     if (G < 1) G = 1;
     if (G > k.nbm || k.nstage < 2 || g_wino_persistent == 0) G = k.nbm;
-    ProfScope ps(ctx, NF == 16 ? "conv_wino_f32<32t x128,F(2x2,3x3)>" : RES ? "conv_wino_f32<32t x64,F(2x2,3x3),res>" : "conv_wino_f32<32t x64,F(2x2,3x3)>", flops, bytes);
-    hipLaunchKernelGGL((conv_wino_f32_kernel<NF, RES>), dim3(G * k.nbn), dim3(256), smem, ctx.stream, k);
+    ProfScope ps(ctx, NF == 16 ? "conv_wino_f32<32t x128,F(2x2,3x3)>" : RES ? "conv_wino_f32<32t x64,F(2x2,3x3),res>" : "conv_wino_f32<32t x64,F(2x2,3x3)>",
+                 flops * k.groups, bytes * k.groups);
+    hipLaunchKernelGGL((conv_wino_f32_kernel<NF, RES>), dim3(G * k.nbn * k.groups), dim3(256), smem, ctx.stream, k);
     return (int)hipGetLastError();
 }
 
-static int wino_launch_one(const ConvArgs& a, const LaunchCtx& ctx) {
+static int wino_launch_one(const ConvArgs& a, const LaunchCtx& ctx, const ConvArgs* b = nullptr) {
     WArgs k;
     k.x = a.x; k.u = a.w; k.scale = a.scale; k.shift = a.shift; k.out = a.out; k.res = a.res;
+    k.groups = b ? 2 : 1;
+    k.g1.x = b ? b->x : nullptr; k.g1.u = b ? b->w : nullptr; k.g1.scale = b ? b->scale : nullptr; k.g1.shift = b ? b->shift : nullptr;
+    k.g1.res = b ? b->res : nullptr; k.g1.out = b ? b->out : nullptr;
     k.H = a.H; k.W = a.W; k.ldx = a.ldx; k.Cout = a.Cout; k.ldo = a.ldo;
     k.TH = (a.H + 1) / 2; k.TW = (a.W + 1) / 2; k.THW = k.TH * k.TW;
     k.Mt = a.B * k.THW;
@@ -564,17 +582,22 @@ static int wino_launch_one(const ConvArgs& a, const LaunchCtx& ctx) {
     const double flops = 2.0 * M * a.Cout * 9.0 * a.Cin;   // algorithmic (direct-convolution) flops
     const double bytes = 4.0 * (M * a.Cin + M * a.Cout * (a.res ? 2.0 : 1.0) + 9.0 * a.Cin * a.Cout);
     if (a.res) return wino_launch_variant<8, true>(k, a.Cout, ctx, flops, bytes);
-    return wino_pick(a) == 16 ? wino_launch_variant<16>(k, a.Cout, ctx, flops, bytes)
+    return wino_pick(a, k.groups) == 16 ? wino_launch_variant<16>(k, a.Cout, ctx, flops, bytes)
                               : wino_launch_variant<8>(k, a.Cout, ctx, flops, bytes);
 }
 
-int launch_conv_wino(const ConvArgs& a, const LaunchCtx& ctx) {
+int launch_conv_wino(const ConvArgs& a, const LaunchCtx& ctx, const ConvArgs* b) {
     if (!conv_wino_supported(a) || (reinterpret_cast<uintptr_t>(a.x) & 7)) return (int)hipErrorInvalidValue;
+    if (b && (!conv_wino_supported(*b) || (reinterpret_cast<uintptr_t>(b->x) & 7) || b->B != a.B || b->H != a.H || b->W != a.W ||
+              b->Cin != a.Cin || b->ldx != a.ldx || b->Cout != a.Cout || b->ldo != a.ldo || b->relu != a.relu ||
+              (b->res != nullptr) != (a.res != nullptr) || b->wino_variant != a.wino_variant))
+        return (int)hipErrorInvalidValue;
     const size_t in_bytes = (size_t)a.H * a.W * a.ldx * 4, o_bytes = (size_t)a.H * a.W * a.ldo * 4;
     const size_t img_bytes = in_bytes > o_bytes ? in_bytes : o_bytes;   // both sides use 32-bit buffer offsets
     const size_t limit = (size_t)1 << (a.Cout % 64 ? 30 : 31);   // see co_b in the kernel
     if (img_bytes >= limit || (size_t)16 * a.Cin * a.Cout * 4 >= ((size_t)1 << 31)) return (int)hipErrorInvalidValue;
     const int max_b = (int)((limit - 1) / img_bytes);
+    if (b) return a.B <= max_b ? wino_launch_one(a, ctx, b) : (int)hipErrorInvalidValue;
     for (int b0 = 0; b0 < a.B; b0 += max_b) {
         ConvArgs s = a;
         s.B = (a.B - b0 < max_b) ? a.B - b0 : max_b;

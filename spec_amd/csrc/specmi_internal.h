@@ -95,7 +95,8 @@ struct ConvArgs {
     int wino_variant = 0;    // conv_wino frequencies per wave (16 / 8)
 };
 // Cin % 32 == 0, Npad % 64 == 0.  Returns hipError as int.
-int launch_conv_igemm(const ConvArgs& a, const LaunchCtx& ctx);
+// b != nullptr: the same layer shape of a SECOND network (own tensors) in the same launch (gridDim.z = 2)
+int launch_conv_igemm(const ConvArgs& a, const LaunchCtx& ctx, const ConvArgs* b = nullptr);
 // small-M 1x1 / FC GEMMs: K slices in parallel + deterministic reduction.  plan() returns the slice count (1 = don't);
 // ws holds S * M * Npad floats, ones / zeros at least Npad floats each.
 int conv_igemm_splitk_plan(const ConvArgs& a);
@@ -109,7 +110,7 @@ const char* conv_igemm_variant(const ConvArgs& a);
 // a.w must point at pack_wino_weights() output; Cin % 16 == 0, Cout % 64 == 0, no residual.
 bool conv_wino_supported(const ConvArgs& a);
 void pack_wino_weights(const float* w_oihw, int cout, int cin, std::vector<float>& out);
-int launch_conv_wino(const ConvArgs& a, const LaunchCtx& ctx);
+int launch_conv_wino(const ConvArgs& a, const LaunchCtx& ctx, const ConvArgs* b = nullptr);   // b: see launch_conv_igemm
 
 // ----------------------------------------------------------------------------------------
 // OPTIONAL: 1x1 / stride-1 convolution with fp32-class results on the bf16 matrix cores  (conv_bf16s.hip)
@@ -125,10 +126,12 @@ int launch_conv_bf16s(const ConvArgs& a, const void* wsplit, int terms, const La
 // ----------------------------------------------------------------------------------------
 // x NCHW (B,3,H,W); w = pack_stem_weights() output; out NHWC (B,OH,OW,64), BN+ReLU.
 void pack_stem_weights(const float* w_oihw, std::vector<float>& out);
+// pair / (x1, out1): the same op of a SECOND network in the same launch (see launch_conv_igemm)
+struct StemPair { const float *x, *w, *scale, *shift; float* out; };
 int launch_stem(const float* x, const float* w, const float* scale, const float* shift,
-                float* out, int B, int H, int W, int OH, int OW, int relu, const LaunchCtx& ctx);
+                float* out, int B, int H, int W, int OH, int OW, int relu, const LaunchCtx& ctx, const StemPair* pair = nullptr);
 int launch_maxpool3x3s2(const float* x, float* out, int B, int H, int W, int C, int OH, int OW,
-                        const LaunchCtx& ctx);
+                        const LaunchCtx& ctx, const float* x1 = nullptr, float* out1 = nullptr);
 // x (B,HW,C) -> out[b*ldo + c] = mean_hw
 int launch_avgpool(const float* x, float* out, int B, int HW, int C, int ldo, const LaunchCtx& ctx);
 

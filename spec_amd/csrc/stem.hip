@@ -39,6 +39,8 @@ struct StemArgs {
     unsigned x_bytes, out_bytes;
     int B, H, W, OH, OW, relu;
     int tiles_x, tiles_y, ntiles;
+    // grouped launch (gridDim.y = 2): blockIdx.y = 1 runs the stem of a second network on these tensors
+    struct { const float *x, *w, *scale, *shift; float* out; } g1;
 };
 
 __global__ void __launch_bounds__(256) stem_conv7x7_kernel(const StemArgs p) {
@@ -48,11 +50,17 @@ __global__ void __launch_bounds__(256) stem_conv7x7_kernel(const StemArgs p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+    const bool grp = blockIdx.y != 0;          // wave-uniform
+    const float* const px = grp ? p.g1.x : p.x;
+    const float* const pw = grp ? p.g1.w : p.w;
+    const float* const pscale = grp ? p.g1.scale : p.scale;
+    const float* const pshift = grp ? p.g1.shift : p.shift;
+    float* const pout = grp ? p.g1.out : p.out;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(px), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(pout, 0, p.out_bytes, 0x00020000);
 
     for (int i = tid; i < SM_WF / 4; i += 256)
-        reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(p.w)[i];
+        reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(pw)[i];
 
     // loader role: element idx = tid + 256 i of the patch -> (channel, row, col), fixed for the kernel's life
     int ld_rel[SM_NLD];    // element offset relative to the patch origin in the image
@@ -97,7 +105,7 @@ __global__ void __launch_bounds__(256) stem_conv7x7_kernel(const StemArgs p) {
     const char* a0 = reinterpret_cast<const char*>(patch) + ((2 * oyl) * SM_PW + 2 * oxl) * 4;
     const char* ab[3] = {a0 + hh * 4, a0 + hh * (SM_PW - 6) * 4, a0 + hh * (SM_CS - 6 * SM_PW - 6) * 4};
     const char* bb = reinterpret_cast<const char*>(wl) + (hh * 32 + l31) * 8;
-    const float sc0 = p.scale[l31], sc1 = p.scale[32 + l31], sh0 = p.shift[l31], sh1 = p.shift[32 + l31];
+    const float sc0 = pscale[l31], sc1 = pscale[32 + l31], sh0 = pshift[l31], sh1 = pshift[32 + l31];
     const unsigned o_lane = (unsigned)((4 * hh) * 256 + l31 * 4);
 
     int t = blockIdx.x;
@@ -154,7 +162,7 @@ void pack_stem_weights(const float* w, std::vector<float>& out) {
 }
 
 int launch_stem(const float* x, const float* w, const float* scale, const float* shift, float* out, int B, int H,
-                int W, int OH, int OW, int relu, const LaunchCtx& ctx) {
+                int W, int OH, int OW, int relu, const LaunchCtx& ctx, const StemPair* pair) {
     constexpr size_t smem = (SM_WF + SM_PATCH) * sizeof(float);
     static DevOnce once;
     if (int e = set_dyn_lds_once(once, reinterpret_cast<const void*>(&stem_conv7x7_kernel), (int)smem)) return e;
@@ -164,8 +172,10 @@ int launch_stem(const float* x, const float* w, const float* scale, const float*
     const size_t big = in_img > out_img ? in_img : out_img;
     if (big >= limit) return (int)hipErrorInvalidValue;
     const int max_b = (int)((limit - 1) / big);
-    const double flops = 2.0 * B * OH * OW * 64.0 * 147.0;
-    const double bytes = 4.0 * ((double)B * 3 * H * W + (double)B * OH * OW * 64 + 147.0 * 64);
+    if (pair && B > max_b) return (int)hipErrorInvalidValue;
+    const int groups = pair ? 2 : 1;
+    const double flops = 2.0 * B * OH * OW * 64.0 * 147.0 * groups;
+    const double bytes = 4.0 * ((double)B * 3 * H * W + (double)B * OH * OW * 64 + 147.0 * 64) * groups;
     ProfScope ps(ctx, "stem_conv7x7_f32", flops, bytes);
     for (int b0 = 0; b0 < B; b0 += max_b) {
         StemArgs a;
@@ -176,8 +186,11 @@ int launch_stem(const float* x, const float* w, const float* scale, const float*
         a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.relu = relu;
         a.tiles_x = (OW + SM_TW - 1) / SM_TW; a.tiles_y = (OH + SM_TH - 1) / SM_TH;
         a.ntiles = a.B * a.tiles_x * a.tiles_y;
-        const int grid = a.ntiles < 768 ? a.ntiles : 768;   // 3 workgroups per CU (47 KB LDS each), persistent
-        hipLaunchKernelGGL(stem_conv7x7_kernel, dim3(grid), dim3(256), smem, ctx.stream, a);
+        a.g1.x = pair ? pair->x : nullptr; a.g1.w = pair ? pair->w : nullptr; a.g1.scale = pair ? pair->scale : nullptr;
+        a.g1.shift = pair ? pair->shift : nullptr; a.g1.out = pair ? pair->out : nullptr;
+        const int slots = 768 / groups;                     // 3 workgroups per CU (47 KB LDS each), persistent
+        const int grid = a.ntiles < slots ? a.ntiles : slots;
+        hipLaunchKernelGGL(stem_conv7x7_kernel, dim3(grid, groups), dim3(256), smem, ctx.stream, a);
         const int rc = (int)hipGetLastError();
         if (rc) return rc;
     }
@@ -191,8 +204,11 @@ int launch_stem(const float* x, const float* w, const float* scale, const float*
 // is 32-bit (the launcher checks the sizes).  Workgroups are renumbered so that each XCD (workgroup id mod 8, the
 // dispatch order) owns one contiguous eighth of the output: the 3x3 / stride-2 windows of neighbouring output rows share
 // input rows, and that re-use then hits the XCD's own L2 instead of fetching the row again through another one.
-__global__ void __launch_bounds__(256) maxpool3x3s2_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                            int H, int W, int C4, int OH, int OW, unsigned total) {
+__global__ void __launch_bounds__(256) maxpool3x3s2_kernel(const float* __restrict__ x0, float* __restrict__ out0,
+                                                            int H, int W, int C4, int OH, int OW, unsigned total,
+                                                            const float* __restrict__ x1, float* __restrict__ out1) {
+    const float* const x = blockIdx.y ? x1 : x0;       // grouped launch: blockIdx.y = 1 pools a second network's map
+    float* const out = blockIdx.y ? out1 : out0;
     const unsigned nb = gridDim.x, per = nb >> 3;
     const unsigned blk = blockIdx.x < per * 8 ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : blockIdx.x;
     const unsigned i = blk * 256u + threadIdx.x;
@@ -219,14 +235,16 @@ __global__ void __launch_bounds__(256) maxpool3x3s2_kernel(const float* __restri
     reinterpret_cast<f32x4*>(out)[i] = m;
 }
 
-int launch_maxpool3x3s2(const float* x, float* out, int B, int H, int W, int C, int OH, int OW, const LaunchCtx& ctx) {
+int launch_maxpool3x3s2(const float* x, float* out, int B, int H, int W, int C, int OH, int OW, const LaunchCtx& ctx,
+                        const float* x1, float* out1) {
     if (C % 4) return (int)hipErrorInvalidValue;
     const long total = (long)B * OH * OW * (C / 4);
     if (total >= (1L << 31) - 256 || (long)H * W * (C / 4) >= (1L << 31)) return (int)hipErrorInvalidValue;   // 32-bit indices
-    const double bytes = 4.0 * ((double)B * H * W * C + (double)B * OH * OW * C);
+    const int groups = x1 ? 2 : 1;
+    const double bytes = 4.0 * ((double)B * H * W * C + (double)B * OH * OW * C) * groups;
     ProfScope ps(ctx, "maxpool3x3s2_f32", 0.0, bytes);
-    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx.stream, x, out, H, W, C / 4, OH, OW,
-                       (unsigned)total);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)((total + 255) / 256), groups), dim3(256), 0, ctx.stream, x, out, H, W, C / 4, OH, OW,
+                       (unsigned)total, x1, out1);
     return (int)hipGetLastError();
 }
 

@@ -154,6 +154,41 @@ class Engine:
         _lib.check(self.h, self.lib.specmi_trunk_forward(self.h, _ptr(x), B, H, W, _ptr(feat), self._stream()))
         return feat
 
+    def _feat_shape(self, H, W):
+        def o(n, k, s_, p):
+            return (n + 2 * p - k) // s_ + 1
+        fh, fw = o(H, 7, 2, 3), o(W, 7, 2, 3)
+        for _ in range(4):
+            fh, fw = o(fh, 3, 2, 1), o(fw, 3, 2, 1)
+        return fh, fw
+
+    def trunk_pair(self, other: 'Engine', images, other_images):
+        """The ResNet trunks of this engine and of ``other`` (same depth, same input shape) in lockstep, every layer of both
+        as one grouped launch (``specmi_trunk_forward_pair``) -> (features of self, features of other), NHWC."""
+        xa, xb = self._images(images), other._images(other_images)
+        if xa.shape != xb.shape:
+            raise ValueError(f'grouped trunk launches need equal input shapes, got {tuple(xa.shape)} and {tuple(xb.shape)}')
+        B, _, H, W = xa.shape
+        fh, fw = self._feat_shape(H, W)
+        fa = torch.empty(B, fh, fw, self.feat_channels, device=self.device, dtype=torch.float32)
+        fb = torch.empty(B, fh, fw, other.feat_channels, device=self.device, dtype=torch.float32)
+        if B == 0:
+            return fa, fb
+        _lib.check(self.h, self.lib.specmi_trunk_forward_pair(self.h, other.h, _ptr(xa), _ptr(xb), B, H, W, _ptr(fa), _ptr(fb),
+                                                              self._stream()))
+        return fa, fb
+
+    def camcalib_head(self, feat_nhwc):
+        """avg-pool + the three Linear chains of CameraRegressorNetwork.forward from a trunk feature map."""
+        f = _dev_f32(feat_nhwc, self.device)
+        B, fh, fw, _ = f.shape
+        out = torch.empty(3, B, self.nbins, device=self.device, dtype=torch.float32)
+        if B == 0:
+            return [out[0], out[1], out[2]]
+        _lib.check(self.h, self.lib.specmi_camcalib_head_forward(self.h, _ptr(f), B, fh, fw, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]),
+                                                                 self._stream()))
+        return [out[0], out[1], out[2]]
+
     def camcalib_forward(self, images):
         x = self._images(images)
         B, _, H, W = x.shape
