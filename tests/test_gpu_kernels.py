@@ -432,3 +432,4 @@ def test_conv_random_shapes(eng, case):
     ref = _conv_ref(x, w, sc, sh, stride, pad, res, relu)
     assert y.shape == ref.shape
     assert rel_err(y.numpy(), ref.numpy()) < 2e-5
+
