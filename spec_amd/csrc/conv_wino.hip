@@ -77,6 +77,14 @@ constexpr int WINO_F_STRIDE = 8 * WINO_C2_STRIDE;    // 8 channel pairs per stag
 constexpr int WINO_BUF = 16 * WINO_F_STRIDE;         // 34816 B per stage buffer
 constexpr int WINO_TAB = 32 * 16;                    // per tile: byte offsets of its 2x2 outputs (or out of range)
 
+// lane id recomputed where it is needed: volatile, so the compiler neither hoists it out of the tile loop nor keeps the first
+// copy alive (with no register to spare across the K loop either would end in scratch)
+__device__ __forceinline__ int wino_lane_now() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 __device__ __forceinline__ int wino_div(int n, int d, unsigned mg, unsigned sh) {
     return d == 1 ? n : (int)(__umulhi((unsigned)n, mg) >> sh);
 }
@@ -139,14 +147,16 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
 
     // ---- loader role: thread = (tile tl, channel pair c2l) ------------------------------------
     const int c2l = tid & 7, tl = tid >> 3;
-    unsigned a_voff[16];
+    // patch element (dy, dx) lives at a_row[dy] + a_col[dx]: 8 registers instead of 16 offsets.  An invalid row is 0xC0000000, an
+    // invalid column 0x80000000: any sum with an invalid part is >= 2^30 modulo 2^32, i.e. out of range for the <= 1 GiB input
+    // the launcher passes (the hardware range check returns 0.0 = the zero padding)
+    unsigned a_row[4], a_col[4];
     // decode tile row tm: the 16 patch offsets of this thread's tile and, for the epilogue, the byte
     // offsets of the tile's 2x2 outputs (table slot `slot`; out-of-range offset = no load / no store)
     auto decode_tile = [&](int tm, int slot) {
-        // everything here is derived from an opaque copy of tid: values the compiler could recognise as loop invariants
+        // everything here is derived from a freshly computed thread id: values the compiler could recognise as loop invariants
         // (tid >> 3, tid & 7, ...) would be hoisted out of the tile loop and, with no register to spare, spilled to scratch
-        int tid_ = tid;
-        asm volatile("" : "+v"(tid_));
+        const int tid_ = wave * 64 + wino_lane_now();
         const int c2l = tid_ & 7, tl = tid_ >> 3;
         const int t = tm * 32 + tl;
         const bool ok = t < p.Mt;
@@ -159,12 +169,10 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
         // per-thread base + wave-uniform (dy, dx) term: the uniform part stays in SGPRs
         const unsigned base = (unsigned)(((b * p.H + iy0) * p.W + ix0) * p.ldx * 4 + c2l * 8);
 #pragma unroll
-        for (int dy = 0; dy < 4; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 4; ++dx) {
-                const bool in = ok && (unsigned)(iy0 + dy) < (unsigned)p.H && (unsigned)(ix0 + dx) < (unsigned)p.W;
-                a_voff[dy * 4 + dx] = in ? base + (unsigned)((dy * p.W + dx) * p.ldx * 4) : kOOB;
-            }
+        for (int d = 0; d < 4; ++d) {
+            a_row[d] = (ok && (unsigned)(iy0 + d) < (unsigned)p.H) ? base + (unsigned)(d * p.W * p.ldx * 4) : 0xC0000000u;
+            a_col[d] = (unsigned)(ix0 + d) < (unsigned)p.W ? (unsigned)(d * p.ldx * 4) : 0x80000000u;
+        }
         if (c2l < 4) {
             const int oy = 2 * ty + (c2l >> 1), ox = 2 * tx + (c2l & 1);
             const bool in = ok && oy < p.H && ox < p.W;
@@ -174,14 +182,18 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
     };
     f32x2 raw[16];
     auto load_raw1 = [&](int st, int q) {
-        raw[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrs, a_voff[q], (unsigned)(st * 64), 0));
+        raw[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrs, a_row[q >> 2] + a_col[q & 3], (unsigned)(st * 64), 0));
     };
     // V = B^T d B on both channels of the pair at once (packed fp32 adds), cut into 12 pieces so that the
     // K loop can slot them under the MFMAs: pieces 0-3 = row pass of patch column j (the four raw values
     // of the column die, four T values are born: T and raw share registers), pieces 4-11 = column pass
     // of half a T row + the LDS writes of its two frequencies.
     f32x2 T[16];
-    char* const vw_base = smem + c2l * WINO_C2_STRIDE + tl * 8;
+    // this thread's slot in a stage buffer, recomputed where it is used (see decode_tile: no register to keep it in)
+    auto vw_base_now = [&]() {
+        const int t_ = wave * 64 + wino_lane_now();
+        return smem + (t_ & 7) * WINO_C2_STRIDE + (t_ >> 3) * 8;
+    };
     auto transform_piece = [&](int s, char* dst) {
         if (s < 4) {
             const int j = s;
@@ -236,11 +248,10 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
     const int co = nb * 32 + l31;
     // the two-wave layout has no register to spare across the K loop: it re-reads these two in every epilogue
     float sc = 0.f, sh = 0.f;
-    if (NF == 16) { sc = pscale[co]; sh = pshift[co]; }
     // channels past Cout (last co column of a Cout % 64 == 32 layer: zero U block, see pack_wino_weights) are never stored:
     // 2^30 added to any offset of a <= 2^30-byte output (launch_conv_wino guarantees that for such layers) is out of
     // range, and added to kOOB it stays out of range (no wrap to a valid address)
-    const unsigned co_b = co < p.Cout ? (unsigned)(co * 4) : 0x40000000u;
+    unsigned co_b = 0;
     auto emit = [&](float v, unsigned off) {   // one-wave layout
         v = fmaf(v, sc, sh);
         if (p.relu) v = fmaxf(v, 0.f);
@@ -256,8 +267,11 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
     for (int d = 0; d < UD; ++d)
 #pragma unroll
         for (int f = 0; f < NF / 2; ++f) load_u(d, d, f);   // nmu >= 4 > UD
+    {
+        char* const vw0 = vw_base_now();
 #pragma unroll
-    for (int s = 0; s < 12; ++s) transform_piece(s, vw_base);
+        for (int s = 0; s < 12; ++s) transform_piece(s, vw0);
+    }
 #pragma unroll
     for (int q = 0; q < 16; ++q) load_raw1(S > 1 ? 1 : 0, q);
     __syncthreads();
@@ -298,7 +312,7 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
             if (S > 1 && st == (S > 2 ? S - 2 : 0)) decode_tile(nm, (it + 1) & 1);
             const char* vr_cur = vr_base + o_cur;
             const char* vr_nxt = vr_base + o_nxt;
-            char* vw_nxt = vw_base + o_nxt;
+            char* vw_nxt = vw_base_now() + o_nxt;
             // stage after next; past the tile's end it is the next tile's stage 0 / 1 (S == 1 never has a next tile)
             const int st2 = st + 2 < S ? st + 2 : (st + 2 - S < S ? st + 2 - S : S - 1);
 #pragma unroll
@@ -346,8 +360,10 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
         const long long t_e0 = __builtin_amdgcn_s_memtime();
 #endif
         if (NF == 16) {
-            int lane_ = tid & 63;                           // opaque copy, see decode_tile
-            asm volatile("" : "+v"(lane_));
+            const int lane_ = wino_lane_now();              // see decode_tile
+            const int co_ = nb * 32 + (lane_ & 31);
+            sc = pscale[co_]; sh = pshift[co_];
+            co_b = co_ < p.Cout ? (unsigned)(co_ * 4) : 0x40000000u;
             const char* tab = smem + TAB0 + (it & 1) * WINO_TAB + (lane_ >> 5) * 64;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -372,8 +388,7 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
             // output column 0 and needs S[a][2] from its partner; the fh = 1 wave finishes column 1 and
             // needs S[a][1].  32 floats per lane cross through the stage buffer that the last stage just
             // released (the other one already holds the next tile's first stage).
-            int lane = tid & 63;                            // opaque copy, see decode_tile
-            asm volatile("" : "+v"(lane));
+            const int lane = wino_lane_now();               // see decode_tile
             const int l31 = lane & 31, hh = lane >> 5;
             const int co = nb * 32 + l31;
             sc = pscale[co]; sh = pshift[co];
@@ -594,7 +609,7 @@ int launch_conv_wino(const ConvArgs& a, const LaunchCtx& ctx, const ConvArgs* b)
         return (int)hipErrorInvalidValue;
     const size_t in_bytes = (size_t)a.H * a.W * a.ldx * 4, o_bytes = (size_t)a.H * a.W * a.ldo * 4;
     const size_t img_bytes = in_bytes > o_bytes ? in_bytes : o_bytes;   // both sides use 32-bit buffer offsets
-    const size_t limit = (size_t)1 << (a.Cout % 64 ? 30 : 31);   // see co_b in the kernel
+    const size_t limit = (size_t)1 << 30;   // see a_row / a_col and co_b in the kernel
     if (img_bytes >= limit || (size_t)16 * a.Cin * a.Cout * 4 >= ((size_t)1 << 31)) return (int)hipErrorInvalidValue;
     const int max_b = (int)((limit - 1) / img_bytes);
     if (b) return a.B <= max_b ? wino_launch_one(a, ctx, b) : (int)hipErrorInvalidValue;
