@@ -114,7 +114,17 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
     constexpr bool EARLYB = true;
 #endif
     constexpr int SPS = 16 / NF;                    // loader pieces per MFMA step
-    constexpr int UD = NF == 16 ? 1 : 2;            // U prefetch distance in micro-chunks (NF MFMA pairs each)
+#ifndef WINO_UD
+#define WINO_UD 2
+#endif
+#ifndef WINO_AD
+#define WINO_AD 8
+#endif
+    // U prefetch distance in micro-chunks (NF MFMA pairs each) and depth of the A-fragment ring in steps.  Measured (round 3,
+    // profiles/r03_n_wino_prefetch_distance.txt): UD = 4 (a whole stage ahead, registers taken from a 4-deep A ring: 251 VGPRs,
+    // no spills) and UD = 2 run at the same speed with one and with two workgroups per CU - the stall the patch loads cause is
+    // the wait for the patch data itself (3 micro-chunks after issue), not U fragments queued behind them
+    constexpr int UD = NF == 16 ? 1 : WINO_UD;
     constexpr int TAB0 = (TRIPLE ? 3 : 2) * WINO_BUF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef WINO_PROF
@@ -275,9 +285,10 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
 #pragma unroll
     for (int q = 0; q < 16; ++q) load_raw1(S > 1 ? 1 : 0, q);
     __syncthreads();
-    f32x2 af[NF];
+    constexpr int AD = NF == 16 ? 16 : WINO_AD;     // A fragments (LDS, ~150 cycles away) are fetched AD steps = AD x 128 cycles ahead
+    f32x2 af[AD];
 #pragma unroll
-    for (int f = 0; f < NF; ++f) af[f] = read_a(vr_base, 0, f);
+    for (int f = 0; f < AD; ++f) af[f] = read_a(vr_base, 0, f);
 
     // ---- K loop, hand-scheduled -------------------------------------------------------------
     // A wave issues in order and an fp32 MFMA holds the matrix pipe for 64 cycles, so whatever sits
@@ -321,13 +332,17 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
                 const int mu1 = mu + UD < nmu ? mu + UD : mu + UD - nmu;
 #pragma unroll
                 for (int fl = 0; fl < NF; ++fl) {
-                    acc[fl] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fl][0], bq[u % UD][fl >> 1][(fl & 1) * 2 + 0], acc[fl], 0, 0, 0);
-                    acc[fl] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fl][1], bq[u % UD][fl >> 1][(fl & 1) * 2 + 1], acc[fl], 0, 0, 0);
+                    acc[fl] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fl % AD][0], bq[u % UD][fl >> 1][(fl & 1) * 2 + 0], acc[fl], 0, 0, 0);
+                    acc[fl] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[fl % AD][1], bq[u % UD][fl >> 1][(fl & 1) * 2 + 1], acc[fl], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (!WABL(1) && (fl & 1)) load_u(u % UD, mu1, fl >> 1);
                     if (!WABL(8)) {
-                    if (u < 3) af[fl] = read_a(vr_cur, u + 1, fl);   // rolling: consumed NF steps from now
-                    else if (EARLYB) af[fl] = read_a(vr_nxt, 0, fl);
+                    {   // rolling: the fragment AD steps ahead goes into the register pair just consumed
+                        const int fn = fl + AD;
+                        if (fn < NF) af[fl % AD] = read_a(vr_cur, u, fn);
+                        else if (u < 3) af[fl % AD] = read_a(vr_cur, u + 1, fn - NF);
+                        else if (EARLYB) af[fl % AD] = read_a(vr_nxt, 0, fn - NF);
+                    }
                     }
                     if (u == 1 && !WABL(4)) transform_step(fl, vw_nxt);
                     if (u == 2 && !WABL(2)) {
@@ -347,7 +362,7 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
                 if (!WABL(16)) __syncthreads();
 #endif
 #pragma unroll
-                for (int fl = 0; fl < NF; ++fl) af[fl] = read_a(vr_nxt, 0, fl);
+                for (int fl = 0; fl < AD; ++fl) af[fl] = read_a(vr_nxt, 0, fl);
             }
             const int t = o_cur; o_cur = o_nxt; o_nxt = TRIPLE ? o_nn : t; o_nn = t;
         }
