@@ -14,7 +14,7 @@ dev = torch.device('cuda:0')
 cc, hm, _, _ = bench.build_models(dev)
 from spec_amd.pipeline import SpecPipeline
 from spec_amd import cam_utils
-pipe = SpecPipeline(cc, hm, overlap=False)
+pipe = SpecPipeline(cc, hm, overlap=False, grouped=(os.environ.get('GROUPED', '1') == '1'))
 x, sc, ce, iw, ih = bench.make_inputs(args.batch, dev, 1)
 for _ in range(3):
     pipe(x, sc, ce, iw, ih)

@@ -433,3 +433,24 @@ def test_conv_random_shapes(eng, case):
     assert y.shape == ref.shape
     assert rel_err(y.numpy(), ref.numpy()) < 2e-5
 
+
+
+def test_smpl_batch_variants_bit_identical(hmr_engine):
+    """An image's vertices, joints and projection must not depend on the batch it travels in (partially filled 8-image skinning
+    tiles: batches 1, 2, 3, 5, 8 against 17)."""
+    Bmax = 17
+    R, betas, cam = _rand_pose(Bmax, 123)
+    g = torch.Generator().manual_seed(9)
+    camR = _rand_pose(1, 98)[0][0, :1].expand(Bmax, 3, 3).contiguous()
+    K = torch.zeros(Bmax, 3, 3)
+    K[:, 0, 0] = K[:, 1, 1] = 400 + 300 * torch.rand(Bmax, generator=g)
+    K[:, 0, 2], K[:, 1, 2] = 320.0, 240.0
+    scale = 0.8 + 0.5 * torch.rand(Bmax, generator=g)
+    center = torch.stack([250 + 100 * torch.rand(Bmax, generator=g), 200 + 80 * torch.rand(Bmax, generator=g)], 1)
+    iw, ih = torch.full((Bmax,), 640.0), torch.full((Bmax,), 480.0)
+    args = [R, betas, cam, camR, K, scale, center, iw, ih]
+    full = {k: v.clone() for k, v in hmr_engine.smpl(*[a.to(DEV) for a in args]).items()}
+    for B in (1, 2, 3, 5, 8):
+        out = hmr_engine.smpl(*[a[:B].contiguous().to(DEV) for a in args])
+        for k in ('smpl_vertices', 'smpl_joints3d', 'smpl_joints2d', 'pred_cam_t'):
+            assert torch.equal(out[k], full[k][:B]), (B, k)
