@@ -745,8 +745,10 @@ def main():
                               'max_rel_err_vs_fp32_path': {k: float(f'{v:.3e}') for k, v in errs.items()},
                               'worst_rel_err_vs_fp32_path': float(f'{max(errs.values()):.3e}'),
                               'fixtures_within_1e-4': 'tests/test_gpu_bf16split.py (3 HMR fixtures + CamCalib fixture, both term counts)',
-                              'layers': 'the 32 1x1 convolutions of each ResNet-50 trunk (conv1 x16, conv3 x16 incl. the 4 with the downsample branch folded in); 3x3, '
-                                        'stem and FC layers stay on the exact fp32 kernels',
+                              'layers': ('every 1x1 and 3x3 convolution of both ResNet-50 trunks (48 per trunk)' if terms == 3 else
+                                         'the 32 1x1 convolutions and the 3 stride-2 3x3 convolutions of each ResNet-50 trunk (the 13 stride-1 3x3 '
+                                         'layers stay on the fp32 Winograd kernel, which is faster than six bf16 products)') +
+                                        '; stem and FC layers stay on the exact fp32 kernels',
                               'launch': mode2})
                 del cc2, hm2, pipe2, run2, out2
         except Exception as e:

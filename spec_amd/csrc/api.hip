@@ -158,9 +158,9 @@ int commit_conv(specmi_handle* h, const std::string& prefix, ConvW& c) {
     }
     // optional split-bf16 path (conv_bf16s.hip): the weights of the plain 1x1 / stride-1 layers as three bf16 pieces
     c.wsplit = nullptr;
-    if (opt_i(h, "conv_precision", 0) != 0 && c.k == 1 && c.stride == 1 && c.pad == 0 && cin % 16 == 0 && cout % 4 == 0) {
+    if (opt_i(h, "conv_precision", 0) != 0 && (c.k == 1 || c.k == 3) && cin % 16 == 0 && cout % 4 == 0) {
         std::vector<unsigned short> pieces;
-        pack_bf16_split_weights(wsrc, cout, cin, c.Npad, pieces);
+        pack_bf16_split_weights_oihw(wsrc, cout, cin, c.k, c.k, c.Npad, pieces);
         if ((rc = dev_upload(h, pieces.data(), pieces.size() * 2, &c.wsplit, h->param_allocs))) return rc;
     }
     return SPECMI_OK;
@@ -567,7 +567,11 @@ static OpLaunch prepare_op(specmi_handle* h, const TrunkOp& op, const float* ima
     }
     if (const void* wsplit = op.fused ? op.fused->f_wsplit : c.wsplit) {
         const int terms = opt_i(h, "conv_precision", 0);
-        if ((terms == 3 || terms == 6) && conv_bf16s_supported(a)) {
+        // 3x3 layers: the bf16 implicit GEMM spends 9 taps x terms / 16 of an fp32 MFMA cycle per MAC, the fp32 Winograd kernel
+        // 16 / 36: with three terms the bf16 path wins on every 3x3 layer, with six only where Winograd does not apply (stride 2)
+        const bool wino_ok = c.wino && opt_i(h, "winograd", 1) && conv_wino_supported(a);
+        const bool take = c.k == 1 || terms == 3 || !wino_ok || opt_i(h, "conv_precision_3x3", 0);
+        if ((terms == 3 || terms == 6) && take && conv_bf16s_supported(a)) {
             L.family = 2; L.wsplit = wsplit; L.terms = terms;
             return L;
         }
@@ -1189,11 +1193,11 @@ int specmi_conv2d(specmi_handle* h, const float* x, int B, int H, int W, int Cin
     const bool wino = !stem && opt_i(h, "winograd", 1) && KH == 3 && stride == 1 && pad == 1 && Cin % 16 == 0 &&
                       (Cout % 64 == 0 || (Cout % 32 == 0 && Cout > 64));
     const int terms = opt_i(h, "conv_precision", 0);
-    const bool split = !stem && (terms == 3 || terms == 6) && KH == 1 && stride == 1 && pad == 0 && Cin % 16 == 0 && Cout % 4 == 0;
+    const bool split = !stem && (terms == 3 || terms == 6) && Cin % 16 == 0 && Cout % 4 == 0;
     std::vector<unsigned short> pieces;
     void* dsplit = nullptr;
     if (split) {
-        pack_bf16_split_weights(w_host, Cout, Cin, Npad, pieces);
+        pack_bf16_split_weights_oihw(w_host, Cout, Cin, KH, KW, Npad, pieces);
         if ((rc = dev_upload(h, pieces.data(), pieces.size() * 2, &dsplit, tmp))) { free_pool(tmp); return rc; }
     }
     if (stem) pack_stem_weights(w_host, packed);

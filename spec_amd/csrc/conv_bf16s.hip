@@ -50,6 +50,8 @@ struct SArgs {
     const float* x2;
     unsigned x2_bytes;
     int nsteps1, ldx2, H2, W2, stride2, OW, OHW;
+    // TAPS: a KH x KW convolution as an implicit GEMM, K ordered (ky, kx, ci): stage s = (filter tap s / cpt, channels 16 (s % cpt)..)
+    int H, W, KH, KW, stride, pad, cpt;
 };
 
 constexpr unsigned kOOB16 = 0x80000000u;
@@ -63,9 +65,10 @@ __device__ __forceinline__ unsigned split_pair(float& a, float& b) {
     return hb;
 }
 
-template <int BN, int TERMS, bool DUAL = false>
+template <int BN, int TERMS, bool DUAL = false, bool TAPS = false>
 __global__ void __launch_bounds__(256) conv1x1_bf16s_kernel(const SArgs p) {
     static_assert(BN == 128 || BN == 64, "");
+    static_assert(!(DUAL && TAPS), "");
     static_assert(TERMS == 6 || TERMS == 3, "");
     constexpr int BM = 128;
     constexpr int NP = TERMS == 6 ? 3 : 2;        // pieces per operand
@@ -91,10 +94,22 @@ __global__ void __launch_bounds__(256) conv1x1_bf16s_kernel(const SArgs p) {
     // ---- loader coordinates ------------------------------------------------------------------------------------------
     const int a_kq = tid & 3, a_r = tid >> 2;                       // quad of the row's 16 k, row (and row + 64)
     unsigned a_voff[2], a_voff2[DUAL ? 2 : 1];
+    unsigned a_mask[TAPS ? 2 : 1];      // TAPS: bit t = filter tap t of this row lies inside the image
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + a_r + 64 * i;
         a_voff[i] = m < p.M ? (unsigned)(m * p.ldx * 4 + a_kq * 16) : kOOB16;
+        if (TAPS) {   // the row's output pixel -> offset of its tap (0, 0) (may wrap for padded rows: only used on valid taps)
+            const int mm = m < p.M ? m : 0;
+            const int b_ = mm / p.OHW, rem = mm - b_ * p.OHW, oy = rem / p.OW, ox = rem - oy * p.OW;
+            const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+            a_voff[i] = (unsigned)(((b_ * p.H + iy0) * p.W + ix0) * p.ldx * 4 + a_kq * 16);
+            unsigned colbits = 0, mk = 0;
+            for (int kx = 0; kx < p.KW; ++kx) colbits |= ((unsigned)(ix0 + kx) < (unsigned)p.W ? 1u : 0u) << kx;
+            for (int ky = 0; ky < p.KH; ++ky)
+                if ((unsigned)(iy0 + ky) < (unsigned)p.H) mk |= colbits << (ky * p.KW);
+            a_mask[i] = m < p.M ? mk : 0u;
+        }
         if (DUAL) {
             const int mm = m < p.M ? m : 0;
             int pix2 = mm;
@@ -114,10 +129,20 @@ __global__ void __launch_bounds__(256) conv1x1_bf16s_kernel(const SArgs p) {
     u32x4 rb[NP];
     auto load_stage = [&](int s) {
         const bool second = DUAL && s >= p.nsteps1;       // wave-uniform: descriptor picked with scalar selects
+        if (TAPS) {
+            const int tap = s / p.cpt, c0 = s - tap * p.cpt;      // scalar
+            const int ky = tap / p.KW, kx = tap - ky * p.KW;
+            const unsigned tap_bytes = (unsigned)((ky * p.W + kx) * p.ldx * 4);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    xrs, ((a_mask[TAPS ? i : 0] >> tap) & 1u) ? a_voff[i] + tap_bytes : kOOB16, (unsigned)(c0 * 64), 0));
+        } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(second ? x2rs : xrs, second ? a_voff2[DUAL ? i : 0] : a_voff[i],
                                                                                     (unsigned)((second ? s - p.nsteps1 : s) * 64), 0));
+        }
 #pragma unroll
         for (int pc = 0; pc < NP; ++pc)
             rb[pc] = __builtin_amdgcn_raw_buffer_load_b128(wrs, b_voff, (unsigned)(pc * p.w_piece_bytes + s * 2 * p.Npad * 16), 0);
@@ -270,6 +295,18 @@ void pack_bf16_split_weights(const float* w, int cout, int cin, int Npad, std::v
         }
 }
 
+// OIHW (cout, cin, kh, kw) -> the same pieces with K ordered (ky, kx, ci), as the TAPS kernel walks it
+void pack_bf16_split_weights_oihw(const float* w, int cout, int cin, int kh, int kw, int Npad, std::vector<unsigned short>& out) {
+    const int K = cin * kh * kw;
+    std::vector<float> oi((size_t)cout * K);
+    for (int n = 0; n < cout; ++n)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int ky = 0; ky < kh; ++ky)
+                for (int kx = 0; kx < kw; ++kx)
+                    oi[(size_t)n * K + (ky * kw + kx) * cin + ci] = w[(((size_t)n * cin + ci) * kh + ky) * kw + kx];
+    pack_bf16_split_weights(oi.data(), cout, K, Npad, out);
+}
+
 bool conv_bf16s_supported(const ConvArgs& a) {
     const size_t xb = (size_t)a.B * a.H * a.W * a.ldx * 4;
     if (a.x2) {
@@ -278,27 +315,32 @@ bool conv_bf16s_supported(const ConvArgs& a) {
             (a.H - 1) * a.stride2 >= a.H2 || (a.W - 1) * a.stride2 >= a.W2)
             return false;
     }
-    return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.Cin % 16 == 0 && a.Npad % 64 == 0 &&
-           a.Cout % 4 == 0 && a.ldx % 4 == 0 && a.ldo % 4 == 0 && a.OH == a.H && a.OW == a.W && xb < ((size_t)1 << 31) &&
-           (size_t)(a.Cin + a.Cin2) * a.Npad * 2 < ((size_t)1 << 30) && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 &&
+    const bool plain = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
+    if (!plain && (a.x2 || a.KH != a.KW || a.KH > 5 || a.stride < 1 || a.pad < 0 || a.OH != (a.H + 2 * a.pad - a.KH) / a.stride + 1 ||
+                   a.OW != (a.W + 2 * a.pad - a.KW) / a.stride + 1))
+        return false;
+    return a.Cin % 16 == 0 && a.Npad % 64 == 0 &&
+           a.Cout % 4 == 0 && a.ldx % 4 == 0 && a.ldo % 4 == 0 && (!plain || (a.OH == a.H && a.OW == a.W)) && xb < ((size_t)1 << 31) &&
+           ((size_t)a.KH * a.KW * a.Cin + a.Cin2) * a.Npad * 2 < ((size_t)1 << 30) && (size_t)a.B * a.OH * a.OW * a.ldo * 4 < ((size_t)1 << 33) && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 &&
            (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 && (!a.res || (reinterpret_cast<uintptr_t>(a.res) & 15) == 0);
 }
 
-template <int BN, int TERMS, bool DUAL = false>
+template <int BN, int TERMS, bool DUAL = false, bool TAPS = false>
 static int bf16s_launch(SArgs k, const LaunchCtx& ctx, double flops, double bytes) {
     constexpr int NP = TERMS == 6 ? 3 : 2;
     constexpr int stage = NP * (2 * 128 * 16 + 2 * BN * 16);
     constexpr int cs = 64 * (BN + 4) * 4;
     constexpr int smem = 2 * stage > cs ? 2 * stage : cs;
     static DevOnce once;
-    if (int e = set_dyn_lds_once(once, reinterpret_cast<const void*>(&conv1x1_bf16s_kernel<BN, TERMS, DUAL>), smem)) return e;
+    if (int e = set_dyn_lds_once(once, reinterpret_cast<const void*>(&conv1x1_bf16s_kernel<BN, TERMS, DUAL, TAPS>), smem)) return e;
     k.nbn = BN == 64 ? (k.Cout + 63) / 64 : k.Npad / 128;
     const int grid = ((k.M + 127) / 128) * k.nbn;
-    ProfScope ps(ctx, DUAL ? (TERMS == 6 ? "conv1x1_bf16split<128xN,6 terms,2src>" : "conv1x1_bf16split<128xN,3 terms,2src>")
+    ProfScope ps(ctx, TAPS ? (TERMS == 6 ? "conv_kxk_bf16split<128xN,6 terms>" : "conv_kxk_bf16split<128xN,3 terms>")
+                      : DUAL ? (TERMS == 6 ? "conv1x1_bf16split<128xN,6 terms,2src>" : "conv1x1_bf16split<128xN,3 terms,2src>")
                       : TERMS == 6 ? (BN == 128 ? "conv1x1_bf16split<128x128,6 terms>" : "conv1x1_bf16split<128x64,6 terms>")
                                    : (BN == 128 ? "conv1x1_bf16split<128x128,3 terms>" : "conv1x1_bf16split<128x64,3 terms>"),
                  flops, bytes);
-    hipLaunchKernelGGL((conv1x1_bf16s_kernel<BN, TERMS, DUAL>), dim3(grid), dim3(256), smem, ctx.stream, k);
+    hipLaunchKernelGGL((conv1x1_bf16s_kernel<BN, TERMS, DUAL, TAPS>), dim3(grid), dim3(256), smem, ctx.stream, k);
     return (int)hipGetLastError();
 }
 
@@ -307,17 +349,23 @@ int launch_conv_bf16s(const ConvArgs& a, const void* wsplit, int terms, const La
     if (!conv_bf16s_supported(a) || !wsplit || (terms != 3 && terms != 6)) return (int)hipErrorInvalidValue;
     SArgs k;
     k.x = a.x; k.w = wsplit; k.scale = a.scale; k.shift = a.shift; k.res = a.res; k.out = a.out;
-    k.M = a.B * a.H * a.W;
-    k.x_bytes = (unsigned)((size_t)k.M * a.ldx * 4);
-    const int K = a.Cin + (a.x2 ? a.Cin2 : 0);
+    const bool taps = !(a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0);
+    k.M = a.B * a.OH * a.OW;
+    k.x_bytes = (unsigned)((size_t)a.B * a.H * a.W * a.ldx * 4);
+    const int K = a.KH * a.KW * a.Cin + (a.x2 ? a.Cin2 : 0);
+    k.H = a.H; k.W = a.W; k.KH = a.KH; k.KW = a.KW; k.stride = a.stride; k.pad = a.pad; k.cpt = a.Cin / 16;
     k.w_piece_bytes = (unsigned)((size_t)K * a.Npad * 2);
     k.ldx = a.ldx; k.Cout = a.Cout; k.Npad = a.Npad; k.ldo = a.ldo; k.nbn = 0; k.nsteps = K / 16; k.relu = a.relu;
-    k.x2 = a.x2; k.nsteps1 = a.Cin / 16; k.ldx2 = a.ldx2; k.H2 = a.H2; k.W2 = a.W2; k.stride2 = a.stride2; k.OW = a.W; k.OHW = a.H * a.W;
+    k.x2 = a.x2; k.nsteps1 = a.Cin / 16; k.ldx2 = a.ldx2; k.H2 = a.H2; k.W2 = a.W2; k.stride2 = a.stride2; k.OW = a.OW; k.OHW = a.OH * a.OW;
     k.x2_bytes = a.x2 ? (unsigned)((size_t)a.B * a.H2 * a.W2 * a.ldx2 * 4) : 0;
     const double flops = 2.0 * k.M * (double)a.Cout * K;
-    const double bytes = 4.0 * ((double)k.M * a.Cin + (a.x2 ? (double)a.B * a.H2 * a.W2 * a.Cin2 : 0.0) +
+    const double bytes = 4.0 * ((double)a.B * a.H * a.W * a.Cin + (a.x2 ? (double)a.B * a.H2 * a.W2 * a.Cin2 : 0.0) +
                                 (double)k.M * a.Cout * (a.res ? 2.0 : 1.0)) + 6.0 * K * (double)a.Cout;
     const bool wide = a.Npad % 128 == 0;
+    if (taps) {
+        if (terms == 6) return wide ? bf16s_launch<128, 6, false, true>(k, ctx, flops, bytes) : bf16s_launch<64, 6, false, true>(k, ctx, flops, bytes);
+        return wide ? bf16s_launch<128, 3, false, true>(k, ctx, flops, bytes) : bf16s_launch<64, 3, false, true>(k, ctx, flops, bytes);
+    }
     if (a.x2) {
         if (terms == 6) return wide ? bf16s_launch<128, 6, true>(k, ctx, flops, bytes) : bf16s_launch<64, 6, true>(k, ctx, flops, bytes);
         return wide ? bf16s_launch<128, 3, true>(k, ctx, flops, bytes) : bf16s_launch<64, 3, true>(k, ctx, flops, bytes);

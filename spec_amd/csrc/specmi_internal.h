@@ -117,6 +117,7 @@ int launch_conv_wino(const ConvArgs& a, const LaunchCtx& ctx, const ConvArgs* b 
 // ----------------------------------------------------------------------------------------
 // w_oi (cout, cin) fp32 -> bf16 pieces w0 + w1 + w2 packed [piece][cin/8][Npad][8]
 void pack_bf16_split_weights(const float* w_oi, int cout, int cin, int Npad, std::vector<unsigned short>& out);
+void pack_bf16_split_weights_oihw(const float* w_oihw, int cout, int cin, int kh, int kw, int Npad, std::vector<unsigned short>& out);
 bool conv_bf16s_supported(const ConvArgs& a);
 // terms = 6 (fp32-class) or 3 (~1e-5); a.w is ignored, wsplit = the packed pieces on the device
 int launch_conv_bf16s(const ConvArgs& a, const void* wsplit, int terms, const LaunchCtx& ctx);

@@ -86,7 +86,9 @@ def test_hmr_fixtures_through_split_bf16(tag, uc, ucf, terms):
        t(g['bbox_center']).to(DEV), t(g['img_w']).to(DEV), t(g['img_h']).to(DEV)) if uc else hm(x)
     n_split = sum(e['launches'] for e in eng.profile_read() if 'bf16split' in e['kernel'])
     eng.profile(False)
-    assert n_split == 32, n_split          # 16 x conv1 + 16 x conv3 (4 of them with the downsample branch folded in as a second source)
+    # 16 x conv1 + 16 x conv3 (4 of them with the downsample branch folded in) + the 3x3 layers: with three terms all 16, with six
+    # only the 3 stride-2 ones (the fp32 Winograd kernel is faster than six bf16 products on the stride-1 layers)
+    assert n_split == (48 if terms == 3 else 35), n_split
     for k in out:
         assert rel_err(out[k].cpu().numpy(), g['out_' + k]) < 1e-4, (k, rel_err(out[k].cpu().numpy(), g['out_' + k]))
 
@@ -130,4 +132,37 @@ def test_trunk_features_split_vs_exact(terms, tol):
     assert sum(e['launches'] for e in ents if '2src' in e['kernel'] and 'bf16split' in e['kernel']) == 4, ents
     assert not any('conv_igemm' in e['kernel'] and '2src' in e['kernel'] for e in ents), ents
     err = float((got.double() - ref.double()).abs().max() / ref.double().abs().max())
+    assert err < tol, err
+
+
+# (Cin, Cout, k, stride, H, W, B, residual): 3x3 layers (stride 1 and 2, ragged sizes) through the bf16 implicit GEMM
+KXK_SHAPES = [(64, 64, 3, 1, 56, 56, 1, False), (128, 128, 3, 2, 56, 56, 1, False), (256, 256, 3, 1, 14, 14, 3, False),
+              (512, 512, 3, 2, 14, 14, 3, False), (32, 96, 3, 1, 9, 7, 2, True), (64, 128, 3, 2, 11, 13, 2, False),
+              (64, 64, 5, 1, 8, 8, 2, False)]
+
+
+@pytest.mark.parametrize('terms,tol', [(6, 3e-6), (3, 1e-4)])
+@pytest.mark.parametrize('shape', KXK_SHAPES, ids=lambda s: 'c%d_%d_k%d_s%d_%dx%d_b%d_r%d' % s)
+def test_conv_kxk_split_bf16_vs_fp64(eng, shape, terms, tol):
+    import torch.nn.functional as F
+    cin, cout, k, stride, H, W, B, use_res = shape
+    pad = k // 2
+    g = torch.Generator().manual_seed(cin + 7 * cout + H + k)
+    x = torch.relu(torch.randn(B, H, W, cin, generator=g)) * 1.3
+    w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    sc = torch.rand(cout, generator=g) + 0.5
+    sh = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), stride=stride, padding=pad).permute(0, 2, 3, 1) * sc.double() + sh.double()
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if res is not None:
+        ref = ref + res.double()
+    ref = torch.relu(ref)
+    eng.set_option('conv_precision', terms)
+    eng.profile(True)
+    y = eng.conv2d(x.to(DEV), w.numpy(), sc.numpy(), sh.numpy(), stride, pad, residual=None if res is None else res.to(DEV), relu=True).cpu()
+    kernels = [e['kernel'] for e in eng.profile_read()]
+    eng.profile(False)
+    eng.set_option('conv_precision', 0)
+    assert any('kxk_bf16split' in kk and f'{terms} terms' in kk for kk in kernels), kernels
+    err = float((y.double() - ref).abs().max() / ref.abs().max())
     assert err < tol, err
