@@ -293,16 +293,20 @@ def test_single_rank_rccl_path():
 
 
 @pytest.mark.timeout(900)
-def test_bench_dist_path_single_rank():
-    """bench.py --gpus 1 --dist: the multi-GPU bench flow (self-launch, RCCL, AsyncGather, comm block) on one rank."""
+@pytest.mark.parametrize('payload', ['full', 'joints'])
+def test_bench_dist_path_single_rank(payload):
+    """bench.py --gpus 1 --dist: the multi-GPU bench flow (self-launch, RCCL, AsyncGather with in-place / joints-only sends,
+    persistent receive buffers, comm block with the with / without-collective step times) on one rank."""
     import json
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--dist', '--steps', '3', '--warmup', '1',
-                        '--batch', '32', '--no-cpu-baseline', '--no-profile', '--no-c2', '--sustained-seconds', '0.2'],
+                        '--batch', '32', '--no-cpu-baseline', '--no-profile', '--no-c2', '--sustained-seconds', '0.2', '--gather', payload],
                        capture_output=True, text=True, timeout=850, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-4000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
-    assert line['n_gpus'] == 1 and line['comm']['backend'] == 'nccl' and line['comm']['world_size'] == 1
-    assert line['comm']['record_bytes_per_image'] == 85176 and line['value'] > 0
+    comm = line['comm']
+    assert line['n_gpus'] == 1 and comm['backend'] == 'nccl' and comm['world_size'] == 1 and comm['payload'] == payload
+    assert comm['record_bytes_per_image'] == 85176 and comm['sent_bytes_per_image'] == (85176 if payload == 'full' else 2496)
+    assert comm['ms_per_step_without_gather'] > 0 and 0.3 < comm['overlap_efficiency'] < 1.5 and line['value'] > 0
     assert line['config']['launch'] == 'hipGraph replay'
 
 
