@@ -103,7 +103,12 @@ __device__ __forceinline__ int wino_div(int n, int d, unsigned mg, unsigned sh) 
 // before the ReLU).  Two-wave layout only: its 32 residual values per lane are fetched between the two halves of the output
 // transform, when the 128 accumulator registers have just died, and before the first store (loads and stores retire in
 // order on one counter: a load issued after a store would wait for it).
-template <int NF, bool RES = false>
+// WIDE (Cin % 32 == 0): the patch loads are 16 bytes per lane and fetch a PAIR of stages at once - half the vector-memory
+// instructions per stage.  A stage's 16 channels are then not 16 consecutive ones: of every 16-byte quad of a 128-byte group of
+// 32 channels, the even stage takes the first 8 bytes and the odd stage the second 8 (channel 32 m + 4 q + 2 (st & 1) + e is
+// local channel 2 q + e of stage 2 m + (st & 1)); pack_wino_weights() orders U's k axis the same way.  Everything after the
+// load (thread = (tile, local channel pair), V layout in LDS, MFMA order) is unchanged.
+template <int NF, bool RES = false, bool WIDE = false>
 __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(const WArgs p) {
     static_assert(!(RES && NF == 16), "the residual epilogue exists for the two-wave layout only");
     constexpr int NWN = NF == 16 ? 4 : 2;          // co blocks (of 32) per workgroup
@@ -177,7 +182,7 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
         const int tx = rem - ty * p.TW;
         const int iy0 = 2 * ty - 1, ix0 = 2 * tx - 1;
         // per-thread base + wave-uniform (dy, dx) term: the uniform part stays in SGPRs
-        const unsigned base = (unsigned)(((b * p.H + iy0) * p.W + ix0) * p.ldx * 4 + c2l * 8);
+        const unsigned base = (unsigned)(((b * p.H + iy0) * p.W + ix0) * p.ldx * 4 + c2l * (WIDE ? 16 : 8));
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             a_row[d] = (ok && (unsigned)(iy0 + d) < (unsigned)p.H) ? base + (unsigned)(d * p.W * p.ldx * 4) : 0xC0000000u;
@@ -190,9 +195,17 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
                 in ? (unsigned)(((b * p.H + oy) * p.W + ox) * p.ldo * 4) : kOOB;
         }
     };
-    f32x2 raw[16];
-    auto load_raw1 = [&](int st, int q) {
-        raw[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrs, a_row[q >> 2] + a_col[q & 3], (unsigned)(st * 64), 0));
+    f32x2 raw[WIDE ? 1 : 16];
+    f32x4 raw4[WIDE ? 16 : 1];                      // WIDE: .xy = the even stage of the pair, .zw = the odd one
+    auto load_raw1 = [&](int st, int q) {           // WIDE: st is the even stage of the pair
+        if (WIDE) raw4[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, a_row[q >> 2] + a_col[q & 3], (unsigned)((st >> 1) * 128), 0));
+        else raw[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrs, a_row[q >> 2] + a_col[q & 3], (unsigned)(st * 64), 0));
+    };
+    auto rawv = [&](int q, int half) {
+        if (!WIDE) return raw[q];
+        f32x2 r;
+        r[0] = raw4[q][2 * half]; r[1] = raw4[q][2 * half + 1];
+        return r;
     };
     // V = B^T d B on both channels of the pair at once (packed fp32 adds), cut into 12 pieces so that the
     // K loop can slot them under the MFMAs: pieces 0-3 = row pass of patch column j (the four raw values
@@ -204,10 +217,10 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
         const int t_ = wave * 64 + wino_lane_now();
         return smem + (t_ & 7) * WINO_C2_STRIDE + (t_ >> 3) * 8;
     };
-    auto transform_piece = [&](int s, char* dst) {
+    auto transform_piece = [&](int s, char* dst, int half) {
         if (s < 4) {
             const int j = s;
-            const f32x2 r0 = raw[0 + j], r1 = raw[4 + j], r2 = raw[8 + j], r3 = raw[12 + j];
+            const f32x2 r0 = rawv(0 + j, half), r1 = rawv(4 + j, half), r2 = rawv(8 + j, half), r3 = rawv(12 + j, half);
             T[0 + j] = r0 - r2;
             T[4 + j] = r1 + r2;
             T[8 + j] = r2 - r1;
@@ -225,14 +238,14 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
     };
     // pieces of step fl of the u == 1 micro-chunk (NF steps): NF == 16: piece fl (12 used); NF == 8: one row
     // piece per step for steps 0-3, two column pieces per step for steps 4-7
-    auto transform_step = [&](int fl, char* dst) {
+    auto transform_step = [&](int fl, char* dst, int half) {
         if (NF == 16) {
-            if (fl < 12) transform_piece(fl, dst);
+            if (fl < 12) transform_piece(fl, dst, half);
         } else if (fl < 4) {
-            transform_piece(fl, dst);
+            transform_piece(fl, dst, half);
         } else {
-            transform_piece(4 + 2 * (fl - 4), dst);
-            transform_piece(5 + 2 * (fl - 4), dst);
+            transform_piece(4 + 2 * (fl - 4), dst, half);
+            transform_piece(5 + 2 * (fl - 4), dst, half);
         }
     };
 
@@ -280,12 +293,14 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
     {
         char* const vw0 = vw_base_now();
 #pragma unroll
-        for (int s = 0; s < 12; ++s) transform_piece(s, vw0);
+        for (int s = 0; s < 12; ++s) transform_piece(s, vw0, 0);
     }
+    if (!WIDE) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) load_raw1(S > 1 ? 1 : 0, q);
+        for (int q = 0; q < 16; ++q) load_raw1(S > 1 ? 1 : 0, q);
+    }
     __syncthreads();
-    constexpr int AD = NF == 16 ? 16 : WINO_AD;     // A fragments (LDS, ~150 cycles away) are fetched AD steps = AD x 128 cycles ahead
+    constexpr int AD = NF == 16 ? 16 : (WIDE ? 4 : WINO_AD);     // A fragments (LDS, ~150 cycles away) are fetched AD steps = AD x 128 cycles ahead
     f32x2 af[AD];
 #pragma unroll
     for (int f = 0; f < AD; ++f) af[f] = read_a(vr_base, 0, f);
@@ -319,7 +334,9 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
 
-        for (int st = 0; st < S; ++st) {
+        // par = st & 1 as a literal (WIDE runs the stages in pairs: which half of raw4 a transform reads, and whether the
+        // stage loads, must be known at compile time)
+        auto stage_body = [&](const int st, const int par) {
             if (S > 1 && st == (S > 2 ? S - 2 : 0)) decode_tile(nm, (it + 1) & 1);
             const char* vr_cur = vr_base + o_cur;
             const char* vr_nxt = vr_base + o_nxt;
@@ -344,8 +361,8 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
                         else if (EARLYB) af[fl % AD] = read_a(vr_nxt, 0, fn - NF);
                     }
                     }
-                    if (u == 1 && !WABL(4)) transform_step(fl, vw_nxt);
-                    if (u == 2 && !WABL(2)) {
+                    if (u == 1 && !WABL(4)) transform_step(fl, vw_nxt, WIDE ? 1 - par : 0);
+                    if (u == 2 && !WABL(2) && (!WIDE || par == 0)) {
 #pragma unroll
                         for (int k = 0; k < SPS; ++k) load_raw1(st2, fl * SPS + k);
                     }
@@ -365,6 +382,14 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
                 for (int fl = 0; fl < AD; ++fl) af[fl] = read_a(vr_nxt, 0, fl);
             }
             const int t = o_cur; o_cur = o_nxt; o_nxt = TRIPLE ? o_nn : t; o_nn = t;
+        };
+        if (WIDE) {
+            for (int st = 0; st < S; st += 2) {
+                stage_body(st, 0);
+                stage_body(st + 1, 1);
+            }
+        } else {
+            for (int st = 0; st < S; ++st) stage_body(st, 0);
         }
 
         // ---- epilogue of this tile: lane-local output transform, BN scale/shift, ReLU, store ------
@@ -522,6 +547,12 @@ bool conv_wino_supported(const ConvArgs& a) {
 }
 
 // OIHW (cout, cin, 3, 3) -> U = G g G^T packed [cout/32][cin/4][f/2][lane = h*32+n][(f&1)*2 + jj], f = 4i+j, ci = 4*mu + 2*h + jj
+#ifndef WINO_NO_WIDE
+static inline bool wino_wide_cin(int cin) { return cin % 32 == 0; }
+#else
+static inline bool wino_wide_cin(int) { return false; }
+#endif
+
 void pack_wino_weights(const float* w, int cout, int cin, std::vector<float>& out) {
     static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     out.assign((size_t)16 * cin * cout, 0.f);
@@ -532,7 +563,10 @@ void pack_wino_weights(const float* w, int cout, int cin, std::vector<float>& ou
             double Gg[4][3];
             for (int i = 0; i < 4; ++i)
                 for (int b = 0; b < 3; ++b) Gg[i][b] = G[i][0] * g[0 * 3 + b] + G[i][1] * g[1 * 3 + b] + G[i][2] * g[2 * 3 + b];
-            const int nb = co / 32, n = co % 32, mu = ci / 4, h = (ci % 4) / 2, jj = ci % 2;
+            // k position of input channel ci: plain order, or (Cin % 32 == 0, the WIDE kernels) the stage-pair order
+            const int r = ci % 32;
+            const int kp = wino_wide_cin(cin) ? (ci / 32) * 32 + ((r % 4) / 2) * 16 + (r / 4) * 2 + (r % 2) : ci;
+            const int nb = co / 32, n = co % 32, mu = kp / 4, h = (kp % 4) / 2, jj = kp % 2;
             for (int i = 0; i < 4; ++i)
                 for (int j = 0; j < 4; ++j) {
                     const double uij = Gg[i][0] * G[j][0] + Gg[i][1] * G[j][1] + Gg[i][2] * G[j][2];
@@ -566,12 +600,12 @@ static int wino_pick(const ConvArgs& a, int groups = 1) {
     return wgs16 < 128 ? 8 : 16;
 }
 
-template <int NF, bool RES = false>
+template <int NF, bool RES = false, bool WIDE = false>
 static int wino_launch_variant(WArgs k, int Cout, const LaunchCtx& ctx, double flops, double bytes) {
     constexpr int NT = NF == 16 ? 128 : 64;
     constexpr int smem = (NF == 16 ? 3 : 2) * WINO_BUF + 2 * WINO_TAB;
     static DevOnce once;
-    if (int e = set_dyn_lds_once(once, reinterpret_cast<const void*>(&conv_wino_f32_kernel<NF, RES>), smem)) return e;
+    if (int e = set_dyn_lds_once(once, reinterpret_cast<const void*>(&conv_wino_f32_kernel<NF, RES, WIDE>), smem)) return e;
     k.nbn = (Cout + NT - 1) / NT;
     k.nbm = (k.Mt + 31) / 32;
     // persistent grid: as many workgroups as the chip holds at once (256 CUs x 1 or 2), split evenly over the
@@ -584,7 +618,7 @@ static int wino_launch_variant(WArgs k, int Cout, const LaunchCtx& ctx, double f
     if (G > k.nbm || k.nstage < 2 || g_wino_persistent == 0) G = k.nbm;
     ProfScope ps(ctx, NF == 16 ? "conv_wino_f32<32t x128,F(2x2,3x3)>" : RES ? "conv_wino_f32<32t x64,F(2x2,3x3),res>" : "conv_wino_f32<32t x64,F(2x2,3x3)>",
                  flops * k.groups, bytes * k.groups);
-    hipLaunchKernelGGL((conv_wino_f32_kernel<NF, RES>), dim3(G * k.nbn * k.groups), dim3(256), smem, ctx.stream, k);
+    hipLaunchKernelGGL((conv_wino_f32_kernel<NF, RES, WIDE>), dim3(G * k.nbn * k.groups), dim3(256), smem, ctx.stream, k);
     return (int)hipGetLastError();
 }
 
@@ -611,14 +645,21 @@ static int wino_launch_one(const ConvArgs& a, const LaunchCtx& ctx, const ConvAr
     const double M = (double)a.B * a.H * a.W;
     const double flops = 2.0 * M * a.Cout * 9.0 * a.Cin;   // algorithmic (direct-convolution) flops
     const double bytes = 4.0 * (M * a.Cin + M * a.Cout * (a.res ? 2.0 : 1.0) + 9.0 * a.Cin * a.Cout);
+    if (wino_wide_cin(a.Cin)) {   // the layout pack_wino_weights() chose for this Cin
+        if (a.res) return wino_launch_variant<8, true, true>(k, a.Cout, ctx, flops, bytes);
+        return wino_pick(a, k.groups) == 16 ? wino_launch_variant<16, false, true>(k, a.Cout, ctx, flops, bytes)
+                                            : wino_launch_variant<8, false, true>(k, a.Cout, ctx, flops, bytes);
+    }
     if (a.res) return wino_launch_variant<8, true>(k, a.Cout, ctx, flops, bytes);
     return wino_pick(a, k.groups) == 16 ? wino_launch_variant<16>(k, a.Cout, ctx, flops, bytes)
                               : wino_launch_variant<8>(k, a.Cout, ctx, flops, bytes);
 }
 
 int launch_conv_wino(const ConvArgs& a, const LaunchCtx& ctx, const ConvArgs* b) {
-    if (!conv_wino_supported(a) || (reinterpret_cast<uintptr_t>(a.x) & 7)) return (int)hipErrorInvalidValue;
-    if (b && (!conv_wino_supported(*b) || (reinterpret_cast<uintptr_t>(b->x) & 7) || b->B != a.B || b->H != a.H || b->W != a.W ||
+    // 8-byte patch loads; 16-byte ones (pixel rows 16-byte aligned too) in the WIDE layout
+    const uintptr_t amask = wino_wide_cin(a.Cin) ? 15 : 7;
+    if (!conv_wino_supported(a) || (reinterpret_cast<uintptr_t>(a.x) & amask) || (wino_wide_cin(a.Cin) && a.ldx % 4)) return (int)hipErrorInvalidValue;
+    if (b && (!conv_wino_supported(*b) || (reinterpret_cast<uintptr_t>(b->x) & amask) || b->B != a.B || b->H != a.H || b->W != a.W ||
               b->Cin != a.Cin || b->ldx != a.ldx || b->Cout != a.Cout || b->ldo != a.ldo || b->relu != a.relu ||
               (b->res != nullptr) != (a.res != nullptr) || b->wino_variant != a.wino_variant))
         return (int)hipErrorInvalidValue;

@@ -80,7 +80,16 @@ def test_hmr_hrnet_end_to_end_vs_oracle(backbone, use_cam, ucf):
     assert set(out.keys()) == set(ref.keys())
     for k in ref:
         err = rel_err(out[k].cpu().numpy(), ref[k].numpy())
-        assert err < 1e-4, (k, err)
+        tol = 1e-4
+        if k == 'pred_cam_t':
+            # tz = 2 f / (res * s): in the max-norm an error of pred_cam's scale s comes back multiplied by max|pred_cam| / min|s|.
+            # The random-weight HRNets produce an s close to 0 for one of these images (condition number > 100), where two fp32
+            # evaluations that agree to 1e-6 in pred_cam differ by 1e-4 in tz; pred_cam itself is held to 5e-6 for it
+            pc = ref['pred_cam'].numpy()
+            cond = float(np.abs(pc).max() / np.abs(pc[:, 0]).min())
+            assert rel_err(out['pred_cam'].cpu().numpy(), pc) < 5e-6
+            tol = max(tol, 5e-6 * cond)
+        assert err < tol, (k, err)
     # collapsed regressor (default) vs the nine-GEMM loop on the 480 / 720-feature head
     eng = hm.engine(torch.device(DEV))
     eng.set_option('head_collapse', 0)

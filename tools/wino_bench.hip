@@ -47,6 +47,7 @@ int main(int argc, char** argv) {
         {"odd      3x3  16->128  7x9 ", 16, 128, 7, 9, 0, 3},
         {"odd2     3x3  32->256  5x3 ", 32, 256, 5, 3, 0, 5},
         {"odd3     3x3  48->64   9x7 ", 48, 64, 9, 7, 0, 4},
+        {"odd4     3x3  96->64   6x5 ", 96, 64, 6, 5, 0, 70},
         {"l1.conv2 3x3  64->64  56   ", 64, 64, 56, 56, 3, 0},
         {"l2.conv2 3x3 128->128 28   ", 128, 128, 28, 28, 3, 0},
         {"l3.conv2 3x3 256->256 14   ", 256, 256, 14, 14, 5, 0},
