@@ -225,7 +225,8 @@ int specmi_smpl_native(specmi_handle* h, const float* pose, int pose_is_axis_ang
 /* A single fused conv+BN(+residual)(+ReLU) layer, y = act(conv(x)*scale + shift [+ res]).
  * x (B,H,W,Cin) NHWC device; w (Cout,Cin,KH,KW) OIHW HOST; scale/shift (Cout) HOST;
  * residual/out (B,OH,OW,Cout) NHWC device.  Cin%32==0 unless (Cin==3,KH==7: stem path,
- * x is then NCHW).  Used by the per-layer parity tests. */
+ * x is then NCHW).  Device pointers 16-byte aligned (the kernels move 16 bytes per lane; a misaligned x is refused by the
+ * Winograd path with an error, never read wrongly).  Used by the per-layer parity tests. */
 int specmi_conv2d(specmi_handle* h, const float* x, int B, int H, int W, int Cin,
                   const float* w_oihw_host, const float* scale_host, const float* shift_host,
                   int Cout, int KH, int KW, int stride, int pad, const float* residual,

@@ -194,6 +194,30 @@ def test_conv_winograd_kernel_is_used(eng):
     eng.profile(False)
 
 
+def test_conv_winograd_input_alignment(eng):
+    """The Winograd kernel fetches 16 bytes per lane when Cin % 32 == 0 (a pair of 16-channel stages per load) and 8 bytes
+    otherwise: an input that is only 8-byte aligned is refused for the former (error, never a wrong read) and served for the latter."""
+    from spec_amd._lib import SpecmiError
+    g = torch.Generator().manual_seed(77)
+    for cin, ok in ((48, True), (64, False)):
+        B, H, W, cout = 2, 9, 7, 64
+        buf = torch.randn(B * H * W * cin + 2, generator=g).to(DEV)
+        x = buf[2:].view(B, H, W, cin)                       # contiguous, 8 bytes past a 256-byte aligned allocation
+        assert x.data_ptr() % 16 == 8 and x.is_contiguous()
+        w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+        sc, sh = np.ones(cout, np.float32), np.zeros(cout, np.float32)
+        if ok:
+            y = eng.conv2d(x, w.numpy(), sc, sh, 1, 1, relu=False).cpu()
+            ref = _conv_ref(x.cpu(), w, torch.from_numpy(sc), torch.from_numpy(sh), 1, 1, None, False)
+            assert rel_err(y.numpy(), ref.numpy()) < 2e-5
+        else:
+            with pytest.raises(SpecmiError):
+                eng.conv2d(x, w.numpy(), sc, sh, 1, 1, relu=False)
+            y = eng.conv2d(x.clone(), w.numpy(), sc, sh, 1, 1, relu=False).cpu()     # the handle stays usable
+            ref = _conv_ref(x.cpu(), w, torch.from_numpy(sc), torch.from_numpy(sh), 1, 1, None, False)
+            assert rel_err(y.numpy(), ref.numpy()) < 2e-5
+
+
 def test_conv_identity_asymmetric(eng):
     """A = I style check with an asymmetric weight: catches row/col transposes of the MFMA C layout."""
     cin = cout = 64
