@@ -703,6 +703,7 @@ def main():
                    'h2d_GBps_sustained_while_overlapped': round(fs.h2d_bytes / el / 1e9, 2),
                    'h2d_GBps_upload_alone': round(slab_bytes / up_ms / 1e6, 1), 'upload_alone_ms': round(up_ms, 3),
                    'overlap': round(B * args.steps / el / value, 4),
+                   'copy_stream_probe': getattr(fs, 'copy_probe', None),
                    'flow': 'pinned host slab -> copy stream -> 2 alternating device slabs -> specmi_crop_normalize_batch into '
                            'the static inputs of the step -> ' + launch_mode,
                    'note': 'overlap = crops/s of this line / value (inputs resident in HBM); CamCalib sees the same crops as in '

@@ -24,9 +24,10 @@ from .preprocess import crop_detections_batch
 
 class FrameStream:
     def __init__(self, step: Callable, device, frame_hw, frames_per_step: int, crops_per_step: int, crop_size: int = 224,
-                 slots: int = 2, scale: float = 1.0):
+                 slots: int = 2, scale: float = 1.0, copy_stream: Optional[torch.cuda.Stream] = None):
         """``step(images, bbox_scale, bbox_center, img_w, img_h)`` is a ``SpecPipeline`` or ``GraphedPipeline``.  When it
-        has ``static_in`` (a captured graph) the crops are written directly into those buffers."""
+        has ``static_in`` (a captured graph) the crops are written directly into those buffers.  ``copy_stream``: the
+        stream of the uploads; by default one is chosen by measurement (``_pick_copy_stream``)."""
         self.step, self.device = step, torch.device(device)
         self.H, self.W = int(frame_hw[0]), int(frame_hw[1])
         self.F, self.N, self.S, self.scale = int(frames_per_step), int(crops_per_step), int(crop_size), float(scale)
@@ -48,13 +49,60 @@ class FrameStream:
             self.img_h = torch.empty(self.N, dtype=torch.float32, device=dev)
         self.img_w.fill_(float(self.W))
         self.img_h.fill_(float(self.H))
-        # default priority: measured on one box, a high-priority copy stream LOWERS the overlap (0.91-0.92 of the HBM-resident rate
-        # against 0.97-0.98 at normal priority): its work then pre-empts the step's kernels instead of slipping in beside them
-        self.copy_stream = torch.cuda.Stream(device=dev)
+        if static is None:                 # benign inputs for the probe step below (a captured step holds its capture inputs)
+            self.x.zero_(); self.sc.fill_(1.0); self.ce.zero_()
+        self.copy_stream = copy_stream if copy_stream is not None else self._pick_copy_stream()
         self.ready = [torch.cuda.Event() for _ in range(slots)]
         self.free = [None] * slots        # recorded after the crop launch that read the slot
         self.turn = 0
         self.h2d_bytes = 0
+
+    def _pick_copy_stream(self, tries: int = 6):
+        """A copy stream whose uploads really run beside the step.  HIP multiplexes a process's streams onto a few hardware
+        queues, and a queue hands its packets out in order: a copy stream that shares the queue of the stream the step is
+        launched on gets its upload dispatched behind the step's ~120 kernels - measured 33.5 instead of 29.6 ms per step with
+        1080p slabs, and WHICH queue a new stream lands on depends on how many streams the process has created before
+        (``scripts/e2e_probe.py``: the same code gives 0.98 or 0.86 of the HBM-resident rate).  So measure instead of hoping:
+        start the step, put an 8 MB upload on a candidate stream and time it; the first candidate that finishes well inside
+        the step is taken (at most ``tries`` steps at construction).  Default priority: a high-priority stream measured lower
+        (0.91-0.92 against 0.97-0.98)."""
+        import time
+        dev = self.device
+        args = (self.x, self.sc, self.ce, self.img_w, self.img_h)
+        with torch.no_grad():
+            self.step(*args)                                   # warm (plans, workspace)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            self.step(*args)
+            torch.cuda.synchronize(dev)
+            t_step = time.perf_counter() - t0
+            if t_step < 2e-3:                                  # nothing to hide an upload behind
+                return torch.cuda.Stream(device=dev)
+            src = torch.empty(8 << 20, dtype=torch.uint8).pin_memory()
+            dst = torch.empty(8 << 20, dtype=torch.uint8, device=dev)
+            best, seen = None, []
+            for _ in range(tries):
+                st = torch.cuda.Stream(device=dev)
+                with torch.cuda.stream(st):
+                    dst.copy_(src, non_blocking=True)           # first use of the stream outside the measurement
+                torch.cuda.synchronize(dev)
+                self.step(*args)                               # asynchronous: the kernels are now queued / running
+                t0 = time.perf_counter()
+                ev = torch.cuda.Event()
+                with torch.cuda.stream(st):
+                    dst.copy_(src, non_blocking=True)
+                    ev.record(st)
+                ev.synchronize()
+                dt = time.perf_counter() - t0
+                torch.cuda.synchronize(dev)
+                seen.append(round(dt * 1e3, 3))
+                if best is None or dt < best[0]:
+                    best = (dt, st)
+                if dt < 0.25 * t_step:
+                    break
+            self.copy_probe = {'step_ms': round(t_step * 1e3, 3), 'upload_8MB_beside_step_ms': round(best[0] * 1e3, 3),
+                               'candidates_ms': seen}
+            return best[1]
 
     def host_buffers(self):
         """Pinned host staging for one step: (frames (F,H,W,3) uint8, boxes (N,4) fp32, frame_index (N,) int32)."""
