@@ -58,51 +58,15 @@ class FrameStream:
         self.h2d_bytes = 0
 
     def _pick_copy_stream(self, tries: int = 6):
-        """A copy stream whose uploads really run beside the step.  HIP multiplexes a process's streams onto a few hardware
-        queues, and a queue hands its packets out in order: a copy stream that shares the queue of the stream the step is
-        launched on gets its upload dispatched behind the step's ~120 kernels - measured 33.5 instead of 29.6 ms per step with
-        1080p slabs, and WHICH queue a new stream lands on depends on how many streams the process has created before
-        (``scripts/e2e_probe.py``: the same code gives 0.98 or 0.86 of the HBM-resident rate).  So measure instead of hoping:
-        start the step, put an 8 MB upload on a candidate stream and time it; the first candidate that finishes well inside
-        the step is taken (at most ``tries`` steps at construction).  Default priority: a high-priority stream measured lower
-        (0.91-0.92 against 0.97-0.98)."""
-        import time
-        dev = self.device
+        """A copy stream whose uploads really run beside the step (``spec_amd/streams.py``): a stream that shares the hardware
+        queue of the stream the step is launched on gets its upload dispatched behind the step's ~120 kernels - measured 33.5
+        instead of 29.6 ms per step with 1080p slabs (``scripts/e2e_probe.py``: the same code gave 0.98 or 0.86 of the
+        HBM-resident rate depending on how many streams the process had created before).  At most ``tries`` steps at
+        construction.  Default priority: a high-priority stream measured lower (0.91-0.92 against 0.97-0.98)."""
+        from .streams import concurrent_stream
         args = (self.x, self.sc, self.ce, self.img_w, self.img_h)
-        with torch.no_grad():
-            self.step(*args)                                   # warm (plans, workspace)
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            self.step(*args)
-            torch.cuda.synchronize(dev)
-            t_step = time.perf_counter() - t0
-            if t_step < 2e-3:                                  # nothing to hide an upload behind
-                return torch.cuda.Stream(device=dev)
-            src = torch.empty(8 << 20, dtype=torch.uint8).pin_memory()
-            dst = torch.empty(8 << 20, dtype=torch.uint8, device=dev)
-            best, seen = None, []
-            for _ in range(tries):
-                st = torch.cuda.Stream(device=dev)
-                with torch.cuda.stream(st):
-                    dst.copy_(src, non_blocking=True)           # first use of the stream outside the measurement
-                torch.cuda.synchronize(dev)
-                self.step(*args)                               # asynchronous: the kernels are now queued / running
-                t0 = time.perf_counter()
-                ev = torch.cuda.Event()
-                with torch.cuda.stream(st):
-                    dst.copy_(src, non_blocking=True)
-                    ev.record(st)
-                ev.synchronize()
-                dt = time.perf_counter() - t0
-                torch.cuda.synchronize(dev)
-                seen.append(round(dt * 1e3, 3))
-                if best is None or dt < best[0]:
-                    best = (dt, st)
-                if dt < 0.25 * t_step:
-                    break
-            self.copy_probe = {'step_ms': round(t_step * 1e3, 3), 'upload_8MB_beside_step_ms': round(best[0] * 1e3, 3),
-                               'candidates_ms': seen}
-            return best[1]
+        self.copy_probe = {}
+        return concurrent_stream(self.device, lambda: self.step(*args), tries=tries, probe=self.copy_probe)
 
     def host_buffers(self):
         """Pinned host staging for one step: (frames (F,H,W,3) uint8, boxes (N,4) fp32, frame_index (N,) int32)."""

@@ -48,9 +48,16 @@ class SpecPipeline:
         self.grouped = grouped
         self._side = {}
 
-    def _side_stream(self, device):
+    def _side_stream(self, device, busy=None):
+        """The stream CamCalib runs on.  Chosen by measurement when ``busy`` (a callable that enqueues the SPEC trunk on the
+        current stream) is given: a stream that shares the main stream's hardware queue would run the two trunks back to back
+        (``spec_amd/streams.py``).  Under graph capture, or without ``busy``, the next stream of the pool is taken."""
         if device not in self._side:
-            self._side[device] = torch.cuda.Stream(device=device)
+            if busy is not None and not torch.cuda.is_current_stream_capturing():
+                from .streams import concurrent_stream
+                self._side[device] = concurrent_stream(device, busy)
+            else:
+                self._side[device] = torch.cuda.Stream(device=device)
         return self._side[device]
 
     @torch.no_grad()
@@ -90,7 +97,7 @@ class SpecPipeline:
                                bbox_scale=bbox_scale, bbox_center=bbox_center, img_w=img_w, img_h=img_h)
         else:
             main = torch.cuda.current_stream(device)
-            side = self._side_stream(device)
+            side = self._side_stream(device, lambda: eng.trunk(images))
             side.wait_stream(main)                      # inputs were produced on the main stream
             with torch.cuda.stream(side):
                 logits = self.camcalib(cam_in)

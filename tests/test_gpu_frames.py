@@ -144,3 +144,23 @@ def test_tester_batched_equals_per_frame(tmp_path):
             for key, v in ref.items():
                 assert results[tag][f][key].shape == v.shape and np.array_equal(results[tag][f][key], v), (tag, f, key)
     assert results['per_frame']['f4.pkl']['smpl_vertices'].shape == (4, 6890, 3)
+
+
+def test_concurrent_stream_is_measured():
+    """``spec_amd.streams.concurrent_stream``: the helper stream is accepted only if a small upload on it finishes while the
+    busy work on the current stream is still running (a stream on the same hardware queue would finish after it)."""
+    from spec_amd.streams import concurrent_stream
+    a = torch.randn(4096, 4096, device=DEV)
+    sink = []
+
+    def busy():
+        sink.clear()
+        for _ in range(24):
+            sink.append(a @ a)
+
+    probe = {}
+    st = concurrent_stream(torch.device(DEV), busy, probe=probe)
+    assert isinstance(st, torch.cuda.Stream)
+    assert probe['step_ms'] > 2.0 and probe['upload_8MB_beside_step_ms'] < 0.5 * probe['step_ms'], probe
+    # nothing to hide behind: no measurement, still a stream
+    assert isinstance(concurrent_stream(torch.device(DEV), lambda: None, probe={}), torch.cuda.Stream)
