@@ -90,8 +90,61 @@ def traffic(dbs):
     print(json.dumps(out, indent=1))
 
 
+def layer_traffic(fetch_db, write_db, layers_json):
+    """Per-LAYER traffic: the conv dispatches of the FETCH_SIZE / WRITE_SIZE passes in dispatch order (eager, one stream: the
+    same order in every step) against the per-launch table bench.py wrote (label, algorithmic bytes), averaged over the steps."""
+    import json
+    entries = [e for e in json.load(open(layers_json))['entries'] if e['kernel'].startswith(('conv_', 'stem_', 'maxpool'))
+               and 'splitK' not in e['kernel']]
+
+    def series(db, counter):
+        c = sqlite3.connect(db)
+        cur = c.execute('select * from counters_collection limit 1')
+        cols = [d[0] for d in cur.description]
+        namec = 'kernel_name' if 'kernel_name' in cols else 'name'
+        order = next((k for k in ('dispatch_id', 'start', 'start_timestamp', 'timestamp', 'id') if k in cols), None)
+        if order is None:
+            raise SystemExit(f'no ordering column in counters_collection: {cols}')
+        q = (f"select {namec}, sum(value), min({order}) from counters_collection where counter_name = '{counter}' "
+             f"group by {order}, {namec} order by min({order})")
+        out = []
+        for kn, v, _ in c.execute(q):
+            k = short(kn)
+            if 'conv_igemm' in k or 'conv_wino' in k or 'stem_conv' in k or 'maxpool' in k:
+                out.append((k, v))
+        return out
+
+    f, w = series(fetch_db, 'FETCH_SIZE'), series(write_db, 'WRITE_SIZE')
+    # split-K dispatches (FC heads) carry the SPLITK template flag: drop them by name
+    issplit = lambda k: bool(re.search(r'conv_igemm_f32_kernel<64, 64, 2, 2, true, 32, false, true, true>', k))
+    f = [x for x in f if not issplit(x[0])]
+    w = [x for x in w if not issplit(x[0])]
+    n = len(entries)
+    if len(f) % n or len(w) % n or not f:
+        raise SystemExit(f'{len(f)} / {len(w)} conv dispatches do not divide into steps of {n} launches')
+    steps = len(f) // n
+    print(f'# per-layer traffic (MB per launch, average of {steps} steps; read = 2 x FETCH_SIZE, write = WRITE_SIZE) vs algorithmic bytes')
+    print(f'{"model":9s} {"layer":34s} {"kernel":44s} {"read":>8s} {"write":>8s} {"sum":>8s} {"algorithmic":>12s} {"ratio":>6s}')
+    agg = {}
+    for i, e in enumerate(entries):
+        rd = sum(2.0 * f[s * n + i][1] * 1024 for s in range(steps)) / steps
+        wr = sum(w[s * n + i][1] * 1024 for s in range(len(w) // n)) / (len(w) // n)
+        alg = e['bytes']
+        print(f'{e["model"]:9s} {e["label"]:34s} {e["kernel"][:44]:44s} {rd / 1e6:8.1f} {wr / 1e6:8.1f} {(rd + wr) / 1e6:8.1f} {alg / 1e6:12.1f} '
+              f'{(rd + wr) / alg:6.2f}   [{f[i][0][:60]}]')
+        key = re.sub(r'^backbone\.', '', e['label'])
+        key = re.sub(r'\.\d+\.', '.', key)
+        a = agg.setdefault(key, [0.0, 0.0, 0])
+        a[0] += rd + wr; a[1] += alg; a[2] += 1
+    print('# by layer type (both networks):')
+    for k, (t, a, c_) in sorted(agg.items(), key=lambda kv: -(kv[1][0] - kv[1][1])):
+        print(f'  {k:28s} x{c_:<3d} measured {t / 1e6:9.1f} MB  algorithmic {a / 1e6:9.1f} MB  ratio {t / a:5.2f}  excess {(t - a) / 1e6:8.1f} MB')
+
+
 if __name__ == '__main__':
-    if sys.argv[1] == 'stats':
+    if sys.argv[1] == 'layer_traffic':
+        layer_traffic(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif sys.argv[1] == 'stats':
         stats(sys.argv[2])
     elif sys.argv[1] == 'traffic':
         traffic(sys.argv[2:])

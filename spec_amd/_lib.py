@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libspecmi.so')
+LIB_PATH = os.environ.get('SPECMI_LIB') or os.path.join(_HERE, 'lib', 'libspecmi.so')   # SPECMI_LIB: an alternative build (A/B runs)
 
 OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_MISSING = 0, 1, 2, 3, 4
 MODEL_CAMCALIB, MODEL_HMR, MODEL_SMPL = 0, 1, 2

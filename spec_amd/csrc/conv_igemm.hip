@@ -64,6 +64,7 @@ struct KArgs {
     int OW, OHW, Cout, Npad, ldo;
     int KH, KW, stride, pad;
     int M, nbn, nchunks, cpc;  // cpc = chunks per filter tap = Cin / 32
+    int xcd_cols;              // > 0: XCD x owns tile columns [x * xcd_cols, (x + 1) * xcd_cols) and walks all tile rows (see the tile order)
     unsigned mg_ohw, sh_ohw, mg_ow, sh_ow;  // magic multipliers: n / OHW, n / OW for n < 2^31
     int relu;
     long split_out_stride;   // SPLITK: blockIdx.y = K slice z of nchunks chunks; partial tile z goes to out + z * stride
@@ -125,7 +126,16 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, q8 = nblk >> 3, r8 = nblk & 7;
     const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int tile_m = L / p.nbn, tile_n = L - tile_m * p.nbn;
+    int tile_m = L / p.nbn, tile_n = L - tile_m * p.nbn;
+    if (p.xcd_cols) {
+        // Weight panel larger than an XCD's 4 MiB L2 and many tile columns (layer4 conv3: 512 / 3072 x 2048 = 4 / 12 MiB, 32
+        // columns): with the row-major order every XCD streams the WHOLE panel again for each few tile rows (measured 0.45 / 2.0 GB
+        // of L2 misses per launch against 0.24 / 0.19 GB algorithmic, profiles/r03_v_layer_traffic.txt).  Here an XCD owns a
+        // fixed eighth of the columns - its slice of the panel stays in its L2 - and walks all tile rows; the (smaller) A
+        // operand is then read by all eight XCDs instead.  nbn % 8 == 0, so the grid splits evenly.
+        tile_n = xcd * p.xcd_cols + (bid >> 3) % p.xcd_cols;
+        tile_m = (bid >> 3) / p.xcd_cols;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- buffer descriptors (wave-uniform) and per-thread row offsets -----------------------
@@ -433,6 +443,14 @@ static int launch_variant(const KArgs& k, int M, const LaunchCtx& ctx, const cha
     kk.nbn = BN < 64 ? (k.Cout + BN - 1) / BN : k.Npad / BN;   // 32-wide tiles skip the all-padding half of a 64-padded weight panel
     const int nbm = (M + BM - 1) / BM;
     const int grid = nbm * kk.nbn;
+    // tile order for weight panels beyond L2 (see the kernel): worth it when eight reads of A cost less than re-streaming B
+    // for every other tile row, i.e. 8 * nbm * BM * K < K * N * nbm / 2  <=>  N > 16 * BM
+    const size_t w_bytes = (size_t)k.nchunks * 32 * k.Npad * 4;
+    kk.xcd_cols = 0;
+#ifndef SPECMI_NO_XCD_COLS
+    if (IS1X1 && !SPLITK && kk.nbn % 8 == 0 && w_bytes >= ((size_t)4 << 20) && k.Npad > 16 * BM && nbm >= 16)
+        kk.xcd_cols = kk.nbn / 8;
+#endif
     ProfScope ps(ctx, name, flops * groups, bytes * groups);
     kk.cpc = k.cpc * 32 / BK;
     kk.nchunks = k.nchunks * 32 / BK;

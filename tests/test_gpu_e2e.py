@@ -67,6 +67,24 @@ def test_trunk_execution_plans_agree(models, B, H, W):
     assert '2src' in names['backbone.layer2.0.conv3+downsample'], names
 
 
+def test_trunk_tile_order_of_wide_layers_keeps_batch_invariance(models):
+    """From 16 tile rows on, layer4's conv3 (+ downsample) launches walk their tiles with every XCD owning an eighth of the 32
+    tile columns (conv_igemm.hip, weight panels beyond L2); below that, row-major.  A tile's arithmetic does not depend on the
+    order the tiles are visited in: the features of an image are bit-identical whether it travels in a batch of 2 or of 24."""
+    _, hm = models
+    eng = hm.engine(torch.device(DEV))
+    x = t(synth.images(17, 24)).to(DEV)
+    big = eng.trunk(x).cpu()
+    eng.profile(True)
+    eng.trunk(x)
+    prof = eng.profile_read()
+    eng.profile(False)
+    assert any('layer4.0.conv3' in e['label'] and '2src' in e['kernel'] for e in prof)
+    for lo in (0, 10, 22):
+        small = eng.trunk(x[lo:lo + 2].contiguous()).cpu()
+        assert torch.equal(small, big[lo:lo + 2]), lo
+
+
 def test_camcalib_vs_reference_fixture(models):
     cc, _ = models
     g = golden('camcalib_e2e.npz')

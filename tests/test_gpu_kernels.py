@@ -218,6 +218,23 @@ def test_conv_winograd_input_alignment(eng):
             assert rel_err(y.numpy(), ref.numpy()) < 2e-5
 
 
+@pytest.mark.parametrize('res', [False, True])
+def test_conv1x1_wide_n_xcd_column_order(eng, res):
+    """512 -> 2048 1x1 with >= 16 tile rows: the launch where every XCD owns four of the 32 tile columns (weight panel = 4 MiB
+    = an XCD's whole L2).  Every tile must be visited exactly once: compared with PyTorch-CPU over the whole output."""
+    g = torch.Generator().manual_seed(4242)
+    B, H, W, cin, cout = 8, 14, 14, 512, 2048            # M = 1568 -> 25 tile rows of 64
+    x = torch.randn(B, H, W, cin, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5
+    sc = torch.rand(cout, generator=g) + 0.5
+    sh = torch.randn(cout, generator=g) * 0.1
+    r = torch.randn(B, H, W, cout, generator=g) if res else None
+    y = eng.conv2d(x.to(DEV), w.numpy(), sc.numpy(), sh.numpy(), 1, 0, residual=None if r is None else r.to(DEV), relu=True).cpu()
+    ref = _conv_ref(x, w, sc, sh, 1, 0, r, True)
+    assert y.shape == ref.shape and not torch.isnan(y).any()
+    assert rel_err(y.numpy(), ref.numpy()) < 2e-5
+
+
 def test_conv_identity_asymmetric(eng):
     """A = I style check with an asymmetric weight: catches row/col transposes of the MFMA C layout."""
     cin = cout = 64
