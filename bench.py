@@ -159,9 +159,9 @@ def stage_table(entries):
             continue
         t_hbm = a['bytes'] / (PEAK_HBM_TBS * 1e12)
         t_mfma = a['flops'] / (PEAK_FP32_MFMA_TFLOPS * 1e12)
-        # flop-bound stages whose kernels use no matrix instruction (SMPL skinning, joints, heads' element-wise kernels) are
+        # flop-bound stages whose kernels use no matrix instruction (joints, heads' element-wise kernels) are
         # priced against the same 157.3 TF/s - gfx950's vector fp32 peak equals its fp32 MFMA peak - but named 'valu'
-        uses_mfma = any(k.startswith(('conv_igemm', 'conv_wino', 'stem_conv')) for k in a['kernels'])
+        uses_mfma = any(k.startswith(('conv_igemm', 'conv_wino', 'stem_conv', 'smpl_skin')) for k in a['kernels'])
         rows.append({'stage': name, 'kernel': '|'.join(sorted(a['kernels'])), 'launches': a['launches'],
                      'ms': round(a['ms'], 4), 'bound': 'hbm' if t_hbm >= t_mfma else ('mfma' if uses_mfma else 'valu'),
                      'frac': round(max(t_hbm, t_mfma) / t, 4),

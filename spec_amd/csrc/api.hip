@@ -410,10 +410,24 @@ static int commit_smpl(specmi_handle* h) {
     m.V = V;
     std::vector<int32_t> parents = par->i;
     parents[0] = -1;
-    if ((rc = dev_upload(h, vt->f.data(), vt->f.size() * 4, (void**)&m.v_template, h->param_allocs))) return rc;
-    if ((rc = dev_upload(h, sd->f.data(), sd->f.size() * 4, (void**)&m.shapedirs, h->param_allocs))) return rc;
-    if ((rc = dev_upload(h, pd->f.data(), pd->f.size() * 4, (void**)&m.posedirs, h->param_allocs))) return rc;
-    if ((rc = dev_upload(h, lw->f.data(), lw->f.size() * 4, (void**)&m.lbs_weights, h->param_allocs))) return rc;
+    {   // the skinning kernel's operands in MFMA fragment order (smpl.hip): [posedirs ; shapedirs ; v_template] per
+        // (vertex group, coordinate) and the skinning weights per vertex group; vertices past V are zero rows
+        const int G = (V + 31) / 32;
+        const size_t tile = (size_t)SMPL_KQ * 256;
+        std::vector<float> dirs((size_t)G * 3 * tile, 0.f), wt((size_t)G * 768, 0.f);
+        for (int v = 0; v < V; ++v) {
+            const int g = v / 32, n = v % 32;
+            for (int c = 0; c < 3; ++c) {
+                float* d = dirs.data() + ((size_t)g * 3 + c) * tile;
+                for (int k = 0; k < 207; ++k) d[frag_slot(k, n)] = pd->f[(size_t)k * V * 3 + (size_t)v * 3 + c];
+                for (int l = 0; l < 10; ++l) d[frag_slot(207 + l, n)] = sd->f[((size_t)v * 3 + c) * 10 + l];
+                d[frag_slot(217, n)] = vt->f[(size_t)v * 3 + c];
+            }
+            for (int j = 0; j < 24; ++j) wt[(size_t)g * 768 + frag_slot(j, n)] = lw->f[(size_t)v * 24 + j];
+        }
+        if ((rc = dev_upload(h, dirs.data(), dirs.size() * 4, (void**)&m.dirsT, h->param_allocs))) return rc;
+        if ((rc = dev_upload(h, wt.data(), wt.size() * 4, (void**)&m.wT, h->param_allocs))) return rc;
+    }
     if ((rc = dev_upload(h, jx->f.data(), jx->f.size() * 4, (void**)&m.J_extra, h->param_allocs))) return rc;
     if ((rc = dev_upload(h, Jt.data(), Jt.size() * 4, (void**)&m.J_template, h->param_allocs))) return rc;
     if ((rc = dev_upload(h, Jd.data(), Jd.size() * 4, (void**)&m.J_shapedirs, h->param_allocs))) return rc;
@@ -461,11 +475,12 @@ static int ensure_ws(specmi_handle* h, int B, int H, int W) {
     if ((rc = dev_alloc(h, (size_t)Bp * 10 * 4, (void**)&h->betas_ws, h->ws_allocs))) return rc;
     if ((rc = dev_alloc(h, (size_t)Bp * 3 * 4, (void**)&h->cam_ws, h->ws_allocs))) return rc;
     if ((rc = dev_alloc(h, (size_t)Bp * V * 3 * 4, (void**)&h->verts_ws, h->ws_allocs))) return rc;
-    if ((rc = dev_alloc(h, (size_t)Bp * (208 + 10) * 4, (void**)&h->pf_ws, h->ws_allocs))) return rc;
-    if ((rc = dev_alloc(h, (size_t)Bp * 288 * 4, (void**)&h->A_ws, h->ws_allocs))) return rc;
+    const int Bp32 = round_up(Bw, 32);   // the skinning kernel's operands come in tiles of 32 images (smpl.hip)
+    if ((rc = dev_alloc(h, (size_t)Bp32 * SMPL_KQ * 8 * 4, (void**)&h->pf_ws, h->ws_allocs))) return rc;
+    if ((rc = dev_alloc(h, (size_t)Bp32 * 288 * 4, (void**)&h->A_ws, h->ws_allocs))) return rc;
     if ((rc = dev_alloc(h, (size_t)Bp * 72 * 4, (void**)&h->pj_ws, h->ws_allocs))) return rc;
-    HIPCHK(h, hipMemset(h->pf_ws, 0, (size_t)Bp * (208 + 10) * 4));
-    HIPCHK(h, hipMemset(h->A_ws, 0, (size_t)Bp * 288 * 4));
+    HIPCHK(h, hipMemset(h->pf_ws, 0, (size_t)Bp32 * SMPL_KQ * 8 * 4));   // rows 218..223 of the feature operand stay zero
+    HIPCHK(h, hipMemset(h->A_ws, 0, (size_t)Bp32 * 288 * 4));
     // split-K partial tiles of the FC GEMMs (<= 16 slices x 1024 rows x 1024 columns) and a row of zeros
     h->splitk_floats = (size_t)16 * (Bp < 1024 ? Bp : 1024) * 1024;
     if ((rc = dev_alloc(h, h->splitk_floats * 4, (void**)&h->splitk_ws, h->ws_allocs))) return rc;

@@ -9,13 +9,14 @@
 //      pose features (R_j - I), and the 24-joint kinematic chain.  Lane j owns joint j; the
 //      tree is walked level by level and a child reads its parent's 3x4 world transform with
 //      wave shuffles (ds_bpermute), so the chain never touches memory.
-//   2. smpl_skin_kernel   (256 vertices x 8 images per workgroup): shape blend, pose blend
-//      (207-term), blended 3x4 transform (24 joints) and the skinned vertex, all in registers.
-//      Everything that is constant across the lanes of a wave (betas, pose features, the
-//      24x12 joint transforms of the 8 images) is laid out so the compiler fetches it with
-//      scalar loads (s_load_dwordx4/x8 through the scalar cache) and feeds it to v_fma as an
-//      SGPR operand - no LDS traffic, no broadcast reads.  posedirs rows are read coalesced
-//      (a wave covers 192 contiguous floats) and reused for the 8 images of the tile.
+//   2. smpl_skin_kernel   (a wave = 32 vertices x 32 images): everything that is a contraction runs on the fp32 matrix
+//      cores.  v_posed = [pose features | betas | 1] (32 images x 224) x [posedirs ; shapedirs ; v_template] (224 x 32
+//      vertices, one GEMM per coordinate) is 3 x 112 v_mfma_f32_32x32x2_f32; the blended transforms T = lbs_weights (32
+//      vertices x 24 joints) x A (24 joints x 32 images, one GEMM per entry of the 3x4 matrix) are 12 x 12 more.  Both
+//      products leave (vertex row, image column) in the same accumulator slot of a lane, so the skinned vertex
+//      T[:, :3] v_posed + T[:, 3] is lane-local arithmetic on the accumulators.  Operands are stored in MFMA fragment
+//      order - the body model at commit (SmplDev::dirsT / wT), the per-image features and transforms by the pose kernel -
+//      so every operand fetch is one coalesced 16-byte load per lane for four MFMA steps.
 //   3. smpl_joints_kernel (one workgroup per image): J_regressor_extra @ vertices (9 dot
 //      products of length V, wave-shuffle + LDS reduction), the 21 vertex-picked joints, the
 //      49-entry joint_map gather, the full-image camera translation and the projection
@@ -24,14 +25,21 @@
 
 namespace specmi {
 
-constexpr int IT = 8;        // images per skinning workgroup
-constexpr int PF_LD = 208;   // 207 pose features padded
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int IT = 32;                     // images per tile = columns of one MFMA
+constexpr int KQ = SMPL_KQ;                // K = 224 = 207 pose features + 10 betas + 1 (template) + 6 zeros = 112 MFMA steps = 28 quads
+constexpr int FEAT_TILE = KQ * 64 * 4;     // floats of one image tile of features  [quad][lane][4]   (224 per image)
+constexpr int SKIN_LD = 98;                // floats per image row of the output transpose (96 + 2: even, so rows stay 8-byte aligned)
+constexpr int A_TILE = 12 * 3 * 64 * 4;    // floats of one image tile of transforms [entry][quad][lane][4] (288 per image)
+
 
 __global__ void __launch_bounds__(64) smpl_pose_kernel(const float* __restrict__ rotmat, const float* __restrict__ betas,
                                                         const float* __restrict__ Jt, const float* __restrict__ Jd,
-                                                        const int* __restrict__ parents, float* __restrict__ pf_t,
-                                                        float* __restrict__ betas_t, float* __restrict__ A,
-                                                        float* __restrict__ posed_j) {
+                                                        const int* __restrict__ parents, float* __restrict__ feat,
+                                                        float* __restrict__ Afrag, float* __restrict__ posed_j) {
     const int b = blockIdx.x;
     const int j = threadIdx.x;
     const bool act = j < 24;
@@ -50,7 +58,11 @@ __global__ void __launch_bounds__(64) smpl_pose_kernel(const float* __restrict__
     float beta[10];
 #pragma unroll
     for (int l = 0; l < 10; ++l) beta[l] = betas[(size_t)b * 10 + l];
-    if (j < 10) betas_t[((size_t)(b / IT) * 10 + j) * IT + (b % IT)] = beta[j];
+    // row b of the skin kernel's feature operand, in fragment order: k < 207 pose features, 207..216 betas, 217 the constant 1
+    // that multiplies v_template (218..223 stay 0 from the allocation)
+    float* const ft = feat + (size_t)(b / IT) * FEAT_TILE;
+    if (j < 10) ft[frag_slot(207 + j, b % IT)] = beta[j];
+    if (j == 10) ft[frag_slot(217, b % IT)] = 1.0f;
 
     float J[3];
 #pragma unroll
@@ -61,13 +73,11 @@ __global__ void __launch_bounds__(64) smpl_pose_kernel(const float* __restrict__
         J[c] = Jt[jj * 3 + c] + s;
     }
 
-    // pose feature (R_j - I) for j >= 1, tiled [tile][k][IT] so the skin kernel reads it with scalar loads
+    // pose feature (R_j - I) for j >= 1
     if (act && j > 0) {
-        float* dst = pf_t + ((size_t)(b / IT) * PF_LD + (j - 1) * 9) * IT + (b % IT);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) dst[k * IT] = R[k] - ((k % 4 == 0) ? 1.0f : 0.0f);
+        for (int k = 0; k < 9; ++k) ft[frag_slot((j - 1) * 9 + k, b % IT)] = R[k] - ((k % 4 == 0) ? 1.0f : 0.0f);
     }
-    if (j == 24) pf_t[((size_t)(b / IT) * PF_LD + 207) * IT + (b % IT)] = 0.f;
 
     const int src = par >= 0 ? par : 0;
     float rel[3];
@@ -100,86 +110,105 @@ __global__ void __launch_bounds__(64) smpl_pose_kernel(const float* __restrict__
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             posed_j[((size_t)b * 24 + j) * 3 + r] = G[r * 4 + 3];
-            float* a = A + ((size_t)b * 24 + j) * 12 + r * 4;
-            a[0] = G[r * 4 + 0]; a[1] = G[r * 4 + 1]; a[2] = G[r * 4 + 2];
-            a[3] = G[r * 4 + 3] - (G[r * 4 + 0] * J[0] + G[r * 4 + 1] * J[1] + G[r * 4 + 2] * J[2]);
+            // entry e = 4 r + c of joint j's relative transform: operand [e] of the skin kernel, k = joint, column = image
+            float* const at = Afrag + (size_t)(b / IT) * A_TILE + frag_slot(j, b % IT);
+            at[(size_t)(r * 4 + 0) * 768] = G[r * 4 + 0]; at[(size_t)(r * 4 + 1) * 768] = G[r * 4 + 1]; at[(size_t)(r * 4 + 2) * 768] = G[r * 4 + 2];
+            at[(size_t)(r * 4 + 3) * 768] = G[r * 4 + 3] - (G[r * 4 + 0] * J[0] + G[r * 4 + 1] * J[1] + G[r * 4 + 2] * J[2]);
         }
     }
 }
 
-__global__ void __launch_bounds__(256) smpl_skin_kernel(const float* __restrict__ v_template,
-                                                         const float* __restrict__ shapedirs,
-                                                         const float* __restrict__ posedirs,
-                                                         const float* __restrict__ lbs_w,
-                                                         const float* __restrict__ betas_t,
-                                                         const float* __restrict__ pf_t, const float* __restrict__ A,
-                                                         float* __restrict__ verts, long ld_verts, int V, int B) {
-    const int v = blockIdx.x * 256 + threadIdx.x;
-    const bool vok = v < V;
-    const int vv = vok ? v : V - 1;
-    const int tile = blockIdx.y, b0 = tile * IT;
-    const float* __restrict__ bt = betas_t + (size_t)tile * 10 * IT;    // [10][IT]   wave-uniform
-    const float* __restrict__ pf = pf_t + (size_t)tile * PF_LD * IT;    // [208][IT]  wave-uniform
-    const float* __restrict__ At = A + (size_t)b0 * 288;                // [IT][24][12] wave-uniform
+// grid (ceil(groups / 4), image tiles); wave w of a workgroup owns vertex group 4 blockIdx.x + w and needs nothing from the
+// other waves (its LDS slice is private: no barrier).
+__global__ void __launch_bounds__(256) smpl_skin_kernel(const float* __restrict__ dirsT, const float* __restrict__ wT,
+                                                         const float* __restrict__ feat, const float* __restrict__ Afrag,
+                                                         float* __restrict__ verts, long ld_verts, int V, int B, int G) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= G) return;
+    const int tile = blockIdx.y;
+    const f32x4* __restrict__ fq = reinterpret_cast<const f32x4*>(feat + (size_t)tile * FEAT_TILE) + lane;     // [quad][64]
+    const f32x4* __restrict__ dq = reinterpret_cast<const f32x4*>(dirsT + (size_t)g * 3 * FEAT_TILE) + lane;   // [coord][quad][64]
 
-    float vp[IT][3];
-    {   // v_shaped = v_template + shapedirs . beta
-        float vt[3], sd[30];
+    // v_posed[vertex][image] per coordinate: A operand = the model's directions (row = vertex), B operand = features (column = image)
+    f32x16 vp[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) vt[c] = v_template[vv * 3 + c];
+    for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int e = 0; e < 30; ++e) sd[e] = shapedirs[(size_t)vv * 30 + e];
+        for (int r = 0; r < 16; ++r) vp[c][r] = 0.f;
+    constexpr int PD = 3;                      // quads in flight ahead of the MFMAs (12 MFMAs = 768 cycles each)
+    f32x4 fb[PD], d0[PD], d1[PD], d2[PD];
 #pragma unroll
-        for (int i = 0; i < IT; ++i)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float s = 0.f;
-#pragma unroll
-                for (int l = 0; l < 10; ++l) s = fmaf(bt[l * IT + i], sd[c * 10 + l], s);
-                vp[i][c] = vt[c] + s;
-            }
+    for (int i = 0; i < PD; ++i) {
+        fb[i] = fq[i * 64]; d0[i] = dq[i * 64]; d1[i] = dq[(KQ + i) * 64]; d2[i] = dq[(2 * KQ + i) * 64];
     }
-    {   // v_posed = pose_offsets + v_shaped, pose_offsets = pose_feature @ posedirs
-        float off[IT][3];
 #pragma unroll
-        for (int i = 0; i < IT; ++i) off[i][0] = off[i][1] = off[i][2] = 0.f;
-        const float* pd = posedirs + (size_t)vv * 3;
-        const size_t ldp = (size_t)V * 3;
-#pragma unroll 9
-        for (int k = 0; k < 207; ++k) {
-            const float p0 = pd[k * ldp + 0], p1 = pd[k * ldp + 1], p2 = pd[k * ldp + 2];
-#pragma unroll
-            for (int i = 0; i < IT; ++i) {
-                const float f = pf[k * IT + i];
-                off[i][0] = fmaf(f, p0, off[i][0]);
-                off[i][1] = fmaf(f, p1, off[i][1]);
-                off[i][2] = fmaf(f, p2, off[i][2]);
-            }
+    for (int s4 = 0; s4 < KQ; ++s4) {
+        const int cur = s4 % PD;
+        const f32x4 f = fb[cur], a0 = d0[cur], a1 = d1[cur], a2 = d2[cur];
+        if (s4 + PD < KQ) {
+            fb[cur] = fq[(s4 + PD) * 64]; d0[cur] = dq[(s4 + PD) * 64];
+            d1[cur] = dq[(KQ + s4 + PD) * 64]; d2[cur] = dq[(2 * KQ + s4 + PD) * 64];
         }
 #pragma unroll
-        for (int i = 0; i < IT; ++i)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) vp[i][c] = off[i][c] + vp[i][c];
+        for (int q = 0; q < 4; ++q) {
+            vp[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], f[q], vp[0], 0, 0, 0);
+            vp[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], f[q], vp[1], 0, 0, 0);
+            vp[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[q], f[q], vp[2], 0, 0, 0);
+        }
     }
-    float w[24];
-#pragma unroll
-    for (int j = 0; j < 24; ++j) w[j] = lbs_w[(size_t)vv * 24 + j];
 
+    // blended transform entry e = 4 c + d of (vertex, image): sum_j w[vertex][j] A[image][j][e]; then the skinned coordinate c
+    const f32x4* __restrict__ wq = reinterpret_cast<const f32x4*>(wT + (size_t)g * 768) + lane;                // [quad (3)][64]
+    const f32x4* __restrict__ aq = reinterpret_cast<const f32x4*>(Afrag + (size_t)tile * A_TILE) + lane;       // [entry][quad][64]
+    const f32x4 w0 = wq[0], w1 = wq[64], w2 = wq[128];
+    // the wave's 32 images x 32 vertices x 3 coordinates go through LDS (wave-private: no barrier) so that global memory sees,
+    // per image, the 384 contiguous bytes of the 32 vertices instead of 4-byte pieces 80 KB apart
+    extern __shared__ __attribute__((aligned(16))) float skin_lds[];
+    float* const tw = skin_lds + (threadIdx.x >> 6) * (IT * SKIN_LD);
+    const int vloc0 = 4 * (lane >> 5);
 #pragma unroll
-    for (int i = 0; i < IT; ++i) {
-        if (b0 + i >= B) break;   // wave-uniform
-        float T[12];
+    for (int c = 0; c < 3; ++c) {
+        f32x16 T[4];
 #pragma unroll
-        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+        for (int d = 0; d < 4; ++d) {
 #pragma unroll
-        for (int j = 0; j < 24; ++j)
+            for (int r = 0; r < 16; ++r) T[d][r] = 0.f;
+            const f32x4 b0 = aq[((4 * c + d) * 3 + 0) * 64], b1 = aq[((4 * c + d) * 3 + 1) * 64], b2 = aq[((4 * c + d) * 3 + 2) * 64];
 #pragma unroll
-            for (int e = 0; e < 12; ++e) T[e] = fmaf(w[j], At[(i * 24 + j) * 12 + e], T[e]);
-        if (vok) {
-            float* o = verts + (size_t)(b0 + i) * ld_verts + (size_t)v * 3;
+            for (int q = 0; q < 4; ++q) T[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[q], b0[q], T[d], 0, 0, 0);
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
-                o[c] = T[c * 4 + 0] * vp[i][0] + T[c * 4 + 1] * vp[i][1] + T[c * 4 + 2] * vp[i][2] + T[c * 4 + 3];
+            for (int q = 0; q < 4; ++q) T[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[q], b1[q], T[d], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) T[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[q], b2[q], T[d], 0, 0, 0);
+        }
+        // accumulator r of this lane = image lane % 32, vertex vloc0 + (r & 3) + 8 (r >> 2) of the group
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float o = T[0][r] * vp[0][r] + T[1][r] * vp[1][r] + T[2][r] * vp[2][r] + T[3][r];
+            tw[(lane & 31) * SKIN_LD + (vloc0 + (r & 3) + 8 * (r >> 2)) * 3 + c] = o;
+        }
+    }
+    // one wave's LDS instructions execute in order: the reads below see the writes above
+    const int nimg = min(IT, B - tile * IT);
+    const int nfl = min(96, (V - g * 32) * 3);                       // floats of this group that exist
+    float* const obase = verts + (size_t)tile * IT * ld_verts + (size_t)g * 96;
+    if (((ld_verts & 1) == 0) && ((reinterpret_cast<uintptr_t>(verts) & 7) == 0)) {
+        // rows of the output start on 8-byte boundaries: 48 lanes x 8 bytes per image
+        const bool on = 2 * lane + 1 < nfl;
+        const bool half = 2 * lane + 1 == nfl;                        // (V * 3 odd: the last float alone)
+#pragma unroll 4
+        for (int i = 0; i < nimg; ++i) {
+            const f32x2 t = *reinterpret_cast<const f32x2*>(tw + i * SKIN_LD + 2 * (lane < 48 ? lane : 0));
+            float* const o = obase + (size_t)i * ld_verts + 2 * lane;
+            if (on) *reinterpret_cast<f32x2*>(o) = t;
+            else if (half) o[0] = t[0];
+        }
+    } else {
+        for (int i = 0; i < nimg; ++i) {
+            float* const o = obase + (size_t)i * ld_verts;
+            if (lane < nfl) o[lane] = tw[i * SKIN_LD + lane];
+            if (lane + 64 < nfl) o[lane + 64] = tw[i * SKIN_LD + lane + 64];
         }
     }
 }
@@ -311,22 +340,20 @@ int launch_rodrigues(const float* aa, float* rot, int n, const LaunchCtx& ctx) {
 int launch_smpl_native(const SmplDev& m, const SmplArgs& a, float* joints24, const LaunchCtx& ctx) {
     const int B = a.B, V = m.V;
     const long ld_verts = a.ld_verts > 0 ? a.ld_verts : (long)V * 3;
-    const int tiles = (B + IT - 1) / IT;
-    float* pf_t = a.pose_feat;
-    float* betas_t = a.pose_feat + (size_t)tiles * PF_LD * IT;
+    const int tiles = (B + IT - 1) / IT, G = (V + 31) / 32;
     {
         ProfScope ps(ctx, "smpl_pose_chain", 0.0, 4.0 * B * (216 + 10 + 207 + 288 + 72));
         hipLaunchKernelGGL(smpl_pose_kernel, dim3(B), dim3(64), 0, ctx.stream, a.rotmat, a.betas, m.J_template,
-                           m.J_shapedirs, m.parents, pf_t, betas_t, a.A, joints24 ? joints24 : a.posed_j);
+                           m.J_shapedirs, m.parents, a.pose_feat, a.A, joints24 ? joints24 : a.posed_j);
     }
     if (a.vertices) {
         const double flops = 2.0 * (double)B * V * (3.0 * 207 + 30 + 288 + 9);
         // algorithmic HBM bytes: the body model once + every output once (the kernel re-reads its model slice once per
-        // tile of IT images - that re-use is served by L2, PMC: 251 MB read per launch at B = 256 - and is not counted)
+        // tile of IT images - that re-use is served by L2 - and is not counted)
         const double bytes = 4.0 * ((double)B * V * 3 + (double)V * (3.0 * 207 + 3 + 30 + 24) + (double)B * (207 + 10 + 288));
         ProfScope ps(ctx, "smpl_skin_lbs", flops, bytes);
-        hipLaunchKernelGGL(smpl_skin_kernel, dim3((V + 255) / 256, tiles), dim3(256), 0, ctx.stream, m.v_template,
-                           m.shapedirs, m.posedirs, m.lbs_weights, betas_t, pf_t, a.A, a.vertices, ld_verts, V, B);
+        hipLaunchKernelGGL(smpl_skin_kernel, dim3((G + 3) / 4, tiles), dim3(256), 4 * IT * SKIN_LD * sizeof(float), ctx.stream, m.dirsT,
+                           m.wT, a.pose_feat, a.A, a.vertices, ld_verts, V, B, G);
     }
     return (int)hipGetLastError();
 }
@@ -334,23 +361,20 @@ int launch_smpl_native(const SmplDev& m, const SmplArgs& a, float* joints24, con
 int launch_smpl(const SmplDev& m, const SmplArgs& a, const LaunchCtx& ctx) {
     const int B = a.B, V = m.V;
     const long ld_verts = a.ld_verts > 0 ? a.ld_verts : (long)V * 3;
-    // workspace layout inside pose_feat: [tiles][208][IT] pose features, then [tiles][10][IT] betas
-    const int tiles = (B + IT - 1) / IT;
-    float* pf_t = a.pose_feat;
-    float* betas_t = a.pose_feat + (size_t)tiles * PF_LD * IT;
+    const int tiles = (B + IT - 1) / IT, G = (V + 31) / 32;
     {
         ProfScope ps(ctx, "smpl_pose_chain", 0.0, 4.0 * B * (216 + 10 + 207 + 288 + 72));
         hipLaunchKernelGGL(smpl_pose_kernel, dim3(B), dim3(64), 0, ctx.stream, a.rotmat, a.betas, m.J_template,
-                           m.J_shapedirs, m.parents, pf_t, betas_t, a.A, a.posed_j);
+                           m.J_shapedirs, m.parents, a.pose_feat, a.A, a.posed_j);
     }
     {
         const double flops = 2.0 * (double)B * V * (3.0 * 207 + 30 + 288 + 9);
         // algorithmic HBM bytes: the body model once + every output once (the kernel re-reads its model slice once per
-        // tile of IT images - that re-use is served by L2, PMC: 251 MB read per launch at B = 256 - and is not counted)
+        // tile of IT images - that re-use is served by L2 - and is not counted)
         const double bytes = 4.0 * ((double)B * V * 3 + (double)V * (3.0 * 207 + 3 + 30 + 24) + (double)B * (207 + 10 + 288));
         ProfScope ps(ctx, "smpl_skin_lbs", flops, bytes);
-        hipLaunchKernelGGL(smpl_skin_kernel, dim3((V + 255) / 256, tiles), dim3(256), 0, ctx.stream, m.v_template,
-                           m.shapedirs, m.posedirs, m.lbs_weights, betas_t, pf_t, a.A, a.vertices, ld_verts, V, B);
+        hipLaunchKernelGGL(smpl_skin_kernel, dim3((G + 3) / 4, tiles), dim3(256), 4 * IT * SKIN_LD * sizeof(float), ctx.stream, m.dirsT,
+                           m.wT, a.pose_feat, a.A, a.vertices, ld_verts, V, B, G);
     }
     {
         JointArgs j;

@@ -162,12 +162,20 @@ int launch_cam_params(const float* pitch, const float* roll, const float* f_pix,
 // ----------------------------------------------------------------------------------------
 // SMPL  (smpl.hip)
 // ----------------------------------------------------------------------------------------
+// Operands of the skinning kernel live in MFMA fragment order.  Slot of element (k, n) of a K x 32 operand of
+// v_mfma_f32_32x32x2_f32 (n = row of an A operand / column of a B operand) stored as [quad][lane][4]: MFMA step st = k / 2 reads
+// register element st % 4 of the 16-byte quad st / 4; lane = (k % 2) * 32 + n.
+constexpr int SMPL_KQ = 28;   // K = 224 = 207 pose features + 10 betas + 1 (v_template) + 6 zeros = 112 steps = 28 quads
+__host__ __device__ inline size_t frag_slot(int k, int n) {
+    const int st = k >> 1;
+    return ((size_t)(st >> 2) * 64 + (k & 1) * 32 + n) * 4 + (st & 3);
+}
+
 struct SmplDev {
     int V = 0;
-    float* v_template = nullptr;   // (V,3)
-    float* shapedirs = nullptr;    // (V,3,10)
-    float* posedirs = nullptr;     // (207, 3V)
-    float* lbs_weights = nullptr;  // (V,24)
+    // [group of 32 vertices][coordinate][frag_slot(k, vertex % 32)], k: 0..206 posedirs, 207..216 shapedirs, 217 v_template
+    float* dirsT = nullptr;
+    float* wT = nullptr;           // [group][frag_slot(joint, vertex % 32)]: lbs_weights, 768 floats per group
     float* J_template = nullptr;   // (24,3)   = J_regressor @ v_template      (fp64 on host)
     float* J_shapedirs = nullptr;  // (24,3,10) = J_regressor @ shapedirs      (fp64 on host)
     float* J_extra = nullptr;      // (9,V)

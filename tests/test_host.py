@@ -173,7 +173,8 @@ def test_bench_stage_table_formulae():
         e('conv_igemm_f32<128x128,4x2>', 'backbone.layer1.1.conv3', 0.35, 26.3e9, 1.85e9),
         e('maxpool3x3s2_f32', 'backbone.maxpool', 0.23, 0.0, 1.03e9),
         e('conv_igemm_f32<64x64,2x2,splitK>', 'head.ief_collapsed', 0.02, 0.18e9, 4e6),
-        e('smpl_skin_lbs', 'smpl', 0.087, 3.3e9, 39.6e6),
+        e('smpl_skin_lbs', 'smpl', 0.047, 3.3e9, 39.6e6),
+        e('smpl_joints_project', 'smpl', 0.025, 0.095e9, 21.8e6),
     ]
     rows = {r['stage']: r for r in bench.stage_table(entries)}
     assert rows['layer3.conv1']['launches'] == 2 and rows['layer3.conv1']['bound'] == 'mfma'
@@ -181,8 +182,10 @@ def test_bench_stage_table_formulae():
     assert abs(rows['layer3.conv2']['TFLOPs'] - 59.2e9 * 16 / 36 / 0.25e-3 / 1e12) < 0.01          # executed, not algorithmic
     assert rows['layer1.conv3']['bound'] == 'hbm' and abs(rows['layer1.conv3']['frac'] - (1.85e9 / 8e12) / 0.35e-3) < 1e-3
     assert rows['stem.maxpool']['bound'] == 'hbm' and rows['hmr.regressor']['launches'] == 1
-    sk = [r for r in rows.values() if r['kernel'] == 'smpl_skin_lbs'][0]       # flop-bound without matrix instructions
-    assert sk['bound'] == 'valu' and abs(sk['frac'] - (3.3e9 / 157.3e12) / 0.087e-3) < 1e-3
+    sk = [r for r in rows.values() if r['kernel'] == 'smpl_skin_lbs'][0]       # the skinning contractions run on the matrix cores
+    assert sk['bound'] == 'mfma' and abs(sk['frac'] - (3.3e9 / 157.3e12) / 0.047e-3) < 1e-3
+    jp = [r for r in rows.values() if r['kernel'] == 'smpl_joints_project'][0]
+    assert jp['bound'] in ('hbm', 'valu')                                       # no matrix instructions: never labelled mfma
     assert all(0 < r['frac'] <= 1.0 for r in rows.values())
     roof = bench.roofline_from_profile(entries)
     igemm_ms = 0.25 + 0.25 + 0.35 + 0.02
