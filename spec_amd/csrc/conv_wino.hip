@@ -56,6 +56,7 @@ struct WArgs {
     int nstage;            // Cin / 16
     unsigned mg_thw, sh_thw, mg_tw, sh_tw;
     int relu;
+    int cpx;               // co columns per XCD (see the workgroup -> (column, tile row) map in the kernel); 1 = one column per XCD
     // grouped launch: the second half of the (persistent) grid runs the SAME layer shape of a second network on these tensors
     // (the CamCalib and SPEC trunks as one launch per layer): twice the tile rows to deal out, half the rounding loss of the
     // last persistent round
@@ -151,9 +152,18 @@ __global__ void __launch_bounds__(256, NF == 16 ? 1 : 2) conv_wino_f32_kernel(co
     const float* const pshift = grp ? p.g1.shift : p.shift;
     const float* const pres = grp ? p.g1.res : p.res;
     float* const pout = grp ? p.g1.out : p.out;
-    const int tile_n = bid % p.nbn;
+    int tile_n = bid % p.nbn;
     const int G = nwg / p.nbn;                     // workgroups per co column (of one network)
     int tile_m = bid / p.nbn;
+    if (p.cpx > 1) {
+        // With one column per XCD every input patch is fetched by nbn XCDs (measured 2 - 3.3x the algorithmic bytes,
+        // profiles/r03_v_layer_traffic.txt).  When the U slices of cpx columns fit an XCD's L2 together, the cpx workgroups that
+        // walk the same tile rows are placed on ONE XCD (workgroup id % 8) instead, and the patches are fetched by nbn / cpx XCDs.
+        const int xcd = bid & 7, j = bid >> 3;
+        const int ngroups = p.nbn / p.cpx, xpg = 8 / ngroups;       // column groups; XCDs serving one group
+        tile_n = (xcd % ngroups) * p.cpx + j % p.cpx;
+        tile_m = (j / p.cpx) * xpg + xcd / ngroups;
+    }
 
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(px), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pu), 0, p.u_bytes, 0x00020000);
@@ -616,6 +626,17 @@ static int wino_launch_variant(WArgs k, int Cout, const LaunchCtx& ctx, double f
 #endif
     if (G < 1) G = 1;
     if (G > k.nbm || k.nstage < 2 || g_wino_persistent == 0) G = k.nbm;
+    // columns per XCD: as many as keep their U slices (16 frequencies x Cin x NT channels) within 2 MiB of the 4 MiB L2
+    k.cpx = 1;
+#ifndef WINO_NO_CPX
+    {
+        const size_t u_col = (size_t)16 * k.nstage * 16 * NT * 4;
+        int c = 1;
+        while (c * 2 <= k.nbn && k.nbn % (c * 2) == 0 && (size_t)(c * 2) * u_col <= ((size_t)2 << 20)) c *= 2;
+        const int nwg = G * k.nbn;
+        if (c > 1 && nwg % 8 == 0 && (nwg / 8) % c == 0 && 8 % (k.nbn / c) == 0) k.cpx = c;
+    }
+#endif
     ProfScope ps(ctx, NF == 16 ? "conv_wino_f32<32t x128,F(2x2,3x3)>" : RES ? "conv_wino_f32<32t x64,F(2x2,3x3),res>" : "conv_wino_f32<32t x64,F(2x2,3x3)>",
                  flops * k.groups, bytes * k.groups);
     hipLaunchKernelGGL((conv_wino_f32_kernel<NF, RES, WIDE>), dim3(G * k.nbn * k.groups), dim3(256), smem, ctx.stream, k);
