@@ -26,6 +26,35 @@ def stats(db):
         print(f'{short(n):58s} {calls:7d} {tot / 1e3 if tot > 1e7 else tot:12.1f} {avg:10.3f} {pct:6.2f}')
 
 
+def timeline(db, last=70):
+    """The last `last` kernel dispatches in start order: duration and the idle gap since the previous kernel ended
+    (a hipGraph replay of a small-batch step: what the kernels take and what the launches cost in between)."""
+    c = sqlite3.connect(db)
+    rows = None
+    for q in ('select name, start, end from kernels order by start',
+              'select kernel_name, start, end from kernels order by start',
+              'select name, start_timestamp, end_timestamp from kernels order by start_timestamp'):
+        try:
+            rows = list(c.execute(q))
+            break
+        except Exception:
+            continue
+    if rows is None:
+        print('no usable kernels view; tables:', [r[0] for r in c.execute("select name from sqlite_master")])
+        return
+    rows = rows[-last:]
+    print(f'# rocprofv3 --kernel-trace: last {len(rows)} dispatches ({db})')
+    print(f'{"kernel":58s} {"dur_us":>9s} {"gap_us":>9s}')
+    prev_end, tk, tg = None, 0.0, 0.0
+    for n, st, en in rows:
+        gap = 0.0 if prev_end is None else (st - prev_end) / 1e3
+        print(f'{short(n):58s} {(en - st) / 1e3:9.2f} {gap:9.2f}')
+        tk += (en - st) / 1e3
+        tg += max(gap, 0.0)
+        prev_end = en
+    print(f'# kernels {tk:.1f} us, gaps {tg:.1f} us, span {(rows[-1][2] - rows[0][1]) / 1e3:.1f} us')
+
+
 def pmc(dbs):
     for db in dbs:
         c = sqlite3.connect(db)
@@ -144,6 +173,8 @@ def layer_traffic(fetch_db, write_db, layers_json):
 if __name__ == '__main__':
     if sys.argv[1] == 'layer_traffic':
         layer_traffic(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif sys.argv[1] == 'timeline':
+        timeline(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 70)
     elif sys.argv[1] == 'stats':
         stats(sys.argv[2])
     elif sys.argv[1] == 'traffic':

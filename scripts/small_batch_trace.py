@@ -1,0 +1,25 @@
+#!/usr/bin/env python
+"""One small-batch step under hipGraph replay, N times - the command to run under `rocprofv3 --kernel-trace` for the
+per-kernel timeline of the latency plan (scripts/rocprof_summary.py timeline)."""
+import argparse, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from spec_amd.pipeline import SpecPipeline, GraphedPipeline
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--batch', type=int, default=1)
+ap.add_argument('--reps', type=int, default=20)
+ap.add_argument('--plan', default='auto')
+args = ap.parse_args()
+torch.set_grad_enabled(False)
+dev = torch.device('cuda:0')
+cc, hm, _, _ = bench.build_models(dev)
+for m in (cc, hm):
+    m.set_plan(args.plan)
+x, sc, ce, iw, ih = bench.make_inputs(args.batch, dev, 7)
+g = GraphedPipeline(SpecPipeline(cc, hm, grouped=True), x, sc, ce, iw, ih)
+for _ in range(args.reps):
+    g(*g.static_in)
+torch.cuda.synchronize()

@@ -460,7 +460,6 @@ static int ensure_ws(specmi_handle* h, int B, int H, int W) {
     // above on the strength of the old sizes and launch kernels on freed memory
     h->act_elems = 0; h->ws_B = 0;
     for (int i = 0; i < 4; ++i) h->act[i] = nullptr;
-    h->splitk_ws = nullptr; h->zeros = nullptr; h->splitk_floats = 0;
     int rc;
     for (int i = 0; i < 4; ++i)
         if ((rc = dev_alloc(h, elems * 4, (void**)&h->act[i], h->ws_allocs))) return rc;
@@ -481,12 +480,36 @@ static int ensure_ws(specmi_handle* h, int B, int H, int W) {
     if ((rc = dev_alloc(h, (size_t)Bp * 72 * 4, (void**)&h->pj_ws, h->ws_allocs))) return rc;
     HIPCHK(h, hipMemset(h->pf_ws, 0, (size_t)Bp32 * SMPL_KQ * 8 * 4));   // rows 218..223 of the feature operand stay zero
     HIPCHK(h, hipMemset(h->A_ws, 0, (size_t)Bp32 * 288 * 4));
-    // split-K partial tiles of the FC GEMMs (<= 16 slices x 1024 rows x 1024 columns) and a row of zeros
-    h->splitk_floats = (size_t)16 * (Bp < 1024 ? Bp : 1024) * 1024;
-    if ((rc = dev_alloc(h, h->splitk_floats * 4, (void**)&h->splitk_ws, h->ws_allocs))) return rc;
-    if ((rc = dev_alloc(h, 4096 * 4, (void**)&h->zeros, h->ws_allocs))) return rc;
-    HIPCHK(h, hipMemset(h->zeros, 0, 4096 * 4));
     h->ws_B = Bw;
+    return SPECMI_OK;
+}
+
+// split-K workspace (partial tiles + arrival counters), grown on demand and never shrunk.  Growing frees and allocates, which a
+// stream capture forbids: the eager warm-up call of a shape (GraphedPipeline runs two) sizes it, captures find it large enough.
+static int ensure_sk(specmi_handle* h, size_t floats, int ncnt) {
+    if (floats <= h->sk.floats && ncnt <= h->sk.ncnt) return SPECMI_OK;
+    HIPCHK(h, hipDeviceSynchronize());
+    if (floats < h->sk.floats) floats = h->sk.floats;
+    if (ncnt < h->sk.ncnt) ncnt = h->sk.ncnt;
+    floats = (floats + ((size_t)1 << 20) - 1) >> 20 << 20;
+    ncnt = round_up(ncnt < 4096 ? 4096 : ncnt, 4096);
+    // the outgrown buffers stay alive until specmi_destroy: a hipGraph captured earlier (GraphedPipeline at another batch
+    // size) has their addresses baked into its kernel nodes
+    if (h->sk.ws) h->sk_retired.push_back(h->sk.ws);
+    if (h->sk.cnt) h->sk_retired.push_back(h->sk.cnt);
+    h->sk = SkWs{};
+    float* ws = nullptr;
+    unsigned* cnt = nullptr;
+    HIPCHK(h, hipMalloc((void**)&ws, floats * 4));
+    hipError_t e = hipMalloc((void**)&cnt, (size_t)ncnt * 4);
+    if (e == hipSuccess) e = hipMemset(cnt, 0, (size_t)ncnt * 4);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        (void)hipFree(ws);
+        if (cnt) (void)hipFree(cnt);
+        return fail(h, SPECMI_ERR_HIP, "split-K workspace: %s", hipGetErrorString(e));
+    }
+    h->sk.ws = ws; h->sk.floats = floats; h->sk.cnt = cnt; h->sk.ncnt = ncnt;
     return SPECMI_OK;
 }
 
@@ -510,8 +533,12 @@ static int run_fc(specmi_handle* h, const FcW& fc, const float* x, int ldx, int 
         a.force_variant = opt_i(h, "force_conv_variant", 0);
         LaunchCtx ctx{s, &h->prof, label};
         const int S = opt_i(h, "fc_splitk", 1) ? conv_igemm_splitk_plan(a) : 1;
-        if (S > 1 && h->splitk_ws && h->zeros && (size_t)S * nb * fc.Npad <= h->splitk_floats && fc.Npad <= 4096) {
-            LAUNCHCHK(h, launch_conv_igemm_splitk(a, S, h->splitk_ws, fc.scale, h->zeros, ctx), label);   // fc.scale is all ones
+        if (S > 1) {
+            int rc;
+            if ((rc = ensure_sk(h, conv_igemm_sk_ws_floats(a, S, 1), conv_igemm_sk_tiles(a, 1)))) return rc;
+            SkPlan pl;
+            pl.leaves = S;      // flat fold of S slices, the order these GEMMs have had since round 1
+            LAUNCHCHK(h, launch_conv_igemm_sk(a, pl, h->sk, ctx), label);
             continue;
         }
         LAUNCHCHK(h, launch_conv_igemm(a, ctx), label);
@@ -542,6 +569,7 @@ struct OpLaunch {
     int kind = 2;             // 0 stem, 1 maxpool, 2 conv
     ConvArgs a;
     int family = 0;           // conv: 0 implicit GEMM, 1 Winograd, 2 split-bf16 (optional path)
+    int sk = 1;               // latency plan: K slices of the implicit GEMM (1 = the throughput kernel)
     const void* wsplit = nullptr;
     int terms = 0;
     const float *x = nullptr, *w = nullptr, *scale = nullptr, *shift = nullptr;   // stem / maxpool operands
@@ -549,7 +577,7 @@ struct OpLaunch {
 };
 
 static OpLaunch prepare_op(specmi_handle* h, const TrunkOp& op, const float* images, float* feat_out, int b0, int nb,
-                           int Himg, int Wimg) {
+                           int Himg, int Wimg, bool latency = false) {
     auto buf = [&](int idx) -> float* { return idx == -2 ? feat_out : h->act[idx]; };
     OpLaunch L;
     L.kind = op.kind;
@@ -591,11 +619,27 @@ static OpLaunch prepare_op(specmi_handle* h, const TrunkOp& op, const float* ima
             return L;
         }
     }
-    if (c.wino && opt_i(h, "winograd", 1) && conv_wino_supported(a)) {
+    bool wino = c.wino && opt_i(h, "winograd", 1) && conv_wino_supported(a);
+    if (latency && !a.force_variant) {
+        // Latency plan (batch <= 8 by default).  Every choice below is a function of the layer's per-image shape, never of the batch:
+        // an image's bits are the same at batch 1 and 16.  Winograd only where an image alone brings enough 2x2 tiles to
+        // fill its 32-tile rows (layer1 / layer2 at 224^2); layer3 / layer4 (49 / 16 tiles per image, U = 16/9 of the
+        // weight bytes) run the direct kernel over K slices.
+        if (wino && ((a.OH + 1) / 2) * ((a.OW + 1) / 2) < opt_i(h, "latency_wino_min_tiles", 128)) wino = false;
+        if (!wino) L.sk = conv_igemm_sk_slices(a, opt_i(h, "latency_target_wgs", 256), opt_i(h, "latency_min_chunks", 4));
+    }
+    if (wino) {
         a.w = c.wino;
         L.family = 1;
     }
     return L;
+}
+
+// plan: 0 auto (latency up to option "latency_max_batch" = 8 images, throughput beyond: measured per batch size,
+// profiles/r04_b_latency_layers.txt), 1 throughput, 2 latency
+static bool use_latency_plan(specmi_handle* h, int B) {
+    const int plan = opt_i(h, "plan", 0);
+    return plan == 2 || (plan == 0 && B <= opt_i(h, "latency_max_batch", 8));
 }
 
 // partner != nullptr: the same op of a second network, launched together (one grouped launch); the caller has checked
@@ -619,14 +663,33 @@ static int launch_op(specmi_handle* h, const TrunkOp& op, const OpLaunch& L, con
         if (partner) LAUNCHCHK(h, launch_conv_bf16s(partner->a, partner->wsplit, partner->terms, ctx), op.label.c_str());
         return SPECMI_OK;
     }
-    if (L.family == 1) LAUNCHCHK(h, launch_conv_wino(L.a, ctx, partner ? &partner->a : nullptr), op.label.c_str());
-    else LAUNCHCHK(h, launch_conv_igemm(L.a, ctx, partner ? &partner->a : nullptr), op.label.c_str());
+    if (L.sk > 1) {
+        const int groups = partner ? 2 : 1;
+        int rc;
+        SkPlan pl = conv_igemm_sk_plan(L.a, groups, opt_i(h, "latency_target_wgs", 256), opt_i(h, "latency_min_chunks", 4),
+                                       opt_i(h, "latency_fill_wgs", 250));
+        const int fu = opt_i(h, "latency_force_unit", 0);   // tests: 1 leaf / 2 group / 3 whole K per workgroup, whatever the batch
+        if (fu) pl.unit = fu == 1 ? 1 : (fu == 2 ? pl.G : pl.leaves);
+        if ((rc = ensure_sk(h, conv_igemm_sk_ws_floats(L.a, pl.leaves / pl.unit, groups), conv_igemm_sk_tiles(L.a, groups)))) return rc;
+        LAUNCHCHK(h, launch_conv_igemm_sk(L.a, pl, h->sk, ctx, partner ? &partner->a : nullptr), op.label.c_str());
+        return SPECMI_OK;
+    }
+    int rc = L.family == 1 ? launch_conv_wino(L.a, ctx, partner ? &partner->a : nullptr)
+                           : launch_conv_igemm(L.a, ctx, partner ? &partner->a : nullptr);
+    if (rc == (int)hipErrorInvalidValue && partner) {
+        // a grouped launch is refused when the batch's activations pass the 32-bit addressing limit of one launch (the
+        // separate launchers split the batch instead): two launches, same kernels, same bits
+        (void)hipGetLastError();
+        rc = L.family == 1 ? launch_conv_wino(L.a, ctx) : launch_conv_igemm(L.a, ctx);
+        if (!rc) rc = L.family == 1 ? launch_conv_wino(partner->a, ctx) : launch_conv_igemm(partner->a, ctx);
+    }
+    LAUNCHCHK(h, rc, op.label.c_str());
     return SPECMI_OK;
 }
 
 static int exec_op(specmi_handle* h, const TrunkOp& op, const float* images, float* feat_out, int b0, int nb,
-                   int Himg, int Wimg, hipStream_t s) {
-    const OpLaunch L = prepare_op(h, op, images, feat_out, b0, nb, Himg, Wimg);
+                   int Himg, int Wimg, hipStream_t s, bool latency = false) {
+    const OpLaunch L = prepare_op(h, op, images, feat_out, b0, nb, Himg, Wimg, latency);
     return launch_op(h, op, L, nullptr, nb, Himg, Wimg, s);
 }
 
@@ -731,8 +794,9 @@ static int run_trunk(specmi_handle* h, const float* images, int B, int H, int W,
                 if ((rc = exec_op(h, ops[i], images, feat_out, b0, nb, H, W, s))) return rc;
         }
     }
+    const bool lat = use_latency_plan(h, B);
     for (size_t i = first_full; i < ops.size(); ++i)
-        if ((rc = exec_op(h, ops[i], images, feat_out, 0, B, H, W, s))) return rc;
+        if ((rc = exec_op(h, ops[i], images, feat_out, 0, B, H, W, s, lat))) return rc;
     *feat = final_buf == -2 ? feat_out : h->act[final_buf];
     *fh = ch; *fw = cw;
     return SPECMI_OK;
@@ -753,9 +817,16 @@ static int run_trunk_pair(specmi_handle* ha, specmi_handle* hb, const float* img
     plan_trunk(ha, H, W, true, Pa);
     plan_trunk(hb, H, W, true, Pb);
     if (Pa.ops.size() != Pb.ops.size()) return fail(ha, SPECMI_ERR_ARG, "the two trunks have different depths");
+    const bool lat = use_latency_plan(ha, B);   // the first handle's options decide for the pair
     for (size_t i = 0; i < Pa.ops.size(); ++i) {
-        const OpLaunch La = prepare_op(ha, Pa.ops[i], img_a, feat_a, 0, B, H, W);
-        const OpLaunch Lb = prepare_op(hb, Pb.ops[i], img_b, feat_b, 0, B, H, W);
+        const OpLaunch La = prepare_op(ha, Pa.ops[i], img_a, feat_a, 0, B, H, W, lat);
+        OpLaunch Lb = prepare_op(hb, Pb.ops[i], img_b, feat_b, 0, B, H, W, lat);
+        if (La.kind == 2 && Lb.kind == 2 && La.family != 2 && Lb.family != 2 && (Lb.family != La.family || Lb.sk != La.sk)) {
+            // the kernel choice reads per-handle options ("winograd", "latency_*"): the pair follows the first handle
+            Lb.family = La.family; Lb.sk = La.sk;
+            Lb.a.w = La.family == 1 ? Pb.ops[i].c->wino : (Pb.ops[i].fused ? Pb.ops[i].fused->f_w : Pb.ops[i].c->w);
+            if (La.family == 1 && !Lb.a.w) return fail(ha, SPECMI_ERR_ARG, "op %zu: the second trunk has no Winograd filters", i);
+        }
         const TrunkOp &oa = Pa.ops[i], &ob = Pb.ops[i];
         if (La.kind != Lb.kind || La.family != Lb.family || oa.H != ob.H || oa.W != ob.W || oa.OH != ob.OH || oa.OW != ob.OW ||
             (La.kind == 2 && (oa.c->cin != ob.c->cin || oa.c->cout != ob.c->cout || oa.c->k != ob.c->k || oa.c->stride != ob.c->stride ||
@@ -878,6 +949,9 @@ int specmi_destroy(specmi_handle* h) {
     for (auto& r : h->prof.log) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     free_pool(h->ws_allocs);
     free_pool(h->param_allocs);
+    if (h->sk.ws) (void)hipFree(h->sk.ws);
+    if (h->sk.cnt) (void)hipFree(h->sk.cnt);
+    free_pool(h->sk_retired);
     if (h->resize_tab) (void)hipFree(h->resize_tab);
     hrnet_free(h->hrnet);
     delete h;
@@ -1239,8 +1313,24 @@ int specmi_conv2d(specmi_handle* h, const float* x, int B, int H, int W, int Cin
         a.ldo = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.relu = relu;
         a.force_variant = opt_i(h, "force_conv_variant", 0);
         a.wino_variant = opt_i(h, "force_wino_variant", 0);
+        // option "conv2d_sk" (tests): > 1 = that many leaves, -1 = the latency plan's own rule, 0 = the throughput kernel;
+        // "latency_force_unit": 0 = by batch, 1 / 2 / 3 = a leaf / a group / the whole K per workgroup
+        int S = wino ? 0 : opt_i(h, "conv2d_sk", 0);
         if (split && conv_bf16s_supported(a)) lrc = launch_conv_bf16s(a, dsplit, terms, ctx);
-        else lrc = wino ? launch_conv_wino(a, ctx) : launch_conv_igemm(a, ctx);
+        else if (S != 0) {
+            SkPlan pl = conv_igemm_sk_plan(a, 1, opt_i(h, "latency_target_wgs", 256), opt_i(h, "latency_min_chunks", 4),
+                                           opt_i(h, "latency_fill_wgs", 250));
+            if (S > 0) {
+                pl.leaves = S; pl.G = 1;
+                for (int g = 2; g <= 4; ++g)
+                    if (S % g == 0) pl.G = g;
+                pl.unit = 1;
+            }
+            const int fu = opt_i(h, "latency_force_unit", 0);
+            if (fu) pl.unit = fu == 1 ? 1 : (fu == 2 ? pl.G : pl.leaves);
+            if ((rc = ensure_sk(h, conv_igemm_sk_ws_floats(a, pl.leaves / pl.unit, 1), conv_igemm_sk_tiles(a, 1)))) { free_pool(tmp); return rc; }
+            lrc = pl.leaves > 1 ? launch_conv_igemm_sk(a, pl, h->sk, ctx) : launch_conv_igemm(a, ctx);
+        } else lrc = wino ? launch_conv_wino(a, ctx) : launch_conv_igemm(a, ctx);
     }
     hipError_t se = hipStreamSynchronize(s);
     free_pool(tmp);

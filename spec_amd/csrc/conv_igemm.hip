@@ -25,7 +25,20 @@
 //     one chunk ahead: no B traffic through LDS, A-only LDS = 18 KB -> 7 workgroups per CU (+6 %).
 //     The 8-wave 128x128 kernel (HBM-bound expand convs) keeps B staged in LDS as [8][BN][4].
 //   * Variants: two A sources (K = Cin + Cin2: a bottleneck's downsample conv folded into conv3),
-//     split-K over blockIdx.y for the small-M FC GEMMs (fixed-order second-pass reduction).
+//     split-K over blockIdx.y (SPLITK) for small M - the FC GEMMs of every plan and every convolution of the
+//     LATENCY plan (batch <= 8 by default: the reference's own operating point, spec/tester.py:109-151 runs the path at
+//     batch = #detections of a frame, scripts/camcalib_demo.py:95-102 at batch 1): a layer that offers 8-64
+//     output tiles walks K = 1024-4608 on as many CUs while 200 idle; cut into S slices of whole 32-channel
+//     chunks it fills the chip.  Slice z leaves its raw accumulators in a workspace, takes a ticket from the
+//     tile's counter, and the LAST slice to arrive adds the partial tiles in a fixed order (whatever the arrival
+//     order) and runs the usual epilogue - one launch, no second pass.
+//     The k sum of a sliced layer has ONE canonical association, fixed by the layer's shape alone: K is cut into
+//     LEAVES of L chunks (each an MFMA chain from +0), G consecutive leaves fold (left to right, from +0) into a
+//     GROUP, the groups fold into the result.  How much of that tree one workgroup computes is a pure speed
+//     choice made per batch size - a leaf (batch 1: most workgroups), a group, or the whole K (batch 16: no
+//     slabs at all): a workgroup that owns several leaves keeps the leaf / group / result accumulators apart
+//     in registers and adds them at the canonical boundaries (16 v_add per 32x32 block per leaf, < 1 %), the
+//     last arriver folds whatever level the slabs hold.  An image's bits therefore do not depend on the batch.
 //   * The fp32 MFMA holds a SIMD's matrix pipe for 64 cycles but the SIMD has only ~16 issue
 //     slots in that time, shared by all its waves - so everything that is not an MFMA is kept
 //     off the VALU: tile rows are addressed with buffer loads (32-bit per-row offset computed
@@ -67,7 +80,11 @@ struct KArgs {
     int xcd_cols;              // > 0: XCD x owns tile columns [x * xcd_cols, (x + 1) * xcd_cols) and walks all tile rows (see the tile order)
     unsigned mg_ohw, sh_ohw, mg_ow, sh_ow;  // magic multipliers: n / OHW, n / OW for n < 2^31
     int relu;
-    long split_out_stride;   // SPLITK: blockIdx.y = K slice z of nchunks chunks; partial tile z goes to out + z * stride
+    // SPLITK: blockIdx.y = K slice z of nchunks chunks; the raw accumulators of slice z of tile t (t = blockIdx.x + gridDim.x *
+    // blockIdx.z) go to sk_ws[(t * S + z) * BM * BN ..] in accumulator order, sk_cnt[t] counts the slices that have arrived
+    float* sk_ws;
+    unsigned* sk_cnt;
+    int sk_leaf, sk_G, sk_unit;   // chunks per leaf; leaves per group; leaves per workgroup (1, sk_G or all: nchunks = sk_unit * sk_leaf)
     int vec_ok;  // out/res rows are 16-byte aligned: float4 epilogue traffic allowed
     // grouped launch (gridDim.z = 2): blockIdx.z = 1 runs the SAME layer shape of a second network on its own tensors - the
     // two ResNet-50 trunks of the path (CamCalib + SPEC) as one launch per layer: half the launches, and the partially
@@ -91,7 +108,7 @@ constexpr unsigned kOutOfRange = 0x80000000u;  // >= any buffer extent: the load
 
 template <int BM, int BN, int WGM, int WGN, bool IS1X1, int BK, bool DUAL = false, bool SPLITK = false, bool BDIR = false>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KArgs p) {
-    static_assert(!SPLITK || (IS1X1 && !DUAL), "split-K serves the small-M FC GEMMs");
+    static_assert(!SPLITK || BDIR, "split-K exists for the 64x64 kernel that streams its B fragments");
     static_assert(!(DUAL && !IS1X1), "");
     static_assert(!DUAL || IS1X1, "the second A source exists for 1x1 layers only");
     constexpr int LDA = BK + 4;
@@ -200,9 +217,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
 
     f32x4 ra[AI], rb[BI];
     // chunk c = (tap, 32-channel slice); the per-chunk part of every address is scalar
-    auto load_chunk = [&](int c) {
+    const int cbase = SPLITK ? (int)blockIdx.y * p.nchunks : 0;   // first chunk of this workgroup's K slice
+    auto load_chunk = [&](int cl) {
+        const int c = cl + cbase;
         const int tap = IS1X1 ? 0 : c / p.cpc;
-        const int c0 = IS1X1 ? (SPLITK ? c + (int)blockIdx.y * p.nchunks : c) : c - tap * p.cpc;
+        const int c0 = IS1X1 ? c : c - tap * p.cpc;
         unsigned tap_bytes = 0;
         if (!IS1X1) {
             const int ky = tap / p.KW, kx = tap - ky * p.KW;
@@ -210,7 +229,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
         }
         const bool second = DUAL && c >= p.cpc1;   // wave-uniform: chunks past cpc1 read the second source
         const unsigned s_a = (unsigned)((second ? c0 - p.cpc1 : c0) * BK * 4);
-        const unsigned s_b = (unsigned)((SPLITK ? c0 : c) * KQ * p.Npad * 16);
+        const unsigned s_b = (unsigned)(c * KQ * p.Npad * 16);
         if (!TUNE_ABLATE(16)) {
 #pragma unroll
             for (int i = 0; i < AI; ++i) {
@@ -259,7 +278,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
     f32x4 fbq[BDIR ? NQ : 1][TN];
     const unsigned fb_voff = (unsigned)((hh * p.Npad + n0 + wn * (BN / WGN) + l31) * 16);
     auto load_bfrag = [&](int c, int q) {
-        const int ca = SPLITK ? c + (int)blockIdx.y * p.nchunks : c;
+        const int ca = c + cbase;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
             fbq[BDIR ? q : 0][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
@@ -276,13 +295,15 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
     const bool full = (n + 3 < p.Cout) && p.vec_ok;
     f32x4 rr[NP];
 
-    load_chunk(0);
-    if (BDIR) {
+    if constexpr (!SPLITK) {
+        load_chunk(0);
+        if (BDIR) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) load_bfrag(0, q);
+            for (int q = 0; q < NQ; ++q) load_bfrag(0, q);
+        }
+        store_chunk(0);
+        __syncthreads();
     }
-    store_chunk(0);
-    __syncthreads();
 
     // ---- one K chunk, hand-scheduled ---------------------------------------------------------
     // A wave issues in order, and an fp32 MFMA occupies the matrix pipe for 64 cycles while its
@@ -322,7 +343,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
                 if (q == 0 && s == 0) {
                     if (PF) {
                         if (!TUNE_ABLATE(1)) load_chunk(c + 1);
-                    } else if (pres && full) {   // last chunk: fetch the residual rows of the epilogue
+                    } else if (!SPLITK && pres && full) {   // last chunk: fetch the residual rows of the epilogue
 #pragma unroll
                         for (int ps = 0; ps < NP; ++ps) {
                             const int m = m0 + r0 + ps * RPP;
@@ -347,14 +368,149 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
         }
     };
 
-    const int last = p.nchunks - 1;
     TUNE_T(t_loop);
-    for (int c = 0; c < last; ++c) {
-        chunk(c, std::true_type{});
+    if constexpr (!SPLITK) {
+        const int last = p.nchunks - 1;
+        for (int c = 0; c < last; ++c) {
+            chunk(c, std::true_type{});
+            __syncthreads();
+        }
+        chunk(last, std::false_type{});
         __syncthreads();
+    } else {
+        // ---- split-K pipeline: a slice is 2-12 chunks on a CU that holds one or two workgroups - nothing hides a load
+        // but distance.  Operands are fetched TWO chunks ahead (a chunk's MFMAs take ~0.4 us on a lone wave, the Infinity
+        // Cache / HBM answer in 0.7-1 us): two register sets alternate by chunk parity (the loop is unrolled by two so that
+        // the set is a compile-time index), A of chunk c+1 moves from registers into the other LDS stage during chunk c.
+        // Loads past the end of the slice get an out-of-range offset: they return 0 without touching memory.
+        f32x4 ra2[2][AI], fb2[2][NQ][TN];
+        auto sk_load_a = [&](int cl, auto slot) {
+            constexpr int SL = decltype(slot)::value;
+            const bool oob = cl >= p.nchunks;
+            const int c = cl + cbase;
+            const int tap = IS1X1 ? 0 : c / p.cpc;
+            const int c0 = IS1X1 ? c : c - tap * p.cpc;
+            unsigned tap_bytes = 0;
+            if (!IS1X1) {
+                const int ky = tap / p.KW, kx = tap - ky * p.KW;
+                tap_bytes = (unsigned)((ky * p.W + kx) * p.ldx * 4);
+            }
+            const bool second = DUAL && c >= p.cpc1;
+            const unsigned s_a = oob ? 0u : (unsigned)((second ? c0 - p.cpc1 : c0) * BK * 4);
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                unsigned voff = a_voff[i];
+                if (!IS1X1) voff = ((a_mask[i] >> (tap & 31)) & 1u) ? voff + tap_bytes : kOutOfRange;
+                if (DUAL) voff = second ? a_voff2[i] : voff;
+                if (oob) voff = kOutOfRange;
+                if (DUAL) {
+                    ra2[SL][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(second ? x2rs : xrs, voff, s_a, 0));
+                } else {
+                    ra2[SL][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, s_a, 0));
+                }
+            }
+        };
+        auto sk_load_b = [&](int cl, int q, auto slot) {
+            constexpr int SL = decltype(slot)::value;
+            const bool oob = cl >= p.nchunks;
+            const int ca = cl + cbase;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb2[SL][q][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    wrs, oob ? kOutOfRange : fb_voff + (unsigned)(j * 32 * 16), oob ? 0u : (unsigned)((ca * KQ + 2 * q) * p.Npad * 16), 0));
+        };
+        auto sk_chunk = [&](int c, auto par) {
+            constexpr int P = decltype(par)::value;   // == c & 1
+            const float* Ab = As + P * A_STAGE + (wm * (BM / WGM) + l31) * LDA + hh * 4;
+            float* Asn = As + (P ^ 1) * A_STAGE;
+            f32x4 fa[2][TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDA);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1][i][s_], fb2[P][q][j][s_], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s_ == 3) sk_load_b(c + 2, q, par);          // this set's next use is two chunks from now
+                    if (q == 0 && s_ == 0) sk_load_a(c + 2, par);   // (its previous content went to LDS during chunk c - 1)
+                    if (s_ == 1 && q < NQ - 1) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) fa[(q + 1) & 1][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDA + (q + 1) * 8);
+                    }
+                    if (q == NQ - 1) {   // chunk c + 1: registers -> the other stage, spread over the last four steps
+#pragma unroll
+                        for (int t_ = 0; t_ < AI; ++t_)
+                            if ((t_ & 3) == s_) *reinterpret_cast<f32x4*>(&Asn[(a_r + ARS * t_) * LDA + a_kq * 4]) = ra2[P ^ 1][t_];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        const std::integral_constant<int, 0> even{};
+        const std::integral_constant<int, 1> odd{};
+        sk_load_a(0, even);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) sk_load_b(0, q, even);
+        sk_load_a(1, odd);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) sk_load_b(1, q, odd);
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(a_r + ARS * i) * LDA + a_kq * 4]) = ra2[0][i];
+        __syncthreads();
+        // canonical boundaries (file header): leaf chain -> group fold -> result fold, every fold from +0, left to right
+        f32x16 accG[TM][TN], accR[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { accG[i][j][r] = 0.f; accR[i][j][r] = 0.f; }
+        int lc = 0, gl = 0;
+        auto leaf_end = [&]() {
+            if (++lc < p.sk_leaf) return;
+            lc = 0;
+            if (p.sk_unit == 1) return;          // the slab is the leaf itself
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { accG[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.f; }
+            if (++gl < p.sk_G) return;
+            gl = 0;
+            if (p.sk_unit == p.sk_G) return;     // the slab is the group
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { accR[i][j][r] += accG[i][j][r]; accG[i][j][r] = 0.f; }
+        };
+        for (int c = 0; c < p.nchunks; c += 2) {
+            sk_chunk(c, even);
+            __syncthreads();
+            leaf_end();
+            if (c + 1 < p.nchunks) {
+                sk_chunk(c + 1, odd);
+                __syncthreads();
+                leaf_end();
+            }
+        }
+        if (p.sk_unit != 1) {
+            const bool grp_level = p.sk_unit == p.sk_G;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = grp_level ? accG[i][j][r] : accR[i][j][r];
+        }
     }
-    chunk(last, std::false_type{});
-    __syncthreads();
     TUNE_T(t_epi);
 
     // ---- epilogue -------------------------------------------------------------------------
@@ -363,7 +519,129 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
     // 4-byte stores at a row stride; after the transpose every lane moves 16 contiguous bytes.
     // All waves have passed the barrier above, so the A/B stages are free to reuse.
     float* Cs = smem;
-    float* const outp = SPLITK ? pout + (size_t)blockIdx.y * p.split_out_stride : pout;
+    float* const outp = pout;
+    if (SPLITK && gridDim.y > 1) {
+        // Partial tile -> workspace in accumulator order (16 bytes per lane, consecutive lanes consecutive: coalesced), then
+        // the arrival ticket.  Per-XCD L2s are not coherent with each other and a CU's L1 is never refreshed by another CU's
+        // stores, so the hand-off is the write-through form (MI355X_MICROARCH.md, inter-workgroup visibility): sc1 stores
+        // leave the XCD's L2 for memory, every wave drains its stores (vmcnt 0), ONE lane takes the ticket with a relaxed
+        // agent-scope atomic, and the last arriver reads all slabs with sc1 loads (no L1, fresh from the fabric) - no
+        // cache-wide write-back / invalidate (a __threadfence() per workgroup measured 35 us per launch here).
+        const unsigned S = gridDim.y;
+        const size_t tile = (size_t)blockIdx.z * gridDim.x + blockIdx.x;
+        constexpr unsigned SLAB = BM * BN * 4;   // bytes
+        constexpr int NQD = TM * TN * 4;          // 16-byte quads per lane
+        float* const tile_ws = p.sk_ws + tile * S * (size_t)(BM * BN);
+        const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(tile_ws, 0, S * SLAB, 0x00020000);
+        const unsigned soff = (unsigned)blockIdx.y * SLAB;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][r4 * 4 + e];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srs,
+                                                           (unsigned)((((i * TN + j) * 4 + r4) * NT + tid) * 16), soff, /*sc1*/ 16);
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slab stores have left for memory
+        __syncthreads();
+        int* const flag = reinterpret_cast<int*>(smem);     // (the one LDS array: the stages are free after the loop's last barrier)
+        if (tid == 0) {
+            const unsigned ticket = __hip_atomic_fetch_add(p.sk_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last_in = ticket == S - 1;
+            // every slice has arrived: the counter is free again for the next launch / graph replay
+            if (last_in) __hip_atomic_store(p.sk_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = last_in;
+        }
+        __syncthreads();
+        if (!*flag) return;
+        __syncthreads();   // (the flag word is about to be overwritten by the transpose)
+        // the rest of the canonical tree, whichever slice arrived last: leaf slabs fold G at a time into groups and the
+        // groups into the result; group slabs fold into the result.  All slabs of a group (<= 4 x NQD loads) are in flight at once.
+        const unsigned gsz = p.sk_unit == 1 ? (unsigned)p.sk_G : 1u;
+        f32x4 tot[NQD];
+#pragma unroll
+        for (int u = 0; u < NQD; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tot[u][e] = 0.f;
+        auto slab = [&](unsigned z, int u) {
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, (unsigned)((u * NT + tid) * 16), z * SLAB, 16));
+        };
+        if (gsz == 4) {
+            for (unsigned z = 0; z < S; z += 4) {
+                f32x4 v[4][NQD];
+#pragma unroll
+                for (int zz = 0; zz < 4; ++zz)
+#pragma unroll
+                    for (int u = 0; u < NQD; ++u) v[zz][u] = slab(z + zz, u);
+#pragma unroll
+                for (int u = 0; u < NQD; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float tg = 0.f;
+#pragma unroll
+                        for (int zz = 0; zz < 4; ++zz) tg += v[zz][u][e];
+                        tot[u][e] += tg;
+                    }
+            }
+        } else if (gsz > 1) {
+            for (unsigned z = 0; z < S; z += gsz) {
+                f32x4 tg[NQD];
+#pragma unroll
+                for (int u = 0; u < NQD; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) tg[u][e] = 0.f;
+                for (unsigned zz = 0; zz < gsz; ++zz) {
+                    f32x4 v[NQD];
+#pragma unroll
+                    for (int u = 0; u < NQD; ++u) v[u] = slab(z + zz, u);
+#pragma unroll
+                    for (int u = 0; u < NQD; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) tg[u][e] += v[u][e];
+                }
+#pragma unroll
+                for (int u = 0; u < NQD; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) tot[u][e] += tg[u][e];
+            }
+        } else {
+            unsigned z = 0;
+            for (; z + 4 <= S; z += 4) {
+                f32x4 v[4][NQD];
+#pragma unroll
+                for (int zz = 0; zz < 4; ++zz)
+#pragma unroll
+                    for (int u = 0; u < NQD; ++u) v[zz][u] = slab(z + zz, u);
+#pragma unroll
+                for (int zz = 0; zz < 4; ++zz)
+#pragma unroll
+                    for (int u = 0; u < NQD; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) tot[u][e] += v[zz][u][e];
+            }
+            for (; z < S; ++z) {
+                f32x4 v[NQD];
+#pragma unroll
+                for (int u = 0; u < NQD; ++u) v[u] = slab(z, u);
+#pragma unroll
+                for (int u = 0; u < NQD; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) tot[u][e] += v[u][e];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][r4 * 4 + e] = tot[(i * TN + j) * 4 + r4][e];
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -388,6 +666,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaf(a[e], sc[e], sh[e]);
             if (pres) {
+                if (SPLITK) rr[ps] = *reinterpret_cast<const f32x4*>(pres + ((m < p.M) ? (size_t)m * p.ldo + n : (size_t)n));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] += rr[ps][e];
             }
@@ -531,8 +810,7 @@ static void magic_u32(unsigned d, unsigned* mg, unsigned* sh) {
     *sh = L - 32;
 }
 
-static int launch_one(const ConvArgs& a, const LaunchCtx& ctx, const ConvArgs* b = nullptr) {
-    KArgs k;
+static void make_kargs(const ConvArgs& a, const ConvArgs* b, KArgs& k, double* flops, double* bytes) {
     k.x = a.x; k.w = a.w; k.scale = a.scale; k.shift = a.shift; k.res = a.res; k.out = a.out;
     k.g1.x = nullptr; k.g1.w = nullptr; k.g1.scale = nullptr; k.g1.shift = nullptr; k.g1.res = nullptr; k.g1.x2 = nullptr; k.g1.out = nullptr;
     if (b) { k.g1.x = b->x; k.g1.w = b->w; k.g1.scale = b->scale; k.g1.shift = b->shift; k.g1.res = b->res; k.g1.x2 = b->x2; k.g1.out = b->out; }
@@ -548,7 +826,7 @@ static int launch_one(const ConvArgs& a, const LaunchCtx& ctx, const ConvArgs* b
     k.x2_bytes = dual ? (unsigned)((size_t)a.B * a.H2 * a.W2 * a.ldx2 * 4) : 0u;
     k.nbn = 0;
     k.relu = a.relu;
-    k.split_out_stride = 0;
+    k.sk_ws = nullptr; k.sk_cnt = nullptr; k.sk_leaf = 0; k.sk_G = 1; k.sk_unit = 1;
     magic_u32((unsigned)k.OHW, &k.mg_ohw, &k.sh_ohw);
     magic_u32((unsigned)a.OW, &k.mg_ow, &k.sh_ow);
     k.x_bytes = (unsigned)((size_t)a.B * a.H * a.W * a.ldx * 4);
@@ -561,45 +839,26 @@ static int launch_one(const ConvArgs& a, const LaunchCtx& ctx, const ConvArgs* b
                (!a.res || (reinterpret_cast<uintptr_t>(a.res) & 15) == 0) &&
                (!b || (((reinterpret_cast<uintptr_t>(b->out) & 15) == 0) && (!b->res || (reinterpret_cast<uintptr_t>(b->res) & 15) == 0)));
     const double Kd = (double)a.KH * a.KW * a.Cin + (dual ? a.Cin2 : 0);
-    const double flops = 2.0 * (double)M * a.Cout * Kd;
-    const double bytes = 4.0 * ((double)a.B * a.H * a.W * a.Cin + (dual ? (double)M * a.Cin2 : 0.0) +
-                                (double)M * a.Cout * (a.res ? 2.0 : 1.0) + Kd * a.Cout);
+    *flops = 2.0 * (double)M * a.Cout * Kd;
+    *bytes = 4.0 * ((double)a.B * a.H * a.W * a.Cin + (dual ? (double)M * a.Cin2 : 0.0) +
+                    (double)M * a.Cout * (a.res ? 2.0 : 1.0) + Kd * a.Cout);
+}
+
+static int launch_one(const ConvArgs& a, const LaunchCtx& ctx, const ConvArgs* b = nullptr) {
+    KArgs k;
+    double flops, bytes;
+    make_kargs(a, b, k, &flops, &bytes);
+    const int M = k.M;
+    const bool dual = a.x2 != nullptr;
     const bool is1x1 = (a.KH == 1 && a.KW == 1 && a.pad == 0);
     const int v = pick_variant(M, a.Npad, is1x1, a.Cin + (dual ? a.Cin2 : 0), a.force_variant, a.Cout);
     if (dual) return dispatch_dual(v, k, M, ctx, flops, bytes);
     return is1x1 ? dispatch<true>(v, k, M, ctx, flops, bytes) : dispatch<false>(v, k, M, ctx, flops, bytes);
 }
 
-// ---- split-K for the small-M FC GEMMs (CamCalib heads, HMR regressor) ---------------------------------
-// M = batch rows only: a 64x64 tiling gives a few dozen workgroups that each walk the whole K (70 chunks for
-// fc1) - pure latency.  K is cut into S slices (blockIdx.y); slice z writes its raw partial tile to
-// ws[z][M][Npad]; a second launch adds the slices in fixed order (deterministic, batch-invariant) and applies
-// scale / shift / residual / ReLU.
-__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int S, long slice, int M, int Npad,
-                                                            int Cout, const float* __restrict__ scale,
-                                                            const float* __restrict__ shift, const float* res, float* out,
-                                                            int ldo, int relu) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int nq = Npad / 4;
-    if (i >= (long)M * nq) return;
-    const int m = (int)(i / nq), n = (int)(i % nq) * 4;
-    f32x4 acc = *reinterpret_cast<const f32x4*>(ws + (size_t)m * Npad + n);
-    for (int z = 1; z < S; ++z) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(ws + (size_t)z * slice + (size_t)m * Npad + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] += v[e];
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (n + e >= Cout) break;
-        float t = fmaf(acc[e], scale[n + e], shift[n + e]);
-        const size_t o = (size_t)m * ldo + n + e;
-        if (res) t += res[o];
-        if (relu) t = fmaxf(t, 0.f);
-        out[o] = t;
-    }
-}
-
+// ---- split-K: the FC GEMMs of every plan, every convolution of the latency plan (see the file header) -----------------
+// K slices of the FC GEMMs (CamCalib heads, HMR regressor; M = batch rows <= 1024): the rule every plan has used since
+// round 1, so the headline's FC results keep their bits
 int conv_igemm_splitk_plan(const ConvArgs& a) {
     const bool is1x1 = (a.KH == 1 && a.KW == 1 && a.pad == 0 && a.stride == 1);
     const int M = a.B * a.OH * a.OW;
@@ -611,45 +870,80 @@ int conv_igemm_splitk_plan(const ConvArgs& a) {
     return best;
 }
 
-int launch_conv_igemm_splitk(const ConvArgs& a, int S, float* ws, const float* ones, const float* zeros,
-                             const LaunchCtx& ctx) {
-    if (a.Cin % (32 * S) != 0 || a.Npad % 64 != 0 || a.ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(a.x) & 15))
-        return (int)hipErrorInvalidValue;
-    KArgs k;
-    const int M = a.B * a.OH * a.OW;
-    k.x = a.x; k.w = a.w; k.scale = ones; k.shift = zeros; k.res = nullptr; k.out = ws;
-    k.g1.x = nullptr; k.g1.w = nullptr; k.g1.scale = nullptr; k.g1.shift = nullptr; k.g1.res = nullptr; k.g1.x2 = nullptr; k.g1.out = nullptr;
-    k.H = a.H; k.W = a.W; k.ldx = a.ldx;
-    k.OW = a.OW; k.OHW = a.OH * a.OW; k.Cout = a.Npad; k.Npad = a.Npad; k.ldo = a.Npad;
-    k.KH = 1; k.KW = 1; k.stride = 1; k.pad = 0;
-    k.M = M;
-    k.cpc = a.Cin / 32;
-    k.nchunks = k.cpc / S;
-    k.nbn = 0;
-    k.relu = 0;
-    k.x2 = nullptr; k.x2_bytes = 0; k.H2 = k.W2 = k.ldx2 = 0; k.stride2 = 1; k.cpc1 = k.cpc;
-    k.split_out_stride = (long)M * a.Npad;
-    magic_u32((unsigned)k.OHW, &k.mg_ohw, &k.sh_ohw);
-    magic_u32((unsigned)a.OW, &k.mg_ow, &k.sh_ow);
-    k.x_bytes = (unsigned)((size_t)a.B * a.H * a.W * a.ldx * 4);
-    k.w_bytes = (unsigned)((size_t)a.Cin * a.Npad * 4);
-#ifdef SPECMI_TUNE
-    k.ablate = 0; k.tprof = nullptr;
-#endif
-    k.vec_ok = 1;
-    const double flops = 2.0 * (double)M * a.Cout * a.Cin;
-    const double bytes = 4.0 * ((double)M * a.Cin + (double)M * a.Cout * (a.res ? 2.0 : 1.0) + (double)a.Cin * a.Cout);
-    int rc;
-    {
-        ProfScope ps(ctx, "conv_igemm_f32<64x64,2x2,splitK>", flops, bytes);
-        rc = launch_variant<64, 64, 2, 2, true, 32, false, true, true>(k, M, LaunchCtx{ctx.stream, nullptr, nullptr}, "", 0, 0, S);
-        if (rc) return rc;
-        const long n = (long)M * (a.Npad / 4);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx.stream, ws, S,
-                           (long)M * a.Npad, M, a.Npad, a.Cout, a.scale, a.shift, a.res, a.out, a.ldo, a.relu);
-        rc = (int)hipGetLastError();
+// K slices of a convolution in the latency plan.  A function of the layer's PER-IMAGE shape only - never of the batch -
+// so that an image's summation order, and with it every bit of its result, is the same in a batch of 1 and of 16 (and in a
+// grouped launch and a separate one): slices of whole 32-channel chunks, at least `min_chunks` each; the smallest slice
+// count that gives the pair of trunks at batch 1 (2 x tiles) `target_wgs` workgroups, else the largest allowed.
+int conv_igemm_sk_slices(const ConvArgs& a, int target_wgs, int min_chunks) {
+    if (a.Npad % 64 != 0 || a.Cin % 32 != 0 || a.force_variant) return 1;
+    const int nch = a.KH * a.KW * (a.Cin / 32) + (a.x2 ? a.Cin2 / 32 : 0);
+    // K < 512: the unsplit kernel wins at every batch size (measured per layer, profiles/r04_b_latency_layers.txt: a second
+    // slab round trip costs more than walking 8-12 chunks)
+    if (nch < 16) return 1;
+    const int tiles1 = ((a.OH * a.OW + 63) / 64) * (a.Npad / 64);
+    int best = 1;
+    for (int s = 1; s <= nch; ++s) {
+        if (nch % s != 0 || nch / s < min_chunks) continue;
+        best = s;
+        if (2 * tiles1 * s >= target_wgs) break;
     }
-    return rc;
+    return best;
+}
+
+// The canonical tree of a layer (leaves, leaves per group) and how much of it one workgroup computes at THIS batch: the
+// largest unit (fewest slabs to write and fold) that still gives `fill_wgs` workgroups.  The unit changes speed, never bits.
+SkPlan conv_igemm_sk_plan(const ConvArgs& a, int groups, int target_wgs, int min_chunks, int fill_wgs) {
+    SkPlan pl;
+    pl.leaves = conv_igemm_sk_slices(a, target_wgs, min_chunks);
+    pl.G = 1;
+    for (int g = 2; g <= 4; ++g)
+        if (pl.leaves % g == 0) pl.G = g;
+    const long tiles = (long)conv_igemm_sk_tiles(a, groups);
+    if (tiles >= fill_wgs) pl.unit = pl.leaves;
+    else if (tiles * (pl.leaves / pl.G) >= fill_wgs) pl.unit = pl.G;
+    else pl.unit = 1;
+    return pl;
+}
+
+size_t conv_igemm_sk_ws_floats(const ConvArgs& a, int S, int groups) {
+    const size_t tiles = (size_t)((a.B * a.OH * a.OW + 63) / 64) * (a.Npad / 64);
+    return S > 1 ? tiles * S * groups * 64 * 64 : 0;
+}
+int conv_igemm_sk_tiles(const ConvArgs& a, int groups) { return ((a.B * a.OH * a.OW + 63) / 64) * (a.Npad / 64) * groups; }
+
+// One launch, gridDim.y = pl.leaves / pl.unit slabs per tile; sk.ws holds conv_igemm_sk_ws_floats(a, slabs, groups) floats,
+// sk.cnt one zeroed counter per (tile, group) - the kernel leaves them zeroed
+int launch_conv_igemm_sk(const ConvArgs& a, const SkPlan& pl, const SkWs& sk, const LaunchCtx& ctx, const ConvArgs* b) {
+    const int nch = a.KH * a.KW * (a.Cin / 32) + (a.x2 ? a.Cin2 / 32 : 0);
+    const int groups = b ? 2 : 1;
+    if (pl.leaves < 1 || nch % pl.leaves != 0 || pl.G < 1 || pl.leaves % pl.G != 0 || (pl.unit != 1 && pl.unit != pl.G && pl.unit != pl.leaves) ||
+        a.Cin % 32 != 0 || a.Npad % 64 != 0 || a.ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(a.x) & 15))
+        return (int)hipErrorInvalidValue;
+    const int S = pl.leaves / pl.unit;
+    if (S > 1 && (!sk.ws || !sk.cnt || conv_igemm_sk_ws_floats(a, S, groups) > sk.floats || conv_igemm_sk_tiles(a, groups) > sk.ncnt))
+        return (int)hipErrorInvalidValue;
+    if (a.x2 && (a.KH != 1 || a.KW != 1 || a.pad != 0 || a.Cin2 % 32 != 0 || a.ldx2 % 4 != 0 || (reinterpret_cast<uintptr_t>(a.x2) & 15)))
+        return (int)hipErrorInvalidValue;
+    if (b && (b->B != a.B || b->H != a.H || b->W != a.W || b->Cin != a.Cin || b->ldx != a.ldx || b->OH != a.OH || b->OW != a.OW ||
+              b->Cout != a.Cout || b->Npad != a.Npad || b->ldo != a.ldo || b->KH != a.KH || b->KW != a.KW || b->stride != a.stride ||
+              b->pad != a.pad || b->relu != a.relu || (b->res != nullptr) != (a.res != nullptr) || (b->x2 != nullptr) != (a.x2 != nullptr) ||
+              b->H2 != a.H2 || b->W2 != a.W2 || b->ldx2 != a.ldx2 || b->Cin2 != a.Cin2 || b->stride2 != a.stride2 ||
+              (reinterpret_cast<uintptr_t>(b->x) & 15) || (b->x2 && (reinterpret_cast<uintptr_t>(b->x2) & 15))))
+        return (int)hipErrorInvalidValue;
+    size_t img_bytes = (size_t)a.H * a.W * a.ldx * 4;
+    if (a.x2 && (size_t)a.H2 * a.W2 * a.ldx2 * 4 > img_bytes) img_bytes = (size_t)a.H2 * a.W2 * a.ldx2 * 4;
+    const size_t limit = (size_t)1 << 31;
+    if (img_bytes * a.B >= limit || (size_t)nch * 32 * a.Npad * 4 >= limit) return (int)hipErrorInvalidValue;   // small-M path: no batch splitting
+    KArgs k;
+    double flops, bytes;
+    make_kargs(a, b, k, &flops, &bytes);
+    k.sk_leaf = nch / pl.leaves; k.sk_G = pl.G; k.sk_unit = pl.unit;
+    k.nchunks = k.sk_leaf * pl.unit;
+    k.sk_ws = sk.ws; k.sk_cnt = sk.cnt;
+    const bool is1x1 = (a.KH == 1 && a.KW == 1 && a.pad == 0);
+    if (a.x2) return launch_variant<64, 64, 2, 2, true, 32, true, true, true>(k, k.M, ctx, "conv_igemm_f32<64x64,2x2,2src,splitK>", flops, bytes, S);
+    if (is1x1) return launch_variant<64, 64, 2, 2, true, 32, false, true, true>(k, k.M, ctx, "conv_igemm_f32<64x64,2x2,splitK>", flops, bytes, S);
+    return launch_variant<64, 64, 2, 2, false, 32, false, true, true>(k, k.M, ctx, "conv_igemm_f32<64x64,2x2,splitK>", flops, bytes, S);
 }
 
 // b != nullptr: the same layer shape of a second network (its own x / w / scale / shift / res / x2 / out) in the same launch

@@ -85,8 +85,9 @@ struct specmi_handle {
     size_t resize_tab_ints = 0;
     std::vector<int> resize_host;       // host image of the same (kept alive for the async copy)
     int resize_geom[4] = {0, 0, 0, 0};  // H, W, OH, OW the tables were built for
-    float *splitk_ws = nullptr, *zeros = nullptr;   // split-K partial tiles (own allocations: hipMalloc here is graph-unsafe, so done in ensure_ws)
-    size_t splitk_floats = 0;
+    SkWs sk;                            // split-K partial tiles + arrival counters (ensure_sk; never allocated under graph capture:
+                                        // the warm-up call of a shape sizes it)
+    std::vector<void*> sk_retired;      // outgrown split-K buffers, kept until destroy (captured graphs may still name them)
 
     Profiler prof;
 };

@@ -97,10 +97,29 @@ struct ConvArgs {
 // Cin % 32 == 0, Npad % 64 == 0.  Returns hipError as int.
 // b != nullptr: the same layer shape of a SECOND network (own tensors) in the same launch (gridDim.z = 2)
 int launch_conv_igemm(const ConvArgs& a, const LaunchCtx& ctx, const ConvArgs* b = nullptr);
-// small-M 1x1 / FC GEMMs: K slices in parallel + deterministic reduction.  plan() returns the slice count (1 = don't);
-// ws holds S * M * Npad floats, ones / zeros at least Npad floats each.
+// Split-K (conv_igemm.hip header): K slices as gridDim.y of ONE launch; the last slice of a tile to arrive adds the partial
+// tiles in slice order and runs the epilogue (deterministic, batch-invariant).
+struct SkWs {
+    float* ws = nullptr;       // partial tiles: conv_igemm_sk_ws_floats() floats
+    size_t floats = 0;
+    unsigned* cnt = nullptr;   // one arrival counter per (tile, group), zero between launches
+    int ncnt = 0;
+};
+// The canonical k-sum tree of a sliced layer and the share of it one workgroup computes (conv_igemm.hip header)
+struct SkPlan {
+    int leaves = 1;   // K = leaves x L chunks; a leaf is one MFMA chain from +0
+    int G = 1;        // consecutive leaves that fold into a group (the groups fold into the result)
+    int unit = 1;     // leaves per workgroup: 1, G or leaves (= no slabs) - a speed choice, the bits are the same
+};
+// leaves of the FC GEMMs (every plan; 1 = don't split)
 int conv_igemm_splitk_plan(const ConvArgs& a);
-int launch_conv_igemm_splitk(const ConvArgs& a, int S, float* ws, const float* ones, const float* zeros, const LaunchCtx& ctx);
+// leaves of a convolution in the latency plan: depends on the layer's per-image shape only, never on the batch
+int conv_igemm_sk_slices(const ConvArgs& a, int target_wgs, int min_chunks);
+// the same + the unit for batch a.B (groups = 2: grouped launch of two networks)
+SkPlan conv_igemm_sk_plan(const ConvArgs& a, int groups, int target_wgs, int min_chunks, int fill_wgs);
+size_t conv_igemm_sk_ws_floats(const ConvArgs& a, int slabs, int groups);
+int conv_igemm_sk_tiles(const ConvArgs& a, int groups);
+int launch_conv_igemm_sk(const ConvArgs& a, const SkPlan& pl, const SkWs& sk, const LaunchCtx& ctx, const ConvArgs* b = nullptr);
 // pick the tile the launcher would use (for tests / labels)
 const char* conv_igemm_variant(const ConvArgs& a);
 

@@ -284,7 +284,25 @@ class _EngineModule(nn.Module):
             raise ValueError('conv_precision must be 0 (exact fp32), 3 or 6 (bf16 piece products)')
         self.conv_precision = int(terms)
         self._invalidate()
-        self._sig = ('stale',)          # forces the next forward to re-commit with the new option
+        if self._engine is not None:    # re-commit now (a frozen module skips the per-forward signature check)
+            self.commit(self._engine.device, freeze=self._frozen)
+        else:
+            self._sig = ('stale',)
+        return self
+
+    # Execution plan of the trunk (include/specmi.h, option "plan"): 'throughput' = the kernels the batch-256 headline runs
+    # (Winograd + 64x64 / 128x128 implicit GEMM); 'latency' = every convolution cut into K slices that fill the chip at batch
+    # 1-8 (one launch per layer, one canonical summation tree); 'auto' (default) = latency up to 8 images per call.  Within a plan an
+    # image's result is bit-identical whatever the batch size; between plans the last bits differ (contract: 1e-4).
+    PLANS = {'auto': 0, 'throughput': 1, 'latency': 2}
+    plan = 'auto'
+
+    def set_plan(self, plan: str):
+        if plan not in self.PLANS:
+            raise ValueError(f"plan must be one of {tuple(self.PLANS)}")
+        self.plan = plan
+        if self._engine is not None:
+            self._engine.set_option('plan', self.PLANS[plan])    # read at every forward: no re-commit
         return self
 
     def _smpl_model(self):
@@ -304,7 +322,8 @@ class _EngineModule(nn.Module):
             self._engine = Engine(self._kind, device)
         sd = {k: v for k, v in self.state_dict().items()
               if not k.startswith('smpl.') and v.dtype.is_floating_point}
-        self._engine.load(sd, smpl=self._smpl_model(), conv_precision=int(self.conv_precision), **self._options())
+        self._engine.load(sd, smpl=self._smpl_model(), conv_precision=int(self.conv_precision), plan=self.PLANS[self.plan],
+                          **self._options())
         self._tracked = None
         self._sig = self._signature()
         self._frozen = freeze

@@ -76,7 +76,7 @@ class SpecPipeline:
             v = eng.record_views(record)
             angles = (v['cam_vfov'], v['cam_pitch'], v['cam_roll'])
         want_group = images.shape[0] <= 16 if self.grouped == 'auto' else bool(self.grouped)
-        can_group = (want_group and self.overlap is not None and self.hmr.use_cam and cam_in.shape == images.shape and
+        can_group = (want_group and self.hmr.use_cam and cam_in.shape == images.shape and
                      getattr(self.hmr, '_backbone_id', 50) == getattr(self.camcalib, '_backbone_depth', 50) and
                      getattr(self.hmr, 'conv_precision', 0) == 0 and getattr(self.camcalib, 'conv_precision', 0) == 0)
         if can_group:

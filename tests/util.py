@@ -1,4 +1,5 @@
 """Shared builders for the tests (oracle side and GPU side use the same seeded tensors)."""
+import contextlib
 import os
 
 import numpy as np
@@ -63,3 +64,17 @@ def gpu_models(use_cam=True, use_cam_feats=True, device='cuda:0'):
     missing, unexpected = hm.load_state_dict({k: t(v) for k, v in hs.items()}, strict=False)
     assert not unexpected and all(m.startswith('smpl.') for m in missing), (missing, unexpected)
     return cc.to(device).eval(), hm.to(device).eval()
+
+
+@contextlib.contextmanager
+def pinned_plan(plan, *modules):
+    """Run a block with the trunk execution plan of ``modules`` pinned ('throughput' | 'latency' | 'auto').  Bit-identity
+    across batch sizes holds WITHIN a plan; 'auto' (the default) switches to the latency plan at 8 images or fewer."""
+    old = [m.plan for m in modules]
+    for m in modules:
+        m.set_plan(plan)
+    try:
+        yield
+    finally:
+        for m, o in zip(modules, old):
+            m.set_plan(o)
