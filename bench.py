@@ -106,14 +106,18 @@ def make_inputs(B, device, seed):
 # roofline bookkeeping
 # ------------------------------------------------------------------------------------------------
 def pmc_traffic():
-    """HBM bytes per conv launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs,
-    gfx950-corrected by scripts/rocprof_summary.py); None when no summary is committed."""
+    """HBM bytes per conv launch from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950-corrected by
+    scripts/rocprof_summary.py; scripts/gpu_prof.sh regenerates the file and stamps it with the hash of the kernel sources
+    it measured) -> (bytes per launch | None, stale | None): stale = the stamp differs from the kernels this run loads."""
     path = os.path.join(ROOT, 'profiles', 'pmc_traffic_latest.json')
     try:
         with open(path) as f:
-            return json.load(f).get('traffic_bytes_per_launch')
+            d = json.load(f)
+        from spec_amd import _lib
+        stamp = d.get('source_hash')
+        return d.get('traffic_bytes_per_launch'), (stamp is None or stamp != _lib.source_hash()), stamp
     except Exception:
-        return None
+        return None, None, None
 
 
 def executed_flops(e):
@@ -198,10 +202,12 @@ def roofline_from_profile(entries):
     # whole step against both roofs (every kernel of the step, executed FLOPs, algorithmic bytes)
     all_fl = sum(executed_flops(e) for e in entries)
     all_by = sum(e['bytes'] for e in entries)
+    traffic, traffic_stale, traffic_stamp = pmc_traffic()
     return {
         'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(),
-        'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/pmc_traffic_latest.json)',
+        'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
+        'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC passes of scripts/gpu_prof.sh, profiles/pmc_traffic_latest.json)',
+        'traffic_stale': traffic_stale, 'traffic_source_hash': traffic_stamp,
         'measured': 'HIP events on the launch stream around every kernel of a second region of the same K steps run '
                     'single-stream / eager right after the timed region (the timed region replays the step as a '
                     '2-stream hipGraph, where per-kernel events would time co-running kernels); agrees with '
@@ -415,7 +421,13 @@ def main():
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29531')
+        if 'MASTER_PORT' not in os.environ:     # (torch.distributed.run always sets it; a bare single-rank --dist run picks a free one)
+            if world > 1:
+                log('[bench] ERROR: MASTER_PORT is not set for a multi-rank job (launch through torch.distributed.run or `bench.py --gpus N`)')
+                sys.exit(2)
+            with socket.socket() as s_:
+                s_.bind(('127.0.0.1', 0))
+                os.environ['MASTER_PORT'] = str(s_.getsockname()[1])
         dist.init_process_group('nccl', device_id=device, rank=rank, world_size=world)
 
     from spec_amd.pipeline import SpecPipeline, AsyncGather, gather_outputs
@@ -477,6 +489,36 @@ def main():
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 
+    # N > 1 start-up probe (outside the timed region): a common 16-image batch, each rank runs its shard_range slice, one
+    # all-gather - the gathered records must equal the unsharded forward of all 16 images bit for bit (plan pinned: an
+    # image's bits are batch-invariant within a plan)
+    probe_ok = None
+    if use_dist:
+        from spec_amd.pipeline import shard_range
+        px, psc, pce, piw, pih = make_inputs(16, device, 424242)          # same seed on every rank
+        for m in (cc, hm):
+            m.set_plan('throughput')
+        whole = pipe(px, psc, pce, piw, pih)['record'].clone()
+        lo, hi = shard_range(16, rank, world)
+        mine = pipe(px[lo:hi], psc[lo:hi], pce[lo:hi], piw[lo:hi], pih[lo:hi])
+        counts = [shard_range(16, r, world)[1] - shard_range(16, r, world)[0] for r in range(world)]
+        if len(set(counts)) == 1:
+            got = gather_outputs(mine)
+        else:                                    # ragged shards (16 % world != 0): pad to the largest, cut after the gather
+            pad = torch.zeros(max(counts), mine['record'].shape[1], device=device)
+            pad[:hi - lo] = mine['record']
+            full = torch.empty(world * max(counts), pad.shape[1], device=device)
+            dist.all_gather_into_tensor(full, pad)
+            got = torch.cat([full[r * max(counts): r * max(counts) + counts[r]] for r in range(world)], 0)
+        flag = torch.tensor([int(torch.equal(got, whole))], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        probe_ok = bool(flag.item())
+        for m in (cc, hm):
+            m.set_plan('auto')
+        if not probe_ok:
+            log(f'[bench] WARNING rank {rank}: gathered 16-image probe differs from the unsharded forward')
+        del whole, mine, got
+
     for _ in range(args.warmup):
         step()
     if gather is not None:
@@ -526,6 +568,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         ms_nc = float(tt.item()) / args.steps * 1e3
         comm = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(), 'payload': args.gather,
+                'probe_gathered_16_images_equal_unsharded': probe_ok,
                 'record_bytes_per_image': int(out['record'].shape[1] * 4),
                 'sent_bytes_per_image': 2496 if args.gather == 'joints' else int(out['record'].shape[1] * 4),
                 'all_gather_ms_blocking_full_record': round(ag_ms, 3),
@@ -608,7 +651,11 @@ def main():
             from spec_amd.pipeline import GraphedPipeline
             for b in (1, 8):
                 row = {'batch': b}
-                for tag, pp in (('grouped', SpecPipeline(cc, hm, grouped=True)), ('two_streams', SpecPipeline(cc, hm, overlap=True, grouped=False))):
+                for tag, pp, plan in (('grouped', SpecPipeline(cc, hm, grouped=True), 'auto'),
+                                      ('two_streams', SpecPipeline(cc, hm, overlap=True, grouped=False), 'auto'),
+                                      ('grouped_throughput_plan', SpecPipeline(cc, hm, grouped=True), 'throughput')):
+                    for m in (cc, hm):
+                        m.set_plan(plan)
                     g = GraphedPipeline(pp, x[:b].contiguous(), scale[:b].contiguous(), center[:b].contiguous(),
                                         img_w[:b].contiguous(), img_h[:b].contiguous())
                     ins = g.static_in
@@ -623,9 +670,17 @@ def main():
                     torch.cuda.synchronize()
                     row[tag + '_ms'] = round(e0.elapsed_time(e1) / 100, 3)
                     del g
+                for m in (cc, hm):
+                    m.set_plan('auto')
                 ms = row['grouped_ms']
-                row.update({'ms_per_step': ms, 'images_per_s': round(b * 1e3 / ms, 1),
-                            'launch': 'both trunks per layer as one grouped launch, one stream, hipGraph replay (bit-identical to two streams)'})
+                # whole-step executed FLOPs against the fp32 MFMA roof and the weights of both networks against HBM
+                row.update({'ms_per_step': ms, 'images_per_s': round(b * 1e3 / ms, 1), 'plan': 'latency (plan = auto, batch <= 8)',
+                            'speedup_vs_throughput_plan': round(row['grouped_throughput_plan_ms'] / ms, 3),
+                            'algorithmic_TFLOPs': round(b * 2 * TRUNK_GFLOP_PER_IMAGE / ms, 2),
+                            'frac_of_mfma_peak_algorithmic': round(b * 2 * TRUNK_GFLOP_PER_IMAGE / ms / PEAK_FP32_MFMA_TFLOPS, 4),
+                            'launch': 'both trunks per layer as one grouped launch, one stream, hipGraph replay (bit-identical to two '
+                                      'streams); every convolution with K >= 512 as K slices of one launch, the last slice to arrive '
+                                      'folds the canonical sum tree (batch-invariant within the plan)'})
                 small.append(row)
         except Exception as e:
             log('[bench] small-batch latency failed:', repr(e))
@@ -711,6 +766,117 @@ def main():
             del fs, hosts
         except Exception as e:
             log('[bench] e2e_frames measurement failed:', repr(e))
+
+    # ---- demo-shaped line: what a `scripts/spec_demo.py` user runs (camcalib/pano_dataset.py:156-162, scripts/camcalib_demo.py:
+    # 95-129, spec/tester.py:86-88,109-151): CamCalib sees the FULL frame at short side 600 once per frame, SPEC sees the K
+    # crops of that frame with the frame's camera.  1080p frames -> specmi_resize_normalize (600 x 1066) -> CamCalib, batch =
+    # frames -> decode -> K = 8 crops per frame -> SPEC + SMPL.  Informational; `value` above stays the C3 number.
+    demo = None
+    if rank == 0 and not use_dist and not args.no_e2e:
+        try:
+            from spec_amd.pipeline import DemoPipeline, GraphedStep
+            from spec_amd.preprocess import camcalib_transform_batch, resize_output_size
+            from spec_amd.streams import concurrent_stream
+            Hf, Wf, Kdet = 1080, 1920, 8
+            F = max(1, B // Kdet)
+            N = F * Kdet
+            ow6, oh6 = resize_output_size(Wf, Hf, 600)
+            gcpu = torch.Generator().manual_seed(78)
+            hosts = []
+            for _ in range(2):
+                hf = torch.randint(0, 256, (F, Hf, Wf, 3), dtype=torch.uint8, generator=gcpu).pin_memory()
+                cx, cy = torch.rand(N, generator=gcpu) * Wf, torch.rand(N, generator=gcpu) * Hf
+                bw, bh = 150 + torch.rand(N, generator=gcpu) * 250, 300 + torch.rand(N, generator=gcpu) * 500
+                hosts.append((hf, torch.stack([cx, cy, bw, bh], 1).pin_memory(), (torch.arange(N) // Kdet).to(torch.int32).pin_memory()))
+            dp = DemoPipeline(cc, hm)
+            dev_in = [[a.to(device) for a in h_] for h_ in hosts]
+            # (a) CamCalib at 600 x 1066 alone, batch = F frames: per-stage table (HIP events, eager, one stream)
+            cam_in = camcalib_transform_batch(dev_in[0][0], 600)
+            for _ in range(2):
+                cc(cam_in)
+            torch.cuda.synchronize()
+            cc._engine.profile(True)
+            cc._engine.profile_read()
+            n6 = 3
+            t1 = time.perf_counter()
+            for _ in range(n6):
+                cc(cam_in)
+            torch.cuda.synchronize()
+            cam_ms = (time.perf_counter() - t1) / n6 * 1e3
+            ents6 = []
+            for r in cc._engine.profile_read():
+                r['model'] = 'camcalib'
+                r['ms'] /= n6; r['flops'] /= n6; r['bytes'] /= n6; r['launches'] //= n6
+                ents6.append(r)
+            cc._engine.profile(False)
+            st6 = stage_table(ents6)
+            k_ms = sum(e['ms'] for e in ents6)
+            ex_fl = sum(executed_flops(e) for e in ents6)
+            alg_fl = sum(e['flops'] for e in ents6)
+            cam600 = {'input': f'{F} x 3 x {oh6} x {ow6} (1080p -> Resize(600), Pillow-exact on the device)', 'frames': F,
+                      'ms_per_step': round(cam_ms, 3), 'ms_per_frame': round(cam_ms / F, 4), 'kernel_ms': round(k_ms, 3),
+                      'frames_per_s': round(F * 1e3 / cam_ms, 1),
+                      'algorithmic_gflop_per_frame': round(alg_fl / F / 1e9, 2),
+                      'executed_mfma_TFLOPs': round(ex_fl / (k_ms * 1e-3) / 1e12, 2),
+                      'frac_of_mfma_peak_executed': round(ex_fl / (k_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                      'algorithmic_TFLOPs': round(alg_fl / (k_ms * 1e-3) / 1e12, 2),
+                      'final_map': '19 x 34 (ragged: M = F x 646 rows, Winograd rows of 32 tiles half empty at the right edge)',
+                      'stages': st6}
+            del cam_in
+            # (b) the whole demo step, frames resident in HBM, hipGraph replay, CamCalib on a second stream beside the SPEC trunk
+            steps = [GraphedStep(dp, *dev_in[i]) for i in range(2)]
+            for i in range(4):
+                steps[i % 2](*steps[i % 2].static_in)
+            torch.cuda.synchronize()
+            nd = max(6, args.steps // 2)
+            t1 = time.perf_counter()
+            for i in range(nd):
+                steps[i % 2](*steps[i % 2].static_in)
+            torch.cuda.synchronize()
+            res_ms = (time.perf_counter() - t1) / nd * 1e3
+            # (c) the same with every slab uploaded from pinned host memory on a copy stream while the other slab's step runs
+            cs_probe = {}
+            copy_stream = concurrent_stream(device, lambda: steps[0](*steps[0].static_in), probe=cs_probe)
+            ready = [torch.cuda.Event() for _ in range(2)]
+            done = [None, None]
+            main = torch.cuda.current_stream(device)
+
+            def submit(i, host):
+                with torch.cuda.stream(copy_stream):
+                    if done[i] is not None:
+                        copy_stream.wait_event(done[i])            # the replay that last read this slab has finished
+                    for dst, src in zip(steps[i].static_in, host):
+                        dst.copy_(src, non_blocking=True)
+                    ready[i].record(copy_stream)
+                main.wait_event(ready[i])
+                steps[i].graph.replay()
+                ev = torch.cuda.Event()
+                ev.record(main)
+                done[i] = ev
+            for i in range(4):
+                submit(i % 2, hosts[i % 2])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(nd):
+                submit(i % 2, hosts[i % 2])
+            torch.cuda.synchronize()
+            up_ms = (time.perf_counter() - t1) / nd * 1e3
+            slab_mb = hosts[0][0].numel() / 1e6
+            demo = {'frame': f'{Wf}x{Hf} uint8 RGB', 'frames_per_step': F, 'detections_per_frame': Kdet, 'crops_per_step': N,
+                    'frames_per_s': round(F * 1e3 / up_ms, 1), 'crops_per_s': round(N * 1e3 / up_ms, 1), 'ms_per_step': round(up_ms, 3),
+                    'frames_resident_in_hbm': {'ms_per_step': round(res_ms, 3), 'frames_per_s': round(F * 1e3 / res_ms, 1)},
+                    'overlap': round(res_ms / up_ms, 4), 'h2d_MB_per_step': round(slab_mb, 1),
+                    'h2d_GBps_sustained_while_overlapped': round(slab_mb / up_ms, 2), 'copy_stream_probe': cs_probe,
+                    'sum_of_parts_ms': round(cam_ms + ms_per_step / 2, 3),
+                    'camcalib_at_600': cam600,
+                    'flow': 'pinned host slab -> copy stream -> 2 alternating device slabs (each the static input of its own hipGraph) -> '
+                            'specmi_resize_normalize x F -> CamCalib (batch F, second stream) || specmi_crop_normalize_batch -> SPEC '
+                            'trunk -> join -> regressor head with the frame camera of every crop -> SMPL -> projection',
+                    'note': 'frames/s of the configuration scripts/spec_demo.py runs; overlap = resident / uploaded step time; '
+                            'sum_of_parts = CamCalib-at-600 alone + half the C3 step (SPEC trunk + heads of 256 crops)'}
+            del steps, dev_in, hosts
+        except Exception as e:
+            log('[bench] e2e_demo measurement failed:', repr(e))
 
     # ---- labelled secondary line: the plain 1x1 convolutions as bf16 piece products on the bf16 matrix cores ----------
     # NOT `value` (which is exact fp32 MFMA arithmetic): a different algorithm for the same contractions, reported with its
@@ -800,7 +966,7 @@ def main():
                        'streams': 1 if args.no_overlap else 2, 'launch': launch_mode,
                        'parallelism': (f'images sharded over {n_gpus} GPUs (one process per GPU), 1 asynchronous RCCL '
                                        f'all-gather of the packed records per step') if n_gpus > 1 else 'single GPU'},
-            'roofline': roof, 'cpu_baseline': cpu, 'sustained': sustained, 'c2': c2, 'small_batch': small, 'pcie': pcie, 'e2e_frames': e2e, 'split_bf16': split, 'comm': comm,
+            'roofline': roof, 'cpu_baseline': cpu, 'sustained': sustained, 'c2': c2, 'small_batch': small, 'pcie': pcie, 'e2e_frames': e2e, 'e2e_demo': demo, 'split_bf16': split, 'comm': comm,
             'stages': stages,
         }
         print(json.dumps(line), flush=True)

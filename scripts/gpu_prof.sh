@@ -30,6 +30,17 @@ if [ "$WHAT" = "pmc" ] || [ "$WHAT" = "all" ]; then
   pass write WRITE_SIZE
   cd $R
   python scripts/rocprof_summary.py traffic $(find $OUT/pmc_${TAG}_fetch $OUT/pmc_${TAG}_write -name "*.db") > $OUT/${TAG}_pmc_traffic.json 2>&1
+  # stamp with the hash of the kernel sources these counters were measured on (bench.py: roofline.traffic_stale)
+  python - "$OUT/${TAG}_pmc_traffic.json" <<'PY'
+import json, sys, time
+sys.path.insert(0, '.')
+from spec_amd import _lib
+d = json.load(open(sys.argv[1]))
+d['source_hash'] = _lib.source_hash()
+d['command'] = 'scripts/gpu_prof.sh: bench.py --steps 3 --warmup 1 --no-overlap --no-graph under rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes)'
+json.dump(d, open(sys.argv[1], 'w'), indent=1)
+PY
+  cp $OUT/${TAG}_pmc_traffic.json $OUT/pmc_traffic_latest.json
   python - "$OUT/${TAG}_pmc_traffic.json" <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1]))

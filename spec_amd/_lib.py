@@ -11,6 +11,24 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SPECMI_LIB') or os.path.join(_HERE, 'lib', 'libspecmi.so')   # SPECMI_LIB: an alternative build (A/B runs)
 
+
+
+def source_hash() -> str:
+    """sha256 (16 hex digits) over the kernel sources the library is built from (spec_amd/csrc/*, include/specmi.h) - the
+    stamp measured artefacts carry (profiles/pmc_traffic_latest.json), so that a number measured on other kernels is
+    recognisable as stale.  Sources, not the binary: a rebuild on another box must not change it."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, 'csrc')
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith(('.hip', '.h')):
+            with open(os.path.join(csrc, name), 'rb') as f:
+                h.update(name.encode() + b'\0' + f.read())
+    with open(os.path.join(os.path.dirname(_HERE), 'include', 'specmi.h'), 'rb') as f:
+        h.update(b'specmi.h\0' + f.read())
+    return h.hexdigest()[:16]
+
+
 OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_MISSING = 0, 1, 2, 3, 4
 MODEL_CAMCALIB, MODEL_HMR, MODEL_SMPL = 0, 1, 2
 

@@ -94,11 +94,14 @@ __global__ void __launch_bounds__(256) crop_normalize_kernel(const unsigned char
                                                               float* __restrict__ out, unsigned char* __restrict__ raw,
                                                               float* __restrict__ bbox_scale,
                                                               float* __restrict__ bbox_center,
-                                                              const int* __restrict__ frame_of, size_t frame_stride) {
+                                                              const int* __restrict__ frame_of, size_t frame_stride, int nframes) {
     __shared__ float lut[3][256];
     __shared__ int2 tabx[TABLE ? kTabX : 1], taby[TABLE ? kTabY : 1];
     const int d = blockIdx.y, t = threadIdx.x;
-    if (frame_of) frame += (size_t)frame_of[d] * frame_stride;   // batched: crop d is cut from frame frame_of[d] of a slab of equal-sized frames
+    // batched: crop d is cut from frame frame_of[d] of a slab of equal-sized frames.  The index comes from caller memory the host
+    // side cannot check without a synchronisation: a stale / negative / too large value is clamped into the slab (a wrong crop,
+    // never an out-of-bounds read); spec_amd.preprocess.crop_detections_batch rejects it while the index is still on the host
+    if (frame_of) frame += (size_t)min((unsigned)max(frame_of[d], 0), (unsigned)(nframes - 1)) * frame_stride;
     {
         const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
 #pragma unroll
@@ -163,9 +166,9 @@ __global__ void __launch_bounds__(256) crop_normalize_kernel(const unsigned char
 template <bool WIDE, bool TABLE>
 static void crop_normalize_go(dim3 grid, hipStream_t st, const unsigned char* frame, int H, int W, const float* bboxes, float scale,
                               int S, float* out, unsigned char* raw, float* bbox_scale, float* bbox_center, const int* frame_of,
-                              size_t frame_stride) {
+                              size_t frame_stride, int nframes) {
     hipLaunchKernelGGL((crop_normalize_kernel<WIDE, TABLE>), grid, dim3(256), 0, st, frame, H, W, bboxes, scale, S, out, raw, bbox_scale,
-                       bbox_center, frame_of, frame_stride);
+                       bbox_center, frame_of, frame_stride, nframes);
 }
 
 int launch_crop_normalize(const unsigned char* frame, int H, int W, const float* bboxes, int n, float scale, int S,
@@ -178,7 +181,8 @@ int launch_crop_normalize(const unsigned char* frame, int H, int W, const float*
     const bool wide = W >= 2 && (size_t)H * W * 3 >= 8, table = S <= kTabX;
     auto go = wide ? (table ? crop_normalize_go<true, true> : crop_normalize_go<true, false>)
                    : (table ? crop_normalize_go<false, true> : crop_normalize_go<false, false>);
-    go(grid, ctx.stream, frame, H, W, bboxes, scale, S, out, raw, bbox_scale, bbox_center, frame_of, (size_t)H * W * 3);
+    if (frame_of && nframes < 1) return (int)hipErrorInvalidValue;
+    go(grid, ctx.stream, frame, H, W, bboxes, scale, S, out, raw, bbox_scale, bbox_center, frame_of, (size_t)H * W * 3, nframes);
     return (int)hipGetLastError();
 }
 

@@ -78,7 +78,9 @@ class FrameStream:
     def submit(self, frames_host: torch.Tensor, boxes_host: torch.Tensor, fidx_host: torch.Tensor):
         """Enqueue one step on frames that sit in (pinned) host memory.  Returns the step's outputs (device tensors; with a
         captured graph: its static outputs, valid until the next submit).  The host buffers may be refilled once
-        ``uploaded(slot)`` / ``drain()`` says the copy has finished - or simply use one pinned set per slot."""
+        ``uploaded()`` / ``drain()`` says the copy has finished - or simply use one pinned set per slot."""
+        if fidx_host.numel() and (int(fidx_host.min()) < 0 or int(fidx_host.max()) >= self.F):
+            raise ValueError(f'frame_index values must lie in [0, {self.F})')     # checked while the index is on the host
         i = self.turn
         self.turn = (i + 1) % len(self.slabs)
         main = torch.cuda.current_stream(self.device)
@@ -97,6 +99,15 @@ class FrameStream:
         ev.record(main)
         self.free[i] = ev
         return self.step(self.x, self.sc, self.ce, self.img_w, self.img_h)
+
+    def uploaded(self, slot: int = None, wait: bool = False) -> bool:
+        """Has the host->device copy of the step submitted into ``slot`` (default: the most recent submit) finished, i.e.
+        may its host buffers be refilled?  ``wait=True`` blocks until it has."""
+        i = (self.turn - 1) % len(self.slabs) if slot is None else slot
+        if wait:
+            self.ready[i].synchronize()
+            return True
+        return bool(self.ready[i].query())
 
     def drain(self):
         torch.cuda.synchronize(self.device)

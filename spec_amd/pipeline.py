@@ -159,6 +159,89 @@ class GraphedPipeline:
         return self.static_outs[i]
 
 
+class DemoPipeline:
+    """The path as the reference's demo runs it (``scripts/spec_demo.py``): CamCalib sees the FULL frame at short side 600
+    (``camcalib/pano_dataset.py:156-162``, ``scripts/camcalib_demo.py:95-129``) once per frame, SPEC sees the K person crops of
+    that frame with the frame's camera (``spec/tester.py:86-88,109-151``).  The reference does this as two processes joined by
+    pickle files, one frame and one small batch at a time; here a slab of F equal-sized frames is one step:
+
+        frames (F,H,W,3) uint8 in HBM --specmi_resize_normalize x F--> (F,3,600,W') --CamCalib, batch F--> decode -> R, K (F)
+                                      \--specmi_crop_normalize_batch--> (N,3,224,224) --SPEC trunk--> head(R[frame], K[frame]) -> SMPL
+
+    CamCalib runs on a second stream beside the SPEC trunk (both are MFMA-bound; the join is the regressor head, which needs the
+    camera).  Everything is enqueued without a host synchronisation, so the step can be captured into a hipGraph."""
+
+    def __init__(self, camcalib, hmr, min_size: int = 600, crop_size: int = 224, overlap: bool = True):
+        self.camcalib, self.hmr, self.min_size, self.crop_size, self.overlap = camcalib, hmr, int(min_size), int(crop_size), overlap
+        self._side = {}
+
+    @torch.no_grad()
+    def __call__(self, frames_u8, boxes, frame_index, record: torch.Tensor = None) -> Dict[str, torch.Tensor]:
+        """frames_u8 (F,H,W,3) uint8 device slab; boxes (N,4) [cx, cy, w, h] device; frame_index (N,) int32 device."""
+        from .preprocess import camcalib_transform_batch, crop_detections_batch
+        device = frames_u8.device
+        F, H, W = frames_u8.shape[:3]
+        N = boxes.shape[0]
+        eng = self.hmr.engine(device)
+        angles = None
+        fh = torch.full((F,), float(H), device=device)
+        fw = torch.full((F,), float(W), device=device)
+
+        def cam_side():
+            cam_in = camcalib_transform_batch(frames_u8, self.min_size)
+            logits = self.camcalib(cam_in)
+            return cam_utils.decode_camera(logits[0], logits[1], logits[2], img_h=fh, img_w=fw)
+
+        main = torch.cuda.current_stream(device)
+        if self.overlap:
+            if device not in self._side:
+                self._side[device] = torch.cuda.Stream(device=device)
+            side = self._side[device]
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                cam = cam_side()
+        crops = crop_detections_batch(frames_u8, frame_index, boxes, scale=1.0, crop_size=self.crop_size)
+        feat = eng.trunk(crops['inp_images'])
+        if self.overlap:
+            main.wait_stream(side)
+            for v in cam.values():
+                if v is not None:
+                    v.record_stream(main)
+        else:
+            cam = cam_side()
+        fi = frame_index.long()
+        R, K = cam['cam_rotmat'].index_select(0, fi), cam['cam_intrinsics'].index_select(0, fi)   # the frame's camera for each of its crops
+        img_w = torch.full((N,), float(W), device=device)
+        img_h = torch.full((N,), float(H), device=device)
+        out = dict(eng.hmr_regress(feat, R, K, crops['bbox_scale'], crops['bbox_center'], img_w, img_h, record=record))
+        out.update({'cam_vfov': cam['vfov'], 'cam_pitch': cam['pitch'], 'cam_roll': cam['roll'], 'cam_f_pix': cam['f_pix'],
+                    'cam_rotmat': cam['cam_rotmat'], 'cam_intrinsics': cam['cam_intrinsics'], 'bbox_scale': crops['bbox_scale'],
+                    'bbox_center': crops['bbox_center']})
+        return out
+
+
+class GraphedStep:
+    """Any no-host-sync step ``fn(*tensors) -> dict`` captured once into a hipGraph and replayed; inputs are copied into static
+    buffers unless they already are those buffers (``static_in``), outputs are the static output tensors."""
+
+    def __init__(self, fn, *inputs, warmup: int = 2):
+        self.static_in = [t.clone() for t in inputs]
+        for _ in range(warmup):
+            fn(*self.static_in)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+            self.static_out = fn(*self.static_in)
+
+    @torch.no_grad()
+    def __call__(self, *inputs):
+        for dst, src in zip(self.static_in, inputs):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+        self.graph.replay()
+        return self.static_out
+
+
 def shard_range(total: int, rank: int, world: int):
     """Contiguous rank-major image slice [lo, hi) of a global batch (config 4: 2048 -> 256 per GPU).
     Remainders go to the lowest ranks, so any total / world is covered exactly once."""

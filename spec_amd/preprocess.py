@@ -67,10 +67,16 @@ def crop_detections_batch(frames_u8, frame_index, dets, scale: float = 1.0, crop
         raise ValueError('dets must be (n,4) [cx, cy, w, h]')
     n = boxes.shape[0]
     fidx = frame_index if isinstance(frame_index, torch.Tensor) else torch.as_tensor(frame_index)
+    F, H, W = frames_u8.shape[:3]
+    if fidx.device.type == 'cpu' and fidx.numel():
+        # still on the host: check the range here (the kernel clamps what reaches it - a wrong crop instead of an
+        # out-of-bounds read - but cannot report it)
+        lo, hi = int(fidx.min()), int(fidx.max())
+        if lo < 0 or hi >= F:
+            raise ValueError(f'frame_index values must lie in [0, {F}), got [{lo}, {hi}]')
     fidx = fidx.to(device=dev, dtype=torch.int32).contiguous()
     if fidx.shape != (n,):
         raise ValueError('frame_index must have one entry per detection')
-    F, H, W = frames_u8.shape[:3]
     img, sc, ce = _crop_outputs(out, n, crop_size, dev)
     if n > 0:
         _lib.check(eng.h, eng.lib.specmi_crop_normalize_batch(eng.h, _ptr(frames_u8), F, H, W, _ptr(fidx), _ptr(boxes), n,
@@ -150,3 +156,24 @@ def camcalib_transform(frame_rgb_u8, min_size: int = 600, return_raw: bool = Fal
     raw = torch.empty(oh, ow, 3, device=eng.device, dtype=torch.uint8) if return_raw else None
     _lib.check(eng.h, eng.lib.specmi_resize_normalize(eng.h, _ptr(frame), H, W, oh, ow, _ptr(out), _ptr(raw), eng._stream()))
     return (out, raw) if return_raw else out
+
+
+@torch.no_grad()
+def camcalib_transform_batch(frames_u8, min_size: int = 600, out=None):
+    """``camcalib_transform`` for a slab of F equal-sized frames: (F,H,W,3) uint8 device -> (F,3,oh,ow) fp32, one
+    ``specmi_resize_normalize`` launch per frame into ONE batch tensor (CamCalib then runs once on all F frames instead of once
+    per frame, ``scripts/camcalib_demo.py:95-102``); each frame's pixels are bit-identical to the single-frame call."""
+    if not isinstance(frames_u8, torch.Tensor) or frames_u8.device.type != 'cuda':
+        raise RuntimeError('camcalib_transform_batch needs a device tensor (no CPU path in spec_amd)')
+    if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.shape[3] != 3 or not frames_u8.is_contiguous():
+        raise ValueError('frames must be a contiguous (F,H,W,3) uint8 RGB slab')
+    eng = _engine(frames_u8.device)
+    F, H, W = frames_u8.shape[:3]
+    ow, oh = resize_output_size(W, H, min_size)
+    if out is None:
+        out = torch.empty(F, 3, oh, ow, device=eng.device, dtype=torch.float32)
+    elif tuple(out.shape) != (F, 3, oh, ow) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError(f'out must be a contiguous (F,3,{oh},{ow}) fp32 tensor')
+    for f in range(F):
+        _lib.check(eng.h, eng.lib.specmi_resize_normalize(eng.h, _ptr(frames_u8[f]), H, W, oh, ow, _ptr(out[f]), None, eng._stream()))
+    return out

@@ -131,14 +131,21 @@ class SPECTester:
     def run_on_image_folder(self, image_folder, detections, output_path, output_img_folder, bbox_scale=1.0):
         """``spec/tester.py:90-163`` with the per-frame loop flattened: frames are decoded ahead on host threads, uploaded
         from pinned memory without blocking, their detections are cropped on the device straight into ONE batch buffer,
-        and the model runs once per ``args.frame_batch`` crops (default 256) instead of once per frame.  An image's outputs
-        do not depend on the batch it travels in (every kernel of the path has a fixed summation order), so the per-frame
-        ``spec_results/<stem>.pkl`` files are bit-identical to ``frame_batch=1``, the reference's own structure."""
+        and the model runs once per ``args.frame_batch`` crops (default 256) instead of once per frame.  Within one execution
+        plan (``args.plan``: 'throughput' | 'latency' | 'auto', see ``spec_amd.modules._EngineModule.set_plan``) an image's
+        outputs do not depend on the batch it travels in (every kernel of the path has a fixed summation order), so with the
+        plan pinned the per-frame ``spec_results/<stem>.pkl`` files are bit-identical to ``frame_batch=1``, the reference's
+        own structure.  Default: 'throughput' when frames are batched, 'auto' (the latency plan for up to 8 detections) for
+        one forward per frame - last bits then differ between the two settings (contract: 1e-4).
+        Decode-ahead is bounded: at most 2 x ``args.decode_threads`` decoded frames wait in host memory (the reference holds
+        one frame at a time; an unbounded queue would keep a whole video folder in RAM when decoding outruns the GPU)."""
+        from collections import deque
         from concurrent.futures import ThreadPoolExecutor
         image_file_names = list_images(image_folder)
         res = self.model_cfg.DATASET.IMG_RES
         cap = max(1, int(getattr(self.args, 'frame_batch', 256) or 1))
         per_frame = cap <= 1                                             # the reference's structure: one forward per frame
+        self.model.set_plan(getattr(self.args, 'plan', None) or ('auto' if per_frame else 'throughput'))
         dev = self.device
         todo = [(i, f) for i, f in enumerate(image_file_names) if len(detections[i]) >= 1]
         if not todo:
@@ -168,8 +175,22 @@ class SPECTester:
                     joblib.dump({key: v[k0:k0 + n].copy() for key, v in output.items()}, save_f)
             k, pending = 0, []
 
-        with ThreadPoolExecutor(max_workers=int(getattr(self.args, 'decode_threads', 4) or 1)) as ex:
-            for (img_idx, img_fname), rgb in zip(todo, ex.map(_read_rgb, [f for _, f in todo])):   # decoded ahead, in order
+        nthreads = int(getattr(self.args, 'decode_threads', 4) or 1)
+
+        def decoded(ex):
+            """(todo entry, RGB array) in order, at most 2 x nthreads frames decoded ahead of the consumer"""
+            window, it = deque(), iter(todo)
+            for entry in it:
+                window.append((entry, ex.submit(_read_rgb, entry[1])))
+                if len(window) >= 2 * nthreads:
+                    e, fut = window.popleft()
+                    yield e, fut.result()
+            while window:
+                e, fut = window.popleft()
+                yield e, fut.result()
+
+        with ThreadPoolExecutor(max_workers=nthreads) as ex:
+            for (img_idx, img_fname), rgb in decoded(ex):
                 dets = np.asarray(detections[img_idx], np.float32).reshape(-1, 4)
                 n = len(dets)
                 if k + n > cap:

@@ -185,8 +185,9 @@ def generate(OUT, upstream=False):
     return sorted(f for f in os.listdir(OUT) if f.endswith('.npz'))
 
 
-def compare(new_dir, old_dir, files, values=True):
-    """Per array: max |new - committed| and that over max |committed|.  Returns (worst relative deviation, problems)."""
+def compare(new_dir, old_dir, files, values=True, records=None):
+    """Per array: max |new - committed| and that over max |committed|.  Returns (worst relative deviation, problems);
+    ``records`` (a list) receives one dict per array for the machine-readable report."""
     worst, problems = 0.0, []
     print(f'{"file":24s} {"array":22s} {"shape":18s} {"max abs dev":>12s} {"max rel dev":>12s}')
     for f in files:
@@ -212,6 +213,9 @@ def compare(new_dir, old_dir, files, values=True):
             if y.dtype.kind in 'iub' and dev != 0:
                 problems.append(f'{f}:{k}: integer / index array differs')
             worst = max(worst, rel)
+            if records is not None:
+                records.append({'file': f, 'array': k, 'shape': list(x.shape), 'dtype': str(y.dtype), 'max_abs_dev': dev, 'max_rel_dev': rel,
+                                'exact_required': y.dtype.kind in 'iub'})
             if dev != 0 or x.size > 1:
                 print(f'{f:24s} {k:22s} {str(x.shape):18s} {dev:12.3e} {rel:12.3e}')
     return worst, problems
@@ -245,13 +249,37 @@ def check_opencv():
     return worst
 
 
+def package_versions(names=('pare', 'smplx', 'loguru', 'opencv-python', 'torch', 'numpy', 'scipy', 'Pillow')):
+    """{distribution: version | None} of what this run could have bound (importlib.metadata; a source checkout on
+    PYTHONPATH, like pare's, reports 'path:<dir>')."""
+    import importlib
+    import importlib.metadata as md
+    out = {}
+    for n in names:
+        try:
+            out[n] = md.version(n)
+        except Exception:                           # noqa: BLE001
+            mod = {'opencv-python': 'cv2', 'Pillow': 'PIL'}.get(n, n)
+            try:
+                m = importlib.import_module(mod)
+                out[n] = getattr(m, '__version__', None) or 'path:' + os.path.dirname(getattr(m, '__file__', '') or '')
+            except Exception:                       # noqa: BLE001
+                out[n] = None
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument('--upstream', action='store_true', help='bind the real pare / smplx / loguru where they import')
     ap.add_argument('--selfcheck', action='store_true', help='regenerate over the shim into a temp dir and diff (must be 0)')
     ap.add_argument('--write', action='store_true', help='with --upstream / --selfcheck: replace the committed fixtures')
     ap.add_argument('--data-root', default=None, help='directory holding the reference data/ tree (real SMPL assets)')
-    ap.add_argument('--tolerance', type=float, default=1e-4, help='relative deviation reported as a failure (--upstream)')
+    ap.add_argument('--tolerance', type=float, default=1e-5,
+                    help='--upstream: relative deviation of a floating-point array above which the run fails (index tables, uint8 '
+                         'crops and the OpenCV checks must be exact)')
+    ap.add_argument('--report', default=None, metavar='pin.json',
+                    help='write the machine-readable pin report: bound leaves + package versions, per-array max abs / rel '
+                         'deviation, OpenCV grey-level deviation, verdict')
     args = ap.parse_args()
     if not (args.upstream or args.selfcheck):
         generate(OUT_DIR)
@@ -275,8 +303,10 @@ def main():
         if args.upstream and 'upstream' not in bound.values():
             print('NOTE: none of pare / smplx / loguru is importable here - every leaf is still the shim, so this run is the '
                   'self-check.  Install them (see the module docstring) and re-run to pin the upstream leaves.')
-        worst, problems = compare(new_dir, OUT_DIR, files, values=args.data_root is None)
+        records = []
+        worst, problems = compare(new_dir, OUT_DIR, files, values=args.data_root is None, records=records)
         print(f'worst relative deviation over all arrays: {worst:.3e}   leaves: {bound}')
+        cv_dev = None
         if args.upstream:
             cv_dev = check_opencv()
             if cv_dev:
@@ -288,7 +318,20 @@ def main():
                 shutil.copy(os.path.join(new_dir, f), os.path.join(OUT_DIR, f))
             print('committed fixtures replaced')
         exact = args.selfcheck or 'upstream' not in bound.values()
-        if problems or (exact and worst != 0.0) or (not exact and worst > args.tolerance):
+        failed = bool(problems or (exact and worst != 0.0) or (not exact and worst > args.tolerance))
+        if args.report:
+            import json
+            rep = {'mode': 'upstream' if args.upstream else 'selfcheck', 'leaves': bound, 'packages': package_versions(),
+                   'pinned_upstream': sorted(k for k, v in bound.items() if v == 'upstream'),
+                   'tolerance_fp_rel': 0.0 if exact else args.tolerance, 'integer_and_byte_arrays': 'exact',
+                   'worst_rel_dev': worst, 'arrays': records,
+                   'opencv': {'checked': cv_dev is not None, 'max_grey_level_dev': cv_dev},
+                   'data_root': args.data_root or 'stand-in tree (synthetic SMPL model in the official pickle format)',
+                   'problems': problems, 'pass': not failed}
+            with open(args.report, 'w') as f:
+                json.dump(rep, f, indent=1)
+            print(f'pin report written to {args.report}: pass = {not failed}')
+        if failed:
             return 1
     return 0
 

@@ -62,11 +62,38 @@ def _write_fake_upstream(root):
 def test_upstream_mode_binds_real_packages_when_they_import(tmp_path):
     """Installed leaf packages must be used INSTEAD of the shim (here: a fake upstream that re-exports the oracle, so the
     regenerated fixtures must still equal the committed ones), and the report must say so."""
+    import json
     _write_fake_upstream(str(tmp_path))
-    r = _run(['--upstream'], extra_path=str(tmp_path))
+    rep_path = str(tmp_path / 'pin.json')
+    r = _run(['--upstream', '--report', rep_path], extra_path=str(tmp_path))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "'pare': 'upstream'" in r.stdout and "'smplx': 'upstream'" in r.stdout and "'loguru': 'upstream'" in r.stdout
     assert 'worst relative deviation over all arrays: 0.000e+00' in r.stdout
+    rep = json.load(open(rep_path))          # the machine-checkable form of the same run
+    assert rep['pass'] is True and rep['mode'] == 'upstream' and rep['pinned_upstream'] == ['loguru', 'pare', 'smplx']
+    assert rep['tolerance_fp_rel'] == 1e-5 and rep['worst_rel_dev'] == 0.0 and not rep['problems']
+    assert len(rep['arrays']) > 40 and all(a['max_abs_dev'] == 0.0 for a in rep['arrays'])
+    assert {'pare', 'smplx', 'torch', 'numpy', 'opencv-python'} <= set(rep['packages'])
+    assert any(a['exact_required'] for a in rep['arrays'])           # index tables are held to byte equality
+
+
+@pytest.mark.timeout(700)
+def test_upstream_report_fails_above_the_tolerance(tmp_path):
+    """A leaf that disagrees with the restatement by more than 1e-5 must turn the exit code and the report red: here the fake
+    upstream's rot6d_to_rotmat is perturbed by 1e-3."""
+    import json
+    _write_fake_upstream(str(tmp_path))
+    with open(os.path.join(str(tmp_path), 'pare/utils/geometry.py'), 'w') as f:
+        f.write('from oracle.geometry import batch_euler2matrix, rotmat_to_rot6d\n'
+                'from oracle import geometry as _g\n'
+                'def rot6d_to_rotmat(x):\n    return _g.rot6d_to_rotmat(x) * (1.0 + 1e-3)\n')
+    with open(os.path.join(str(tmp_path), 'pare/models/head/__init__.py'), 'w') as f:
+        f.write('from oracle import heads as _h\nimport pare.utils.geometry as _pg\n'
+                '_h.rot6d_to_rotmat = _pg.rot6d_to_rotmat\nfrom oracle.heads import HMRHead, SMPLHead, SMPLCamHead\n')
+    rep_path = str(tmp_path / 'pin.json')
+    r = _run(['--upstream', '--report', rep_path], extra_path=str(tmp_path))
+    rep = json.load(open(rep_path))
+    assert r.returncode == 1 and rep['pass'] is False and rep['worst_rel_dev'] > 1e-5, (r.returncode, rep['worst_rel_dev'])
 
 
 @pytest.mark.timeout(700)

@@ -81,10 +81,17 @@ def test_c5_standin_flow_vs_oracle(tmp_path, dataset):
 
 
 def test_spec_eval_cli_standin(tmp_path):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'spec_eval.py'), '--standin', str(tmp_path)],
+    import json
+    rep_path = os.path.join(str(tmp_path), 'eval.json')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'spec_eval.py'), '--standin', str(tmp_path), '--report', rep_path],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     assert 'W-MPJPE-24:' in r.stdout and 'PA-MPJPE-24:' in r.stdout and 'W-V2V:' in r.stdout and 'README 74.9' in r.stdout
+    rep = json.load(open(rep_path))      # the machine-readable README delta (config 5): scores, table row, delta, verdict
+    ds = rep['datasets']['spec-syn']
+    assert rep['standin_tree'] is True and rep['target_abs_delta_wmpjpe_mm'] == 0.1
+    assert ds['readme'] == {'wmpjpe': 74.9, 'pampjpe': 54.5, 'wpve': 90.5}
+    assert abs(ds['delta_mm']['wmpjpe'] - (ds['mean']['wmpjpe_24'] - 74.9)) < 1e-9 and isinstance(ds['within_target'], bool)
 
 
 def test_reference_demo_commands_on_standin_tree(tmp_path):

@@ -126,6 +126,67 @@ def test_hmr_vs_reference_fixture(tag, use_cam, ucf, plan):
         assert hasattr(out[k], 'cpu')      # spec/tester.py:153-154 contract
 
 
+def _elementwise_ok(out, ref, key):
+    """The element-wise reading of BASELINE.json's "1e-4 relative fp32": |err| <= 1e-5 |ref| + floor per element, with an
+    absolute floor of 2e-6 m for vertices / joints3d (one fp32 ulp of a 2 m body is 2.4e-7 m; the trunk's rounding noise reaches
+    the mesh through the regressor) and 1e-4 px (or normalised units) for joints2d.  DESIGN.md section 2 states both readings."""
+    a = out.detach().cpu().numpy().astype(np.float64)
+    b = np.asarray(ref, dtype=np.float64)
+    floor = 1e-4 if key == 'smpl_joints2d' else 2e-6
+    excess = np.abs(a - b) - (1e-5 * np.abs(b) + floor)
+    return float(excess.max()), float(np.abs(a - b).max())
+
+
+@pytest.mark.parametrize('plan', ['latency', 'throughput'])
+@pytest.mark.parametrize('tag,use_cam,ucf', [('camfeats', True, True), ('cam', True, False), ('nocam', False, False)])
+def test_hmr_fixture_elementwise_bound(tag, use_cam, ucf, plan):
+    """What tests/parity_report.py prints, asserted: every element of the mesh, the joints and the projection, not only the
+    tensor's max-norm."""
+    g = golden(f'hmr_e2e_{tag}.npz')
+    _, hm = gpu_models(use_cam, ucf, DEV)
+    hm.set_plan(plan)
+    x = t(synth.images(int(g['seed_images']), int(g['batch']))).to(DEV)
+    if use_cam:
+        out = hm(x, t(g['cam_rotmat']).to(DEV), t(g['cam_intrinsics']).to(DEV), t(g['bbox_scale']).to(DEV),
+                 t(g['bbox_center']).to(DEV), t(g['img_w']).to(DEV), t(g['img_h']).to(DEV))
+    else:
+        out = hm(x)
+    for k in ('smpl_vertices', 'smpl_joints3d', 'smpl_joints2d'):
+        excess, worst = _elementwise_ok(out[k], g[f'out_{k}'], k)
+        assert excess <= 0, (k, excess, worst)
+
+
+def test_full_pipeline_b8_elementwise_bound(models):
+    """The same bound on the whole path (CamCalib -> decode -> SPEC -> SMPL -> projection) against the CPU oracle, batch 8."""
+    from oracle.models import full_pipeline
+    from spec_amd.pipeline import SpecPipeline
+    cc, hm = models
+    occ, ohm = oracle_models(True, True)
+    B = 8
+    x = t(synth.images(33, B))
+    sc, ce, iw, ih = [t(a) for a in synth.bbox_inputs(33, B, 640., 480.)]
+    ref = full_pipeline(occ, ohm, x, sc, ce, iw, ih)
+    for plan in ('latency', 'throughput'):
+        with pinned_plan(plan, cc, hm):
+            out = SpecPipeline(cc, hm)(x.to(DEV), sc.to(DEV), ce.to(DEV), iw.to(DEV), ih.to(DEV))
+        for k in ('smpl_vertices', 'smpl_joints3d', 'smpl_joints2d'):
+            excess, worst = _elementwise_ok(out[k], ref[k].numpy(), k)
+            assert excess <= 0, (plan, k, excess, worst)
+
+
+def test_c2_shape_camcalib_trunk_b64_vs_oracle(models):
+    """BASELINE.json config 2 as stated: the CamCalib ResNet-50 trunk alone, synthetic 224x224, batch 64, against the CPU fp32
+    oracle (rel <= 2e-5 on the layer-4 map)."""
+    cc, _ = models
+    occ, _ = oracle_models(True, True)
+    x = t(synth.images(64, 64))
+    feat = cc.engine(torch.device(DEV)).trunk(x.to(DEV)).cpu()
+    ref = occ.backbone(x).permute(0, 2, 3, 1)
+    assert feat.shape == (64, 7, 7, 2048)
+    err = rel_err(feat.numpy(), ref.numpy())
+    assert err < 2e-5, err
+
+
 def _wmpjpe_mm(verts_a, verts_b, J):
     """spec/utils/compute_error.py:33-49,184: J_regressor @ vertices, pelvis aligned, mean L2 (mm)."""
     ja = np.einsum('jv,bvc->bjc', J, verts_a)

@@ -46,6 +46,23 @@ def test_batched_crops_equal_per_frame_crops_bit_for_bit(F, H, W):
     assert k == len(boxes)
 
 
+def test_frame_index_out_of_range_is_rejected_on_the_host_and_clamped_on_the_device():
+    """A stale / negative / too large frame index must never become an out-of-bounds read: a host-side index is range-checked,
+    a device-side one (the host cannot look at it without a sync) is clamped into the slab by the kernel."""
+    from spec_amd.preprocess import crop_detections_batch
+    rng = np.random.default_rng(3)
+    frames = torch.from_numpy(rng.integers(0, 256, (2, 64, 80, 3), dtype=np.uint8)).to(DEV)
+    dets = torch.tensor([[40., 32., 30., 50.], [20., 20., 25., 40.], [60., 40., 20., 30.]])
+    with pytest.raises(ValueError):
+        crop_detections_batch(frames, torch.tensor([0, 2, 1], dtype=torch.int32), dets)
+    with pytest.raises(ValueError):
+        crop_detections_batch(frames, [0, -1, 1], dets)
+    bad = crop_detections_batch(frames, torch.tensor([0, 7, -5], dtype=torch.int32, device=DEV), dets)
+    ref = crop_detections_batch(frames, torch.tensor([0, 1, 0], dtype=torch.int32, device=DEV), dets)
+    torch.cuda.synchronize()
+    assert torch.equal(bad['inp_images'], ref['inp_images'])        # 7 -> last frame, -5 -> frame 0
+
+
 def test_crop_into_batch_buffer_slices():
     """crop_detections(out=...) writes into slices of a larger batch buffer (what the batched tester does)."""
     from spec_amd.preprocess import crop_detections
@@ -115,35 +132,42 @@ def test_tester_batched_equals_per_frame(tmp_path):
     folder = os.path.join(d, 'frames')
     os.makedirs(folder)
     rng = np.random.default_rng(5)
-    sizes = [(240, 320), (240, 320), (300, 200), (240, 320), (128, 128)]
+    sizes = [(240, 320), (240, 320), (300, 200), (240, 320), (128, 128), (200, 260)]
     dets = []
     for i, (h, w) in enumerate(sizes):
         Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(os.path.join(folder, f'f{i}.png'))
-        n = [2, 0, 3, 1, 4][i]
+        n = [2, 0, 3, 1, 4, 70][i]        # the last frame alone crosses the kernel-variant thresholds of a small batch
         dets.append(np.stack([rng.uniform(0, w, n), rng.uniform(0, h, n), rng.uniform(40, w, n), rng.uniform(60, h, n)], 1).astype(np.float32))
     hs = {k_: t(v) for k_, v in synth.hmr_state(1002, True).items()}
     cwd = os.getcwd()
     os.chdir(d)
     try:
         results = {}
-        for tag, fb in (('per_frame', 1), ('batched', 256), ('small_cap', 5)):
+        for tag, fb, plan in (('per_frame', 1, 'throughput'), ('batched', 256, 'throughput'), ('small_cap', 5, 'throughput'),
+                              ('per_frame_default_plan', 1, None)):
             out = os.path.join(d, 'out_' + tag)
-            args = SimpleNamespace(cfg=None, ckpt=hs, no_save=False, no_render=True, synthetic_assets=True, frame_batch=fb,
-                                   camcalib_model=gpu_models(True, True, DEV)[0], detections=dets)
+            args = SimpleNamespace(cfg=None, ckpt=hs, no_save=False, no_render=True, synthetic_assets=True, frame_batch=fb, plan=plan,
+                                   decode_threads=2, camcalib_model=gpu_models(True, True, DEV)[0], detections=dets)
             te = SPECTester(args)
             te.run_camcalib(folder, out)
             n_done = te.run_on_image_folder(folder, te.run_detector(folder), out, None)
-            assert n_done == 4
+            assert n_done == 5
             results[tag] = {f: joblib.load(os.path.join(out, 'spec_results', f)) for f in sorted(os.listdir(os.path.join(out, 'spec_results')))}
     finally:
         os.chdir(cwd)
-    assert sorted(results['per_frame']) == ['f0.pkl', 'f2.pkl', 'f3.pkl', 'f4.pkl']
-    for tag in ('batched', 'small_cap'):
+    assert sorted(results['per_frame']) == ['f0.pkl', 'f2.pkl', 'f3.pkl', 'f4.pkl', 'f5.pkl']
+    for tag in ('batched', 'small_cap'):           # one plan: bit-identical whatever the batching (1 ... 80 crops per forward)
         assert sorted(results[tag]) == sorted(results['per_frame'])
         for f, ref in results['per_frame'].items():
             for key, v in ref.items():
                 assert results[tag][f][key].shape == v.shape and np.array_equal(results[tag][f][key], v), (tag, f, key)
+    # the default of one-forward-per-frame is the latency plan for up to 8 detections: same results to fp32 rounding
+    for f, ref in results['per_frame'].items():
+        for key in ('smpl_vertices', 'smpl_joints2d', 'pred_cam_t'):
+            a, b = results['per_frame_default_plan'][f][key].astype(np.float64), ref[key].astype(np.float64)
+            assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max(), (f, key)
     assert results['per_frame']['f4.pkl']['smpl_vertices'].shape == (4, 6890, 3)
+    assert results['per_frame']['f5.pkl']['smpl_vertices'].shape == (70, 6890, 3)
 
 
 def test_concurrent_stream_is_measured():
