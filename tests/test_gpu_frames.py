@@ -81,11 +81,13 @@ def test_crop_into_batch_buffer_slices():
 @pytest.mark.parametrize('graph', [False, True])
 def test_frame_stream_equals_per_frame_forward(graph):
     """FrameStream (pinned host slab -> copy stream -> batched crops -> step, two slabs alternating) against the reference's
-    structure: per frame, crops of that frame's detections, one forward per frame.  Bit-identical outputs."""
+    structure: per frame, crops of that frame's detections, one forward per frame.  Bit-identical outputs (one execution plan:
+    the step of 12 crops and the per-frame forwards of 3 would otherwise take the throughput and the latency plan)."""
     from spec_amd.frames import FrameStream
     from spec_amd.pipeline import SpecPipeline, GraphedPipeline
     from spec_amd.preprocess import crop_detections
     cc, hm = gpu_models(True, True, DEV)
+    cc.set_plan('throughput'); hm.set_plan('throughput')
     pipe = SpecPipeline(cc, hm, overlap=True)
     F, H, W, N = 4, 360, 480, 12
     per = [3, 3, 3, 3]
