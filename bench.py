@@ -862,12 +862,35 @@ def main():
             torch.cuda.synchronize()
             up_ms = (time.perf_counter() - t1) / nd * 1e3
             slab_mb = hosts[0][0].numel() / 1e6
+            # (d) the reference's own granularity: ONE frame per step (spec/tester.py:109-151 - batch = the frame's K detections,
+            # CamCalib at batch 1), frame resident in HBM, hipGraph replay: the latency a spec_demo.py user sees per frame
+            single = {}
+            one = [a[:1].contiguous() if a.dim() == 4 else a[:Kdet].contiguous() for a in (hosts[0][0], hosts[0][1], hosts[0][2])]
+            one = [a.to(device) for a in one]
+            for plan in ('auto', 'throughput', 'latency'):
+                for m in (cc, hm):
+                    m.set_plan(plan)
+                g1 = GraphedStep(dp, *one)
+                for _ in range(5):
+                    g1(*g1.static_in)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(50):
+                    g1(*g1.static_in)
+                torch.cuda.synchronize()
+                single[plan + '_plan_ms'] = round((time.perf_counter() - t1) / 50 * 1e3, 3)
+                del g1
+            for m in (cc, hm):
+                m.set_plan('auto')
+            single.update({'frames_per_s': round(1e3 / single['auto_plan_ms'], 1), 'detections': Kdet,
+                           'note': 'one 1080p frame per step: CamCalib at 1 x 3 x 600 x 1066 (auto: throughput plan, 12.7 crops worth of '
+                                   'rows) beside the SPEC trunk on its 8 crops (auto: latency plan)'})
             demo = {'frame': f'{Wf}x{Hf} uint8 RGB', 'frames_per_step': F, 'detections_per_frame': Kdet, 'crops_per_step': N,
                     'frames_per_s': round(F * 1e3 / up_ms, 1), 'crops_per_s': round(N * 1e3 / up_ms, 1), 'ms_per_step': round(up_ms, 3),
                     'frames_resident_in_hbm': {'ms_per_step': round(res_ms, 3), 'frames_per_s': round(F * 1e3 / res_ms, 1)},
                     'overlap': round(res_ms / up_ms, 4), 'h2d_MB_per_step': round(slab_mb, 1),
                     'h2d_GBps_sustained_while_overlapped': round(slab_mb / up_ms, 2), 'copy_stream_probe': cs_probe,
-                    'sum_of_parts_ms': round(cam_ms + ms_per_step / 2, 3),
+                    'sum_of_parts_ms': round(cam_ms + ms_per_step / 2, 3), 'single_frame': single,
                     'camcalib_at_600': cam600,
                     'flow': 'pinned host slab -> copy stream -> 2 alternating device slabs (each the static input of its own hipGraph) -> '
                             'specmi_resize_normalize x F -> CamCalib (batch F, second stream) || specmi_crop_normalize_batch -> SPEC '

@@ -635,11 +635,12 @@ static OpLaunch prepare_op(specmi_handle* h, const TrunkOp& op, const float* ima
     return L;
 }
 
-// plan: 0 auto (latency up to option "latency_max_batch" = 8 images, throughput beyond: measured per batch size,
-// profiles/r04_b_latency_layers.txt), 1 throughput, 2 latency
-static bool use_latency_plan(specmi_handle* h, int B) {
+// plan: 0 auto, 1 throughput, 2 latency.  auto = latency while the call carries no more pixels than option "latency_max_batch"
+// (8) images of 224 x 224 (measured per batch size, profiles/r04_b_latency_layers.txt: level at 8, the throughput kernels ahead
+// from 12) - a single CamCalib frame at 600 x 1066 (12.7 crops' worth of rows per layer) takes the throughput plan
+static bool use_latency_plan(specmi_handle* h, int B, int H, int W) {
     const int plan = opt_i(h, "plan", 0);
-    return plan == 2 || (plan == 0 && B <= opt_i(h, "latency_max_batch", 8));
+    return plan == 2 || (plan == 0 && (long)B * H * W <= (long)opt_i(h, "latency_max_batch", 8) * 224 * 224);
 }
 
 // partner != nullptr: the same op of a second network, launched together (one grouped launch); the caller has checked
@@ -794,7 +795,7 @@ static int run_trunk(specmi_handle* h, const float* images, int B, int H, int W,
                 if ((rc = exec_op(h, ops[i], images, feat_out, b0, nb, H, W, s))) return rc;
         }
     }
-    const bool lat = use_latency_plan(h, B);
+    const bool lat = use_latency_plan(h, B, H, W);
     for (size_t i = first_full; i < ops.size(); ++i)
         if ((rc = exec_op(h, ops[i], images, feat_out, 0, B, H, W, s, lat))) return rc;
     *feat = final_buf == -2 ? feat_out : h->act[final_buf];
@@ -817,7 +818,7 @@ static int run_trunk_pair(specmi_handle* ha, specmi_handle* hb, const float* img
     plan_trunk(ha, H, W, true, Pa);
     plan_trunk(hb, H, W, true, Pb);
     if (Pa.ops.size() != Pb.ops.size()) return fail(ha, SPECMI_ERR_ARG, "the two trunks have different depths");
-    const bool lat = use_latency_plan(ha, B);   // the first handle's options decide for the pair
+    const bool lat = use_latency_plan(ha, B, H, W);   // the first handle's options decide for the pair
     for (size_t i = 0; i < Pa.ops.size(); ++i) {
         const OpLaunch La = prepare_op(ha, Pa.ops[i], img_a, feat_a, 0, B, H, W, lat);
         OpLaunch Lb = prepare_op(hb, Pb.ops[i], img_b, feat_b, 0, B, H, W, lat);

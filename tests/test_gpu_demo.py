@@ -31,7 +31,8 @@ def _frames(seed, F, H, W):
 def test_batched_full_resolution_camcalib_equals_per_frame(models, plan):
     """F frames of 540 x 960 -> Resize(600) = 600 x 1066 (the 1080p geometry: final map 19 x 34, M no tile multiple) in ONE
     CamCalib call == one call per frame, bit for bit - the batched transform writes the same pixels and an image's logits do
-    not depend on the batch within a plan ('auto': 3 frames and 1 frame both take the latency plan)."""
+    not depend on the batch within a plan ('auto': a 600 x 1066 frame carries more rows than 8 crops - 3 frames and 1 frame
+    both take the throughput plan)."""
     from spec_amd.preprocess import camcalib_transform, camcalib_transform_batch
     cc, _ = models
     F = 3
