@@ -110,7 +110,24 @@ const char* specmi_version(void);
  * specmi_hmr_head_forward / specmi_smpl_forward addresses image 0 and image b lives at pointer + b*n floats, i.e. the outputs
  * are columns of ONE caller-owned (B, n) record - the packed all-gather record of SURVEY.md 8e - written by the kernels
  * directly); "angle_ld" (the same for vfov / pitch / roll of specmi_camcalib_decode);
- * "force_conv_variant" / "force_wino_variant" (tests and tuning: pin the tile variant of this handle's launches, 0 = auto). */
+ * "force_conv_variant" / "force_wino_variant" (tests and tuning: pin the tile variant of this handle's launches, 0 = auto);
+ * "plan" (any time, read at every forward; round 4): the execution plan of the ResNet trunk -
+ *     1 = throughput: the kernels the batch-256 benchmark runs (Winograd F(2x2,3x3) + 64x64 / 128x128 implicit GEMM);
+ *     2 = latency: for the reference's own operating point - spec/tester.py:109-151 runs the path at batch = #detections of one
+ *         frame, scripts/camcalib_demo.py:95-102 at batch 1 - every convolution with K >= 512 is cut into K slices that run as ONE
+ *         launch (the last slice of a tile to arrive folds the partial tiles and applies BN / residual / ReLU), layer3 / layer4
+ *         3x3 convolutions leave Winograd for the sliced direct kernel;
+ *     0 = auto (default): latency while the call carries no more pixels than "latency_max_batch" (default 8) images of 224 x 224,
+ *         throughput beyond.
+ *   WITHIN a plan an image's result is bit-identical whatever the batch size, the grouping (specmi_trunk_forward_pair) or the
+ *   replay (every k sum has one association fixed by the layer's shape: the latency plan's is a canonical tree - leaves of L chunks,
+ *   groups of G leaves - of which a workgroup computes a leaf, a group or the whole by batch size; 8 x 256 rank shards == 2048
+ *   unsharded).  BETWEEN plans the last bits differ (other association of the same products, other algorithm on layer3 / layer4
+ *   conv2); both meet the 1e-4 contract on every reference fixture (tests/test_gpu_e2e.py).  Callers that need bit-reproducibility
+ *   across batch sizes on both sides of the switch pin a plan.
+ *   Tuning / tests: "latency_target_wgs" (256), "latency_min_chunks" (4), "latency_wino_min_tiles" (128), "latency_fill_wgs" (250),
+ *   "latency_force_unit" (0 = by batch, 1 / 2 / 3 = a leaf / a group / the whole K per workgroup: same bits),
+ *   "conv2d_sk" (specmi_conv2d only: 0 = throughput kernel, -1 = the latency plan's rule, n > 1 = n leaves). */
 int specmi_set_option_i32(specmi_handle* h, const char* name, int value);
 int specmi_set_option_f32(specmi_handle* h, const char* name, float value);
 
@@ -129,7 +146,8 @@ int specmi_commit(specmi_handle* h);
 
 /* ---- forward: CamCalib ----------------------------------------------------------------- */
 
-/* The ResNet trunks of TWO committed models (CamCalib + SPEC: camcalib/model.py:73 `self.backbone(images)` and
+/* (The execution plan - option "plan" above - is chosen from the FIRST handle's options and B, H, W for both trunks.)
+ * The ResNet trunks of TWO committed models (CamCalib + SPEC: camcalib/model.py:73 `self.backbone(images)` and
  * spec/models/hmr.py:92 `self.backbone(images)`, which the reference runs as two processes / two calls) walked in lockstep
  * with every layer of both as ONE grouped launch: images_a / images_b (B,3,H,W) NCHW -> feat_a / feat_b (B, H/32, W/32, C)
  * NHWC.  Both trunks must be ResNets of the same depth and see the same B, H, W; each keeps its own weights and workspaces.
@@ -253,8 +271,9 @@ int specmi_crop_normalize(specmi_handle* h, const uint8_t* frame_rgb_hwc, int H,
 
 /* The same crops for the detections of MANY frames in one launch - the loop over images of spec/tester.py:109-128 (one
  * frame, its detections, one crop each) flattened: `frames` is a slab of nframes equal-sized uint8 RGB HWC frames in device
- * memory (frame f at frames + f*H*W*3), crop d is cut from frame frame_index[d] (device, (n) int32, values in [0, nframes))
- * with bbox d.  Same arithmetic, same outputs per crop as specmi_crop_normalize (bit-identical); what it removes is one
+ * memory (frame f at frames + f*H*W*3), crop d is cut from frame frame_index[d] (device, (n) int32, values in [0, nframes);
+ * the index lives in caller memory the library cannot inspect without a synchronisation: an out-of-range value is CLAMPED into
+ * the slab - a wrong crop, never an out-of-bounds read; validate on the host where the index is produced) with bbox d.  Same arithmetic, same outputs per crop as specmi_crop_normalize (bit-identical); what it removes is one
  * launch, one host synchronisation and one small batch per frame. */
 int specmi_crop_normalize_batch(specmi_handle* h, const uint8_t* frames_rgb_hwc, int nframes, int H, int W,
                                 const int32_t* frame_index, const float* bboxes, int n, float scale, int crop_size,

@@ -491,15 +491,23 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { accR[i][j][r] += accG[i][j][r]; accG[i][j][r] = 0.f; }
         };
-        for (int c = 0; c < p.nchunks; c += 2) {
+        // The loop body is a whole (even, odd) pair and an odd chunk count ends in a peeled tail: with the odd chunk under an
+        // `if` inside the loop the compiler's wait-count pass sees a path even -> even, assumes six fewer loads in flight and
+        // waits for vmcnt(3) instead of vmcnt(9) at the top of every even chunk - the two-chunk prefetch distance collapses to
+        // less than one (a lone wave then runs the loop at 0.65 of the matrix pipe).
+        int c = 0;
+        for (; c + 2 <= p.nchunks; c += 2) {
             sk_chunk(c, even);
             __syncthreads();
             leaf_end();
-            if (c + 1 < p.nchunks) {
-                sk_chunk(c + 1, odd);
-                __syncthreads();
-                leaf_end();
-            }
+            sk_chunk(c + 1, odd);
+            __syncthreads();
+            leaf_end();
+        }
+        if (c < p.nchunks) {
+            sk_chunk(c, even);
+            __syncthreads();
+            leaf_end();
         }
         if (p.sk_unit != 1) {
             const bool grp_level = p.sk_unit == p.sk_G;
