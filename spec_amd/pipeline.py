@@ -169,7 +169,7 @@ class DemoPipeline:
     pickle files, one frame and one small batch at a time; here a slab of F equal-sized frames is one step:
 
         frames (F,H,W,3) uint8 in HBM --specmi_resize_normalize x F--> (F,3,600,W') --CamCalib, batch F--> decode -> R, K (F)
-                                      \--specmi_crop_normalize_batch--> (N,3,224,224) --SPEC trunk--> head(R[frame], K[frame]) -> SMPL
+                                      +--specmi_crop_normalize_batch--> (N,3,224,224) --SPEC trunk--> head(R[frame], K[frame]) -> SMPL
 
     CamCalib runs on a second stream beside the SPEC trunk (both are MFMA-bound; the join is the regressor head, which needs the
     camera).  Everything is enqueued without a host synchronisation, so the step can be captured into a hipGraph."""
