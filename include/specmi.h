@@ -95,7 +95,8 @@ const char* specmi_version(void);
 /* ---- parameters (replaces load_state_dict / load_pretrained_model,
  *      spec/tester.py:63-71, scripts/camcalib_demo.py:80-81) ---------------------------- */
 
-/* Integer options before commit.  CamCalib (camcalib/model.py:25-70): "backbone" (50 default | 34),
+/* Integer options before commit.  CamCalib (camcalib/model.py:25-70): "backbone" (50 default | 18 | 34 | 101 | 152: the torchvision ResNet family the
+ * reference's eval(backbone) resolves, spec/models/hmr.py:53, camcalib/model.py:33; HMR also 32 / 48 = HRNet-W32 / W48),
  * "num_fc_layers" (1..3), "num_fc_channels" (<= 1024, multiple of 32).  HMR: "use_cam" (SMPLCamHead vs SMPLHead, hmr.py:66-74),
  * "use_cam_feats" (hmr.py:55,94-98), "img_res" (hmr.py:69).  Float option: "focal_length".
  * Any time: "winograd" (default 1: 3x3 / stride-1 convolutions with Cin % 16 == 0 and Cout % 64 == 0

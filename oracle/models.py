@@ -12,6 +12,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import resnet as _resnet
 from .resnet import ResNet50Trunk, ResNet34Trunk, get_backbone_info
 from .heads import HMRHead, SMPLCamHead, SMPLHead, set_assets  # noqa: F401
 from .geometry import softargmax1d, batch_euler2matrix
@@ -29,7 +30,7 @@ class CamCalibOracle(nn.Module):
                  num_out_channels=256):
         super().__init__()
         assert num_fc_layers > 0
-        self.backbone = ResNet50Trunk() if backbone == 'resnet50' else ResNet34Trunk()
+        self.backbone = getattr(_resnet, backbone)()          # eval(backbone)(pretrained=True), camcalib/model.py:33
         self.num_out_channels = num_out_channels
         self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
         c = get_backbone_info(backbone)['n_output_channels']
@@ -109,7 +110,7 @@ class HMROracle(nn.Module):
             backbone, use_conv = backbone.split('-')                                  # :45
             self.backbone = getattr(hrnet, backbone)(pretrained=True, downsample=True, use_conv=(use_conv == 'conv'))
         else:
-            self.backbone = ResNet50Trunk() if backbone == 'resnet50' else ResNet34Trunk()
+            self.backbone = getattr(_resnet, backbone)()      # eval(backbone)(pretrained=True), hmr.py:53
         self.use_cam_feats = use_cam_feats
         self.head = HMRHead(num_input_features=get_backbone_info(backbone)['n_output_channels'],
                             backbone=backbone, use_cam_feats=use_cam_feats)

@@ -116,6 +116,19 @@ def resnet34(pretrained=False, **kwargs):
     return ResNet34Trunk()
 
 
+def resnet18(pretrained=False, **kwargs):
+    """torchvision ``ResNet(BasicBlock, [2,2,2,2])`` (pare.models.backbone re-exports the torchvision family)."""
+    return ResNet34Trunk(layers=(2, 2, 2, 2))
+
+
+def resnet101(pretrained=False, **kwargs):
+    return ResNet50Trunk(layers=(3, 4, 23, 3))
+
+
+def resnet152(pretrained=False, **kwargs):
+    return ResNet50Trunk(layers=(3, 8, 36, 3))
+
+
 def resnet50(pretrained=False, **kwargs):
     """``pretrained`` is accepted and ignored: no network, weights come from a state_dict."""
     return ResNet50Trunk()
@@ -127,6 +140,7 @@ def get_backbone_info(backbone):
     info = {
         'resnet18': {'n_output_channels': 512}, 'resnet34': {'n_output_channels': 512},
         'resnet50': {'n_output_channels': 2048}, 'resnet101': {'n_output_channels': 2048},
+        'resnet152': {'n_output_channels': 2048},
         'hrnet_w32': {'n_output_channels': 480}, 'hrnet_w48': {'n_output_channels': 720},
     }
     return info[backbone]

@@ -206,6 +206,13 @@ static int commit_fused_ds(specmi_handle* h, const std::string& prefix, Bneck& b
 }
 
 // One or several Linear layers stacked along the output dimension
+// (nout, nin) -> (nout, Kp) row-major with zero padding: the operand of the small-batch GEMV kernel (head.hip)
+static int upload_row_major(specmi_handle* h, const float* w, int nout, int nin, FcW& fc) {
+    std::vector<float> rm((size_t)nout * fc.Kp, 0.f);
+    for (int n = 0; n < nout; ++n) std::memcpy(rm.data() + (size_t)n * fc.Kp, w + (size_t)n * nin, (size_t)nin * 4);
+    return dev_upload(h, rm.data(), rm.size() * 4, (void**)&fc.w_rm, h->param_allocs);
+}
+
 static int commit_fc(specmi_handle* h, const std::vector<std::string>& names, const std::vector<int>& nouts, int nin,
                      FcW& fc) {
     int ntot = 0;
@@ -229,7 +236,7 @@ static int commit_fc(specmi_handle* h, const std::vector<std::string>& names, co
     if ((rc = dev_upload(h, packed.data(), packed.size() * 4, (void**)&fc.w, h->param_allocs))) return rc;
     if ((rc = dev_upload(h, ones.data(), ones.size() * 4, (void**)&fc.scale, h->param_allocs))) return rc;
     if ((rc = dev_upload(h, bias.data(), bias.size() * 4, (void**)&fc.shift, h->param_allocs))) return rc;
-    return SPECMI_OK;
+    return upload_row_major(h, wcat.data(), ntot, nin, fc);
 }
 
 // HMRHead in eval mode is an affine map: there is no activation between fc1, fc2 and the decoders and dropout is
@@ -315,6 +322,7 @@ static int commit_head_collapsed(specmi_handle* h, int F, int ucf) {
     if ((rc = dev_upload(h, packed.data(), packed.size() * 4, (void**)&fc.w, h->param_allocs))) return rc;
     if ((rc = dev_upload(h, ones.data(), ones.size() * 4, (void**)&fc.scale, h->param_allocs))) return rc;
     if ((rc = dev_upload(h, bias.data(), bias.size() * 4, (void**)&fc.shift, h->param_allocs))) return rc;
+    if ((rc = upload_row_major(h, wcat.data(), NS, nin, fc))) return rc;
     h->has_head_c = true;
     return SPECMI_OK;
 }
@@ -325,8 +333,11 @@ static void build_resnet(specmi_handle* h, int depth) {
     h->stem.name = "conv1"; h->stem.bn_name = "bn1";
     h->stem.cin = 3; h->stem.cout = 64; h->stem.k = 7; h->stem.stride = 2; h->stem.pad = 3;
     h->blocks.clear();
-    const bool basic = depth == 34;
-    const int nblocks[4] = {3, 4, 6, 3}, planes[4] = {64, 128, 256, 512};
+    // torchvision's family: BasicBlock [2,2,2,2] (18) / [3,4,6,3] (34), Bottleneck [3,4,6,3] (50) / [3,4,23,3] (101) / [3,8,36,3] (152)
+    const bool basic = depth == 34 || depth == 18;
+    const int nb18[4] = {2, 2, 2, 2}, nb50[4] = {3, 4, 6, 3}, nb101[4] = {3, 4, 23, 3}, nb152[4] = {3, 8, 36, 3};
+    const int* nblocks = depth == 18 ? nb18 : depth == 101 ? nb101 : depth == 152 ? nb152 : nb50;
+    const int planes[4] = {64, 128, 256, 512};
     const int expansion = basic ? 1 : 4;
     int inplanes = 64;
     for (int li = 0; li < 4; ++li) {
@@ -469,6 +480,8 @@ static int ensure_ws(specmi_handle* h, int B, int H, int W) {
     if ((rc = dev_alloc(h, (size_t)Bp * h->xc_ld * 4, (void**)&h->xc, h->ws_allocs))) return rc;
     if ((rc = dev_alloc(h, (size_t)Bp * 1024 * 4, (void**)&h->h1, h->ws_allocs))) return rc;
     if ((rc = dev_alloc(h, (size_t)Bp * 1024 * 4, (void**)&h->h2, h->ws_allocs))) return rc;
+    for (int i = 0; i < 2; ++i)   // hidden rows of the three CamCalib Linear chains when they run as one launch per layer
+        if ((rc = dev_alloc(h, (size_t)3 * Bp * 1024 * 4, (void**)&h->fc_hidden[i], h->ws_allocs))) return rc;
     if ((rc = dev_alloc(h, (size_t)Bp * 2048 * 4, (void**)&h->xf, h->ws_allocs))) return rc;
     if ((rc = dev_alloc(h, (size_t)Bp * 216 * 4, (void**)&h->rot_ws, h->ws_allocs))) return rc;
     if ((rc = dev_alloc(h, (size_t)Bp * 10 * 4, (void**)&h->betas_ws, h->ws_allocs))) return rc;
@@ -641,6 +654,11 @@ static OpLaunch prepare_op(specmi_handle* h, const TrunkOp& op, const float* ima
 static bool use_latency_plan(specmi_handle* h, int B, int H, int W) {
     const int plan = opt_i(h, "plan", 0);
     return plan == 2 || (plan == 0 && (long)B * H * W <= (long)opt_i(h, "latency_max_batch", 8) * 224 * 224);
+}
+// the FC layers behind the trunk see batch rows only: the small-batch GEMV kernel (head.hip) up to "latency_max_batch" rows
+static bool use_latency_heads(specmi_handle* h, int B) {
+    const int plan = opt_i(h, "plan", 0);
+    return opt_i(h, "fc_gemv", 1) && (plan == 2 || (plan == 0 && B <= opt_i(h, "latency_max_batch", 8)));
 }
 
 // partner != nullptr: the same op of a second network, launched together (one grouped launch); the caller has checked
@@ -870,17 +888,27 @@ static int run_head(specmi_handle* h, const float* feat, int B, int fh, int fw, 
     }
     const float* state = h->xc + F;
     long ld_state = LD;
+    const bool gemv = use_latency_heads(h, B);
+    auto fc = [&](const FcW& w, const float* x, int ldx, const float* res, float* out, int ldo, const char* label) -> int {
+        if (gemv && w.w_rm) {     // latency plan: one wave per output column (head.hip: fc_gemv_kernel)
+            const FcGemv hd{x, w.w_rm, w.shift, res, out};
+            LaunchCtx ctx{s, &h->prof, label};
+            LAUNCHCHK(h, launch_fc_gemv(&hd, 1, w.nout, w.Kp, ldx, ldo, B, ctx), label);
+            return SPECMI_OK;
+        }
+        return run_fc(h, w, x, ldx, B, res, out, ldo, s, label);
+    };
     if (h->has_head_c && opt_i(h, "head_collapse", 1)) {
         // the three IEF iterations as one composed affine map (commit_head_collapsed)
-        if ((rc = run_fc(h, h->head_c, h->xc, LD, B, nullptr, h->h1, 1024, s, "head.ief_collapsed"))) return rc;
+        if ((rc = fc(h->head_c, h->xc, LD, nullptr, h->h1, 1024, "head.ief_collapsed"))) return rc;
         state = h->h1;
         ld_state = 1024;
     } else {
         for (int it = 0; it < 3; ++it) {
-            if ((rc = run_fc(h, h->fc1, h->xc, LD, B, nullptr, h->h1, 1024, s, "head.fc1"))) return rc;
-            if ((rc = run_fc(h, h->fc2, h->h1, 1024, B, nullptr, h->h2, 1024, s, "head.fc2"))) return rc;
+            if ((rc = fc(h->fc1, h->xc, LD, nullptr, h->h1, 1024, "head.fc1"))) return rc;
+            if ((rc = fc(h->fc2, h->h1, 1024, nullptr, h->h2, 1024, "head.fc2"))) return rc;
             float* st = h->xc + F;  // dec* + running estimate, in place
-            if ((rc = run_fc(h, h->dec, h->h2, 1024, B, st, st, LD, s, "head.dec"))) return rc;
+            if ((rc = fc(h->dec, h->h2, 1024, st, st, LD, "head.dec"))) return rc;
         }
     }
     {
@@ -1013,8 +1041,8 @@ int specmi_commit(specmi_handle* h) {
     }
     const std::string bp = "backbone.";
     const int depth = opt_i(h, "backbone", 50);
-    if (depth != 50 && depth != 34 && depth != 32 && depth != 48)
-        return fail(h, SPECMI_ERR_ARG, "backbone %d: resnet50 (50), resnet34 (34), hrnet_w32 (32) and hrnet_w48 (48) are built", depth);
+    if (depth != 50 && depth != 34 && depth != 18 && depth != 101 && depth != 152 && depth != 32 && depth != 48)
+        return fail(h, SPECMI_ERR_ARG, "backbone %d: resnet18 / 34 / 50 / 101 / 152, hrnet_w32 (32) and hrnet_w48 (48) are built", depth);
     if ((depth == 32 || depth == 48) && h->kind != SPECMI_MODEL_HMR)
         return fail(h, SPECMI_ERR_ARG, "the HRNet trunks belong to HMR (camcalib/model.py:33 builds resnet trunks only)");
     if (h->hrnet) { hrnet_free(h->hrnet); h->hrnet = nullptr; }
@@ -1134,6 +1162,28 @@ static int run_camcalib_head(specmi_handle* h, const float* f, int B, int fh, in
     }
     float* outs[3] = {lv, lp, lr};
     const char* labels[3] = {"fc_vfov", "fc_pitch", "fc_roll"};
+    if (use_latency_heads(h, B) && h->fc_cam[0][0].w_rm) {
+        // latency plan: the three heads of a layer as ONE launch (head.hip: fc_gemv_kernel); Linear chains layer by layer
+        const float* x[3] = {h->xf, h->xf, h->xf};
+        int ldx = 2048;
+        for (int l = 0; l < h->fc_layers; ++l) {
+            const bool lastl = (l + 1 == h->fc_layers);
+            FcGemv hd[3];
+            // hidden rows of head i: h1 / h2 hold two of them, the third borrows the regressor-state buffer xc (unused by CamCalib)
+            const FcW& f0 = h->fc_cam[0][l];
+            const int ldy = lastl ? f0.nout : 1024;
+            for (int i = 0; i < 3; ++i) {
+                const FcW& fc = h->fc_cam[i][l];
+                if (fc.nout != f0.nout || fc.Kp != f0.Kp) return fail(h, SPECMI_ERR_STATE, "CamCalib heads differ in shape");
+                hd[i] = FcGemv{x[i], fc.w_rm, fc.shift, nullptr, lastl ? outs[i] : h->fc_hidden[l & 1] + (size_t)i * B * 1024};
+            }
+            LaunchCtx ctx{s, &h->prof, "fc_vfov|pitch|roll"};
+            LAUNCHCHK(h, launch_fc_gemv(hd, 3, f0.nout, f0.Kp, ldx, ldy, B, ctx), "fc heads");
+            for (int i = 0; i < 3; ++i) x[i] = hd[i].out;
+            ldx = ldy;
+        }
+        return SPECMI_OK;
+    }
     for (int i = 0; i < 3; ++i) {
         // Linear chain (no activation in between, camcalib/model.py:59-70); hidden rows live in h1 / h2 (1024 wide)
         const float* x = h->xf;

@@ -46,6 +46,7 @@ struct Bneck {
 struct FcW {  // Linear layers as H=W=1 convolutions
     int nin = 0, nout = 0, Kp = 0, Npad = 0;
     float *w = nullptr, *scale = nullptr, *shift = nullptr;
+    float* w_rm = nullptr;   // the same matrix as (nout, Kp) row-major rows, zero padded to Kp: the small-batch GEMV kernel's operand
 };
 
 struct HrNet;
@@ -78,6 +79,7 @@ struct specmi_handle {
     float* act[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t act_elems = 0;
     float *xc = nullptr, *h1 = nullptr, *h2 = nullptr, *xf = nullptr;
+    float* fc_hidden[2] = {nullptr, nullptr};   // (3, B, 1024) each: hidden rows of the three CamCalib Linear chains (latency plan)
     float *rot_ws = nullptr, *betas_ws = nullptr, *cam_ws = nullptr, *verts_ws = nullptr;
     float *pf_ws = nullptr, *A_ws = nullptr, *pj_ws = nullptr;
     int ws_B = 0;

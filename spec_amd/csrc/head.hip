@@ -138,6 +138,76 @@ __device__ __forceinline__ void build_cam_RK(float pt, float rl, float f, float 
     }
 }
 
+// ---- FC layers at small batch (latency plan) -------------------------------------------------------------------------
+// The three CamCalib heads (camcalib/model.py:77-79: fc_vfov / fc_pitch / fc_roll on the same pooled features) and the HMR
+// regressor's composed map (spec/models/hmr.py:96) are M = batch-row GEMMs: on the matrix-core kernel each is a launch of 4-24
+// tiles that are 1/64 ... 8/64 full plus a fold of K slices - 11-12 us per GEMM for 0.2 us of arithmetic, and three graph nodes
+// where one will do.  Here: ONE launch for up to three heads (blockIdx.y), one WAVE per output column, lanes across K (16-byte
+// loads of the row-major weight row: 1 KiB per instruction, coalesced), all images of a block of 8 per wave, fixed lane-local k
+// order and a fixed xor-shuffle tree - an image's result does not depend on the batch it travels in.
+struct GemvHead { const float* x; const float* w; const float* bias; const float* res; float* out; };
+struct GemvArgs {
+    GemvHead hd[3];
+    int nheads, N, Kp, ldx, ldo, B;   // w: (N, Kp) row-major, zero padded beyond the true K; x rows ldx apart (>= Kp floats readable)
+};
+
+__global__ void __launch_bounds__(256) fc_gemv_kernel(const GemvArgs a) {
+    const GemvHead& hd = a.hd[blockIdx.y];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + wave;
+    const int b0 = blockIdx.z * 8;
+    if (n >= a.N) return;
+    const int nb = min(8, a.B - b0);
+    const float* wrow = hd.w + (size_t)n * a.Kp;
+    float acc[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[b] = 0.f;
+    for (int k = lane * 4; k < a.Kp; k += 256) {
+        const float4 wv = *reinterpret_cast<const float4*>(wrow + k);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            if (b < nb) {
+                const float4 xv = *reinterpret_cast<const float4*>(hd.x + (size_t)(b0 + b) * a.ldx + k);
+                acc[b] = fmaf(wv.x, xv.x, acc[b]);
+                acc[b] = fmaf(wv.y, xv.y, acc[b]);
+                acc[b] = fmaf(wv.z, xv.z, acc[b]);
+                acc[b] = fmaf(wv.w, xv.w, acc[b]);
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        float v = acc[b];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        acc[b] = v;
+    }
+    if (lane < nb) {
+        float v = 0.f;
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+            if (lane == b) v = acc[b];
+        const size_t o = (size_t)(b0 + lane) * a.ldo + n;
+        v += hd.bias[n];
+        if (hd.res) v += hd.res[o];
+        hd.out[o] = v;
+    }
+}
+
+int launch_fc_gemv(const FcGemv* heads, int nheads, int N, int Kp, int ldx, int ldo, int B, const LaunchCtx& ctx) {
+    if (nheads < 1 || nheads > 3 || N < 1 || B < 1 || Kp % 4 != 0 || ldx % 4 != 0) return (int)hipErrorInvalidValue;
+    GemvArgs a;
+    a.nheads = nheads; a.N = N; a.Kp = Kp; a.ldx = ldx; a.ldo = ldo; a.B = B;
+    for (int i = 0; i < 3; ++i) {
+        const FcGemv& f = heads[i < nheads ? i : 0];
+        if ((reinterpret_cast<uintptr_t>(f.x) | reinterpret_cast<uintptr_t>(f.w)) & 15) return (int)hipErrorInvalidValue;
+        a.hd[i] = GemvHead{f.x, f.w, f.bias, f.res, f.out};
+    }
+    ProfScope ps(ctx, "fc_gemv_f32", 2.0 * nheads * (double)B * N * Kp, 4.0 * nheads * ((double)N * Kp + (double)B * (Kp + N)));
+    hipLaunchKernelGGL(fc_gemv_kernel, dim3((N + 3) / 4, nheads, (B + 7) / 8), dim3(256), 0, ctx.stream, a);
+    return (int)hipGetLastError();
+}
+
 __global__ void __launch_bounds__(192) camcalib_decode_kernel(const float* __restrict__ lv, const float* __restrict__ lp,
                                                                const float* __restrict__ lr, int nbins,
                                                                const float* __restrict__ img_h,

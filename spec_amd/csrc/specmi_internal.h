@@ -175,6 +175,11 @@ int launch_camcalib_decode(const float* lv, const float* lp, const float* lr, in
 // per-row argmax (first maximum, NumPy NaN semantics) and / or normalised soft-argmax of (rows, nbins) logits
 int launch_bins_reduce(const float* x, int rows, int nbins, int* idx, float* soft, const LaunchCtx& ctx);
 
+// FC layers at small batch: one launch for up to three heads, one wave per output column (head.hip).  w = (N, Kp) row-major,
+// zero padded to Kp; x rows ldx floats apart with Kp floats readable; out[b * ldo + n] = w[n] . x[b] + bias[n] (+ res[b * ldo + n])
+struct FcGemv { const float* x; const float* w; const float* bias; const float* res; float* out; };
+int launch_fc_gemv(const FcGemv* heads, int nheads, int N, int Kp, int ldx, int ldo, int B, const LaunchCtx& ctx);
+
 int launch_cam_params(const float* pitch, const float* roll, const float* f_pix, const float* img_w, const float* img_h,
                       int B, float* R, float* K, const LaunchCtx& ctx);
 

@@ -96,7 +96,7 @@ class Engine:
             last = [k for k in tensors if k.startswith('fc_vfov.') and k.endswith('.weight')]
             if last:
                 self.nbins = int(tensors[sorted(last)[-1]].shape[0])
-        self.feat_channels = {34: 512, 32: 480, 48: 720}.get(int(options.get('backbone', 50)), 2048)
+        self.feat_channels = {18: 512, 34: 512, 32: 480, 48: 720}.get(int(options.get('backbone', 50)), 2048)
         _lib.check(self.h, self.lib.specmi_commit(self.h))
 
     def _set_ld(self, name: str, value: int):

@@ -41,14 +41,15 @@ class _BottleneckParams(nn.Module):
 
 
 class ResNet50Params(nn.Module):
-    """torchvision-layout ResNet-50 trunk parameters (no avgpool / fc), 318 tensors."""
+    """torchvision-layout Bottleneck ResNet trunk parameters (no avgpool / fc): ResNet-50 by default (318 tensors), ``layers``
+    = (3, 4, 23, 3) / (3, 8, 36, 3) for ResNet-101 / 152."""
 
-    def __init__(self):
+    def __init__(self, layers=(3, 4, 6, 3)):
         super().__init__()
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         inplanes = 64
-        for li, (nb, planes) in enumerate(zip((3, 4, 6, 3), (64, 128, 256, 512)), start=1):
+        for li, (nb, planes) in enumerate(zip(layers, (64, 128, 256, 512)), start=1):
             blocks = []
             for b in range(nb):
                 stride = 2 if (b == 0 and li > 1) else 1
@@ -73,15 +74,15 @@ class _BasicBlockParams(nn.Module):
 
 
 class ResNet34Params(nn.Module):
-    """torchvision-layout ResNet-34 trunk parameters (BasicBlock [3,4,6,3], no avgpool / fc) - the CamCalib
-    config default (camcalib/config.py:81) and one of the two trunks of camcalib/model.py:85."""
+    """torchvision-layout BasicBlock ResNet trunk parameters (no avgpool / fc): ResNet-34 ([3,4,6,3]) - the CamCalib
+    config default (camcalib/config.py:81) and one of the two trunks of camcalib/model.py:85 - or ResNet-18 ([2,2,2,2])."""
 
-    def __init__(self):
+    def __init__(self, layers=(3, 4, 6, 3)):
         super().__init__()
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         inplanes = 64
-        for li, (nb, planes) in enumerate(zip((3, 4, 6, 3), (64, 128, 256, 512)), start=1):
+        for li, (nb, planes) in enumerate(zip(layers, (64, 128, 256, 512)), start=1):
             blocks = []
             for b in range(nb):
                 stride = 2 if (b == 0 and li > 1) else 1
@@ -95,6 +96,18 @@ class ResNet34Params(nn.Module):
 
 def resnet34(pretrained=False, **kwargs):
     return ResNet34Params()
+
+
+def resnet18(pretrained=False, **kwargs):
+    return ResNet34Params((2, 2, 2, 2))
+
+
+def resnet101(pretrained=False, **kwargs):
+    return ResNet50Params((3, 4, 23, 3))
+
+
+def resnet152(pretrained=False, **kwargs):
+    return ResNet50Params((3, 8, 36, 3))
 
 
 # ---- HRNet-W32 / W48 (pare.models.backbone.hrnet as HMR builds it, spec/models/hmr.py:44-51) -------------------
@@ -181,7 +194,16 @@ def get_backbone_info(backbone):
     """pare.models.backbone.utils.get_backbone_info: the trunk's feature width (HRNet, downsample=True head: the four
     branches concatenated, 32+64+128+256 / 48+96+192+384)."""
     return {'resnet50': {'n_output_channels': 2048}, 'resnet34': {'n_output_channels': 512},
+            'resnet18': {'n_output_channels': 512}, 'resnet101': {'n_output_channels': 2048},
+            'resnet152': {'n_output_channels': 2048},
             'hrnet_w32': {'n_output_channels': 480}, 'hrnet_w48': {'n_output_channels': 720}}[backbone]
+
+
+# the torchvision ResNet family the reference's ``eval(backbone)(pretrained=True)`` resolves through pare.models.backbone
+# (spec/models/hmr.py:53, camcalib/model.py:33): name -> (constructor, depth id of the library's "backbone" option)
+def _resnet_family():
+    return {'resnet18': (resnet18, 18), 'resnet34': (resnet34, 34), 'resnet50': (resnet50, 50), 'resnet101': (resnet101, 101),
+            'resnet152': (resnet152, 152)}
 
 
 class HMRHeadParams(nn.Module):
@@ -346,13 +368,13 @@ class CameraRegressorNetwork(_EngineModule):
 
     def __init__(self, backbone='resnet50', num_fc_layers=1, num_fc_channels=1024, num_out_channels=256):
         super().__init__()
-        if backbone not in ('resnet50', 'resnet34'):
-            raise NotImplementedError(f'backbone {backbone!r}: resnet50 (the released model) and resnet34 are built')
+        if backbone not in _resnet_family():
+            raise NotImplementedError(f'backbone {backbone!r}: resnet50 (the released model), resnet18 / 34 / 101 / 152 are built')
         assert num_fc_layers > 0, 'Number of FC layers should be more than 0'
         if num_fc_layers > 3 or num_fc_channels > 1024 or num_fc_channels % 32:
             raise NotImplementedError('num_fc_layers <= 3 and num_fc_channels <= 1024 (multiple of 32) are built')
-        self.backbone = resnet50(pretrained=True) if backbone == 'resnet50' else resnet34(pretrained=True)
-        self._backbone_depth = 50 if backbone == 'resnet50' else 34
+        ctor, self._backbone_depth = _resnet_family()[backbone]
+        self.backbone = ctor(pretrained=True)
         self.num_fc_layers, self.num_fc_channels = num_fc_layers, num_fc_channels
         self.num_out_channels = num_out_channels
         out_channels = get_backbone_info(backbone)['n_output_channels']
@@ -411,11 +433,12 @@ class HMR(_EngineModule):
             self.backbone = (hrnet_w32 if backbone == 'hrnet_w32' else hrnet_w48)(pretrained=True, downsample=True,
                                                                                   use_conv=(use_conv == 'conv'))
             self._backbone_id = 32 if backbone == 'hrnet_w32' else 48
-        elif backbone in ('resnet50', 'resnet34'):               # eval(backbone)(pretrained=True), hmr.py:53
-            self.backbone = resnet50(pretrained=True) if backbone == 'resnet50' else resnet34(pretrained=True)
-            self._backbone_id = 50 if backbone == 'resnet50' else 34
+        elif backbone in _resnet_family():                       # eval(backbone)(pretrained=True), hmr.py:53
+            ctor, self._backbone_id = _resnet_family()[backbone]
+            self.backbone = ctor(pretrained=True)
         else:
-            raise NotImplementedError(f'backbone {backbone!r}: resnet50, resnet34, hrnet_w32-(conv|interp), hrnet_w48-(conv|interp) are built')
+            raise NotImplementedError(f'backbone {backbone!r}: resnet18 / 34 / 50 / 101 / 152, hrnet_w32-(conv|interp), '
+                                      'hrnet_w48-(conv|interp) are built (pare also ships a mobilenet trunk: not built)')
         self.use_cam_feats = use_cam_feats
         self.head = HMRHeadParams(get_backbone_info(backbone)['n_output_channels'], use_cam_feats)
         self.use_cam = use_cam

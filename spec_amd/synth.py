@@ -74,11 +74,15 @@ RESNET50_BLOCKS = (3, 4, 6, 3)
 RESNET50_PLANES = (64, 128, 256, 512)
 
 
-def resnet50_conv_specs():
-    """List of (name, cin, cout, k, stride, pad, bn_name) in state-dict order."""
+RESNET_FAMILY = {'resnet18': ('basic', (2, 2, 2, 2)), 'resnet34': ('basic', (3, 4, 6, 3)), 'resnet50': ('bottleneck', (3, 4, 6, 3)),
+                 'resnet101': ('bottleneck', (3, 4, 23, 3)), 'resnet152': ('bottleneck', (3, 8, 36, 3))}
+
+
+def resnet50_conv_specs(blocks=RESNET50_BLOCKS):
+    """List of (name, cin, cout, k, stride, pad, bn_name) in state-dict order (Bottleneck trunks: 50 / 101 / 152 by ``blocks``)."""
     specs = [('conv1', 3, 64, 7, 2, 3, 'bn1')]
     inplanes = 64
-    for li, (nb, planes) in enumerate(zip(RESNET50_BLOCKS, RESNET50_PLANES), start=1):
+    for li, (nb, planes) in enumerate(zip(blocks, RESNET50_PLANES), start=1):
         for b in range(nb):
             stride = 2 if (b == 0 and li > 1) else 1
             p = f'layer{li}.{b}'
@@ -92,10 +96,10 @@ def resnet50_conv_specs():
     return specs
 
 
-def resnet50_state(seed: int, prefix: str = '') -> 'OrderedDict[str, np.ndarray]':
-    """Random ResNet-50 trunk parameters with activations kept O(1) through 16 blocks."""
+def resnet50_state(seed: int, prefix: str = '', blocks=RESNET50_BLOCKS) -> 'OrderedDict[str, np.ndarray]':
+    """Random ResNet-50 (101 / 152 by ``blocks``) trunk parameters with activations kept O(1) through the blocks."""
     sd = OrderedDict()
-    for (name, cin, cout, k, _s, _p, bn) in resnet50_conv_specs():
+    for (name, cin, cout, k, _s, _p, bn) in resnet50_conv_specs(blocks):
         fan_in = cin * k * k
         sd[f'{prefix}{name}.weight'] = normal(seed, name + '.weight', (cout, cin, k, k),
                                                std=math.sqrt(2.0 / fan_in))
@@ -113,11 +117,11 @@ def resnet50_state(seed: int, prefix: str = '') -> 'OrderedDict[str, np.ndarray]
     return sd
 
 
-def resnet34_conv_specs():
-    """(name, cin, cout, k, stride, pad, bn_name) of the torchvision ResNet-34 trunk in state-dict order."""
+def resnet34_conv_specs(blocks=RESNET50_BLOCKS):
+    """(name, cin, cout, k, stride, pad, bn_name) of the torchvision ResNet-34 (ResNet-18 by ``blocks``) trunk in state-dict order."""
     specs = [('conv1', 3, 64, 7, 2, 3, 'bn1')]
     inplanes = 64
-    for li, (nb, planes) in enumerate(zip(RESNET50_BLOCKS, RESNET50_PLANES), start=1):
+    for li, (nb, planes) in enumerate(zip(blocks, RESNET50_PLANES), start=1):
         for b in range(nb):
             stride = 2 if (b == 0 and li > 1) else 1
             p = f'layer{li}.{b}'
@@ -129,10 +133,10 @@ def resnet34_conv_specs():
     return specs
 
 
-def resnet34_state(seed: int, prefix: str = '') -> 'OrderedDict[str, np.ndarray]':
-    """Random ResNet-34 trunk parameters, activations O(1) through the 16 blocks (bn2 damps the residual branch)."""
+def resnet34_state(seed: int, prefix: str = '', blocks=RESNET50_BLOCKS) -> 'OrderedDict[str, np.ndarray]':
+    """Random ResNet-34 (18 by ``blocks``) trunk parameters, activations O(1) through the blocks (bn2 damps the residual branch)."""
     sd = OrderedDict()
-    for (name, cin, cout, k, _s, _p, bn) in resnet34_conv_specs():
+    for (name, cin, cout, k, _s, _p, bn) in resnet34_conv_specs(blocks):
         sd[f'{prefix}{name}.weight'] = normal(seed, name + '.weight', (cout, cin, k, k), std=math.sqrt(2.0 / (cin * k * k)))
         g0 = 0.25 if bn.endswith('bn2') else (0.7 if bn.endswith('downsample.1') else 1.0)
         sd[f'{prefix}{bn}.weight'] = (g0 * (1.0 + 0.1 * normal(seed, bn + '.weight', (cout,)))).astype(np.float32)
@@ -181,12 +185,19 @@ def hrnet_state(seed: int, width: int = 32, use_conv: bool = True, prefix: str =
     return sd
 
 
+def resnet_family_state(seed: int, backbone: str, prefix: str = ''):
+    """(trunk state, feature width) of a torchvision-family trunk by name (resnet18 / 34 / 50 / 101 / 152)."""
+    kind, blocks = RESNET_FAMILY[backbone]
+    if kind == 'basic':
+        return resnet34_state(seed, prefix, blocks), 512
+    return resnet50_state(seed, prefix, blocks), 2048
+
+
 def camcalib_state(seed: int = 1001, fc_std: float = 0.05, nbins: int = C.NUM_CAMCALIB_BINS, backbone: str = 'resnet50',
                    num_fc_layers: int = 1, num_fc_channels: int = 1024):
     """CameraRegressorNetwork parameters (camcalib/model.py:40-70 layout): one Linear per angle, or the
     ``fc_*.{0..L-1}`` Linear chain of ``_get_fc_layers``."""
-    sd = resnet50_state(seed, 'backbone.') if backbone == 'resnet50' else resnet34_state(seed, 'backbone.')
-    feat = 2048 if backbone == 'resnet50' else 512
+    sd, feat = resnet_family_state(seed, backbone, 'backbone.')
     for head in ('fc_vfov', 'fc_pitch', 'fc_roll'):
         if num_fc_layers == 1:
             sd[f'{head}.weight'] = normal(seed, head + '.weight', (nbins, feat), std=fc_std)
@@ -219,12 +230,8 @@ def hmr_state(seed: int = 1002, use_cam_feats: bool = True, dec_gain: float = 1.
         width = 32 if name == 'hrnet_w32' else 48
         sd = hrnet_state(seed, width, mode == 'conv', 'backbone.')
         feat = width * 15
-    elif backbone == 'resnet34':
-        sd = resnet34_state(seed, 'backbone.')
-        feat = 512
     else:
-        sd = resnet50_state(seed, 'backbone.')
-        feat = 2048
+        sd, feat = resnet_family_state(seed, backbone, 'backbone.')
     nin = feat + 144 + 13 + (7 if use_cam_feats else 0)
 
     def linear(name, nout, nin_, bound=None, bias_bound=None):

@@ -383,6 +383,56 @@ def test_camcalib_model_matrix(backbone, num_fc_layers, num_fc_channels, size):
         assert rel_err(o.cpu().numpy(), r.numpy()) < 1e-4, (backbone, num_fc_layers, num_fc_channels, size)
 
 
+@pytest.mark.parametrize('plan', ['latency', 'throughput'])
+@pytest.mark.parametrize('backbone', ['resnet18', 'resnet101', 'resnet152'])
+def test_other_resnet_depths_vs_oracle(backbone, plan):
+    """The rest of the torchvision family that the reference's ``eval(backbone)(pretrained=True)`` resolves (spec/models/hmr.py:53,
+    camcalib/model.py:33 through pare.models.backbone): BasicBlock [2,2,2,2] and Bottleneck [3,4,23,3] / [3,8,36,3] trunks under
+    CameraRegressorNetwork against the oracle (B = 2; a non-square size for the shallow one)."""
+    from oracle.models import CamCalibOracle, load_numpy_state
+    from spec_amd.modules import CameraRegressorNetwork
+    sd = synth.camcalib_state(1700, backbone=backbone)
+    ref_m = load_numpy_state(CamCalibOracle(backbone).eval(), sd)
+    m = CameraRegressorNetwork(backbone=backbone)
+    m.load_state_dict({k: t(v) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).eval().set_plan(plan)
+    x = t(synth.images(81, 2, 224, 224) if backbone != 'resnet18' else synth.images(81, 2, 160, 288))
+    feat = m.engine(torch.device(DEV)).trunk(x.to(DEV)).cpu()
+    ref = ref_m.backbone(x).permute(0, 2, 3, 1)
+    assert feat.shape == ref.shape
+    assert rel_err(feat.numpy(), ref.numpy()) < 5e-5, (backbone, plan)
+    for o, r in zip(m(x.to(DEV)), ref_m(x)):
+        assert rel_err(o.cpu().numpy(), r.numpy()) < 1e-4
+
+
+def test_hmr_resnet101_end_to_end_vs_oracle():
+    """HMR(backbone='resnet101') - a name the reference's constructor accepts (hmr.py:53) - end to end against the oracle."""
+    from oracle import heads
+    from oracle.models import HMROracle, load_numpy_state, cam_params
+    from spec_amd import assets
+    from spec_amd.modules import HMR
+    from tests.util import smpl_model
+    assets.use_synthetic_assets(1003)
+    heads.set_assets(smpl_model=smpl_model())
+    sd = synth.hmr_state(1701, True, backbone='resnet101')
+    ref_m = load_numpy_state(HMROracle(backbone='resnet101', use_cam=True, use_cam_feats=True).eval(), sd)
+    m = HMR(backbone='resnet101', use_cam=True, use_cam_feats=True)
+    missing, unexpected = m.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(k.startswith('smpl.') for k in missing)
+    m = m.to(DEV).eval()
+    B = 2
+    x = t(synth.images(82, B))
+    sc, ce, iw, ih = [t(a) for a in synth.bbox_inputs(82, B, 640., 480.)]
+    g = torch.Generator().manual_seed(7)
+    R, K = cam_params(0.3 * torch.randn(B, generator=g), 0.2 * torch.randn(B, generator=g),
+                      (400 + 200 * torch.rand(B, generator=g)).numpy(), iw, ih)
+    ref = ref_m(x, R, K, sc, ce, iw, ih)
+    out = m(x.to(DEV), cam_rotmat=R.to(DEV), cam_intrinsics=K.to(DEV), bbox_scale=sc.to(DEV), bbox_center=ce.to(DEV),
+            img_w=iw.to(DEV), img_h=ih.to(DEV))
+    for k in ref:
+        assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < TOL, k
+
+
 def test_resnet34_trunk_vs_oracle_batch():
     """ResNet-34 trunk (BasicBlocks: Winograd conv1, direct conv2 with the residual fused) against the oracle, B=3."""
     from oracle.models import CamCalibOracle, load_numpy_state

@@ -231,3 +231,48 @@ def test_latency_plan_other_resolutions_and_resnet34(models):
             outs[plan] = [l.clone() for l in m(xs)]
     for a, b in zip(outs['latency'], outs['throughput']):
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 2e-5
+
+
+def test_fc_heads_small_batch_kernel(models):
+    """Latency plan: the three CamCalib heads as ONE launch and the HMR regressor's composed map on the small-batch GEMV kernel
+    (one wave per output column) - against the matrix-core GEMMs of the throughput plan, batch-invariant across the kernel's
+    blocks of 8 images, and one launch where there were three."""
+    cc, hm = models
+    dev = torch.device(DEV)
+    e = cc.engine(dev)
+    feat = torch.randn(11, 7, 7, 2048, generator=torch.Generator().manual_seed(3)).relu().to(DEV)
+    outs = {}
+    for plan in ('latency', 'throughput'):
+        with pinned_plan(plan, cc):
+            e.profile(True)
+            outs[plan] = [l.clone() for l in e.camcalib_head(feat)]
+            prof = e.profile_read()
+            e.profile(False)
+            fc = [p_ for p_ in prof if p_['label'].startswith('fc_')]
+            assert sum(p_['launches'] for p_ in fc) == (1 if plan == 'latency' else 3), prof
+            assert ('gemv' in fc[0]['kernel']) == (plan == 'latency')
+    for a, b in zip(outs['latency'], outs['throughput']):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 5e-6
+    with pinned_plan('latency', cc):
+        for lo, n in ((0, 1), (7, 2), (8, 3), (10, 1)):      # across the 8-image blocks of the kernel
+            one = e.camcalib_head(feat[lo:lo + n].contiguous())
+            for a, b in zip(one, outs['latency']):
+                assert torch.equal(a, b[lo:lo + n]), (lo, n)
+    # HMR: collapsed regressor and the reference's nine-GEMM loop (residual epilogue) through the same kernel
+    eh = hm.engine(dev)
+    g = torch.Generator().manual_seed(5)
+    f2 = torch.randn(3, 7, 7, 2048, generator=g).relu().to(DEV)
+    R = torch.eye(3).expand(3, 3, 3).contiguous().to(DEV)
+    K = torch.tensor([[500., 0., 320.], [0., 500., 240.], [0., 0., 0.]]).expand(3, 3, 3).contiguous().to(DEV)
+    ih = torch.full((3,), 480.0, device=DEV)
+    res = {}
+    for plan in ('latency', 'throughput'):
+        for collapse in (1, 0):
+            eh.set_option('head_collapse', collapse)
+            with pinned_plan(plan, hm):
+                res[(plan, collapse)] = {k: v.clone() for k, v in eh.hmr_head(f2, R, K, ih).items()}
+    eh.set_option('head_collapse', 1)
+    for k in ('pred_pose_6d', 'pred_shape', 'pred_cam'):
+        ref = res[('throughput', 1)][k].cpu().numpy()
+        for key, v in res.items():
+            assert rel_err(v[k].cpu().numpy(), ref) < 2e-5, (key, k)

@@ -146,7 +146,7 @@ def test_unsupported_variants_raise():
     with pytest.raises(NotImplementedError):
         CameraRegressorNetwork(num_fc_layers=4)
     with pytest.raises(NotImplementedError):
-        HMR(backbone='resnet101')
+        HMR(backbone='mobilenet_v2')            # pare's one trunk outside the torchvision ResNet / HRNet families
     with pytest.raises(NotImplementedError):
         HMR(backbone='hrnet_w18-conv')
     with pytest.raises(NotImplementedError):
@@ -154,7 +154,8 @@ def test_unsupported_variants_raise():
     from spec_amd import assets
     assets.use_synthetic_assets(1003)
     # every trunk the build carries, with the regressor input width the reference derives from get_backbone_info
-    for bb, feat in (('resnet50', 2048), ('resnet34', 512), ('hrnet_w32-conv', 480), ('hrnet_w48-interp', 720)):
+    for bb, feat in (('resnet50', 2048), ('resnet34', 512), ('resnet18', 512), ('resnet101', 2048), ('resnet152', 2048),
+                     ('hrnet_w32-conv', 480), ('hrnet_w48-interp', 720)):
         assert HMR(backbone=bb, use_cam_feats=True).head.fc1.weight.shape == (1024, feat + 144 + 13 + 7)
 
 
