@@ -118,8 +118,9 @@ const char* specmi_version(void);
  *         frame, scripts/camcalib_demo.py:95-102 at batch 1 - every convolution with K >= 512 is cut into K slices that run as ONE
  *         launch (the last slice of a tile to arrive folds the partial tiles and applies BN / residual / ReLU), layer3 / layer4
  *         3x3 convolutions leave Winograd for the sliced direct kernel;
- *     0 = auto (default): latency while the call carries no more pixels than "latency_max_batch" (default 8) images of 224 x 224,
- *         throughput beyond.
+ *     0 = auto (default): latency while the call carries no more pixels than N images of 224 x 224 - N = "latency_max_batch"
+ *         (default 10) for specmi_trunk_forward_pair and the FC heads, "latency_max_batch_single" (default 16) for a single trunk
+ *         (measured crossovers; one CamCalib frame at 600 x 1066 counts as 12.7 images) - throughput beyond.
  *   WITHIN a plan an image's result is bit-identical whatever the batch size, the grouping (specmi_trunk_forward_pair) or the
  *   replay (every k sum has one association fixed by the layer's shape: the latency plan's is a canonical tree - leaves of L chunks,
  *   groups of G leaves - of which a workgroup computes a leaf, a group or the whole by batch size; 8 x 256 rank shards == 2048

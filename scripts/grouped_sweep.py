@@ -16,9 +16,12 @@ from spec_amd.pipeline import SpecPipeline, GraphedPipeline  # noqa: E402
 torch.set_grad_enabled(False)
 dev = torch.device('cuda', 0)
 cc, hm, _, _ = bench.build_models(dev)
+PLAN = os.environ.get('PLAN', 'auto')       # pin the execution plan of both networks: auto | throughput | latency
+for m in (cc, hm):
+    m.set_plan(PLAN)
 for B in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8, 16, 32, 64, 128, 256]:
     x, sc, ce, iw, ih = bench.make_inputs(B, dev, 5)
-    row = {'batch': B}
+    row = {'batch': B, 'plan': PLAN}
     for tag, kw in (('two_streams', dict(overlap=True, grouped=False)), ('grouped', dict(grouped=True)), ('one_stream', dict(overlap=False, grouped=False))):
         run = GraphedPipeline(SpecPipeline(cc, hm, **kw), x, sc, ce, iw, ih)
         n = 200 if B <= 16 else 40 if B <= 64 else 20

@@ -634,7 +634,7 @@ static OpLaunch prepare_op(specmi_handle* h, const TrunkOp& op, const float* ima
     }
     bool wino = c.wino && opt_i(h, "winograd", 1) && conv_wino_supported(a);
     if (latency && !a.force_variant) {
-        // Latency plan (batch <= 8 by default).  Every choice below is a function of the layer's per-image shape, never of the batch:
+        // Latency plan (batch <= 10 by default).  Every choice below is a function of the layer's per-image shape, never of the batch:
         // an image's bits are the same at batch 1 and 16.  Winograd only where an image alone brings enough 2x2 tiles to
         // fill its 32-tile rows (layer1 / layer2 at 224^2); layer3 / layer4 (49 / 16 tiles per image, U = 16/9 of the
         // weight bytes) run the direct kernel over K slices.
@@ -648,17 +648,19 @@ static OpLaunch prepare_op(specmi_handle* h, const TrunkOp& op, const float* ima
     return L;
 }
 
-// plan: 0 auto, 1 throughput, 2 latency.  auto = latency while the call carries no more pixels than option "latency_max_batch"
-// (8) images of 224 x 224 (measured per batch size, profiles/r04_b_latency_layers.txt: level at 8, the throughput kernels ahead
-// from 12) - a single CamCalib frame at 600 x 1066 (12.7 crops' worth of rows per layer) takes the throughput plan
-static bool use_latency_plan(specmi_handle* h, int B, int H, int W) {
+// plan: 0 auto, 1 throughput, 2 latency.  auto = latency while the call carries no more pixels than N images of 224 x 224,
+// N = option "latency_max_batch" (10) for the trunk PAIR and "latency_max_batch_single" (16) for one trunk - measured per batch size
+// (profiles/r04_l_plan_crossover.jsonl: pair 1.67 vs 1.78 ms at 10 images, 2.18 vs 2.15 at 12; one trunk after the other 3.08 vs
+// 3.32 ms still at 16; a single CamCalib frame at 600 x 1066 = 12.7 crops' worth of rows: 2.10 vs 2.27 ms for the demo's one-frame step)
+static bool use_latency_plan(specmi_handle* h, int B, int H, int W, bool pair = false) {
     const int plan = opt_i(h, "plan", 0);
-    return plan == 2 || (plan == 0 && (long)B * H * W <= (long)opt_i(h, "latency_max_batch", 8) * 224 * 224);
+    const int nmax = pair ? opt_i(h, "latency_max_batch", 10) : opt_i(h, "latency_max_batch_single", 16);
+    return plan == 2 || (plan == 0 && (long)B * H * W <= (long)nmax * 224 * 224);
 }
 // the FC layers behind the trunk see batch rows only: the small-batch GEMV kernel (head.hip) up to "latency_max_batch" rows
 static bool use_latency_heads(specmi_handle* h, int B) {
     const int plan = opt_i(h, "plan", 0);
-    return opt_i(h, "fc_gemv", 1) && (plan == 2 || (plan == 0 && B <= opt_i(h, "latency_max_batch", 8)));
+    return opt_i(h, "fc_gemv", 1) && (plan == 2 || (plan == 0 && B <= opt_i(h, "latency_max_batch", 10)));
 }
 
 // partner != nullptr: the same op of a second network, launched together (one grouped launch); the caller has checked
@@ -836,7 +838,7 @@ static int run_trunk_pair(specmi_handle* ha, specmi_handle* hb, const float* img
     plan_trunk(ha, H, W, true, Pa);
     plan_trunk(hb, H, W, true, Pb);
     if (Pa.ops.size() != Pb.ops.size()) return fail(ha, SPECMI_ERR_ARG, "the two trunks have different depths");
-    const bool lat = use_latency_plan(ha, B, H, W);   // the first handle's options decide for the pair
+    const bool lat = use_latency_plan(ha, B, H, W, true);   // the first handle's options decide for the pair
     for (size_t i = 0; i < Pa.ops.size(); ++i) {
         const OpLaunch La = prepare_op(ha, Pa.ops[i], img_a, feat_a, 0, B, H, W, lat);
         OpLaunch Lb = prepare_op(hb, Pb.ops[i], img_b, feat_b, 0, B, H, W, lat);

@@ -26,7 +26,7 @@
 //     The 8-wave 128x128 kernel (HBM-bound expand convs) keeps B staged in LDS as [8][BN][4].
 //   * Variants: two A sources (K = Cin + Cin2: a bottleneck's downsample conv folded into conv3),
 //     split-K over blockIdx.y (SPLITK) for small M - the FC GEMMs of every plan and every convolution of the
-//     LATENCY plan (batch <= 8 by default: the reference's own operating point, spec/tester.py:109-151 runs the path at
+//     LATENCY plan (batch <= 10 by default: the reference's own operating point, spec/tester.py:109-151 runs the path at
 //     batch = #detections of a frame, scripts/camcalib_demo.py:95-102 at batch 1): a layer that offers 8-64
 //     output tiles walks K = 1024-4608 on as many CUs while 200 idle; cut into S slices of whole 32-channel
 //     chunks it fills the chip.  Slice z leaves its raw accumulators in a workspace, takes a ticket from the

@@ -314,7 +314,7 @@ class _EngineModule(nn.Module):
 
     # Execution plan of the trunk (include/specmi.h, option "plan"): 'throughput' = the kernels the batch-256 headline runs
     # (Winograd + 64x64 / 128x128 implicit GEMM); 'latency' = every convolution cut into K slices that fill the chip at batch
-    # 1-8 (one launch per layer, one canonical summation tree); 'auto' (default) = latency up to 8 images per call.  Within a plan an
+    # 1-8 (one launch per layer, one canonical summation tree); 'auto' (default) = latency up to 10 images per call (16 for a single trunk).  Within a plan an
     # image's result is bit-identical whatever the batch size; between plans the last bits differ (contract: 1e-4).
     PLANS = {'auto': 0, 'throughput': 1, 'latency': 2}
     plan = 'auto'

@@ -135,7 +135,7 @@ class SPECTester:
         plan (``args.plan``: 'throughput' | 'latency' | 'auto', see ``spec_amd.modules._EngineModule.set_plan``) an image's
         outputs do not depend on the batch it travels in (every kernel of the path has a fixed summation order), so with the
         plan pinned the per-frame ``spec_results/<stem>.pkl`` files are bit-identical to ``frame_batch=1``, the reference's
-        own structure.  Default: 'throughput' when frames are batched, 'auto' (the latency plan for up to 8 detections) for
+        own structure.  Default: 'throughput' when frames are batched, 'auto' (the latency plan for up to 10 detections) for
         one forward per frame - last bits then differ between the two settings (contract: 1e-4).
         Decode-ahead is bounded: at most 2 x ``args.decode_threads`` decoded frames wait in host memory (the reference holds
         one frame at a time; an unbounded queue would keep a whole video folder in RAM when decoding outruns the GPU)."""

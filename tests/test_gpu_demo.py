@@ -27,12 +27,12 @@ def _frames(seed, F, H, W):
     return torch.from_numpy(np.ascontiguousarray(fr))
 
 
-@pytest.mark.parametrize('plan', ['auto', 'throughput', 'latency'])
+@pytest.mark.parametrize('plan', ['throughput', 'latency'])
 def test_batched_full_resolution_camcalib_equals_per_frame(models, plan):
     """F frames of 540 x 960 -> Resize(600) = 600 x 1066 (the 1080p geometry: final map 19 x 34, M no tile multiple) in ONE
     CamCalib call == one call per frame, bit for bit - the batched transform writes the same pixels and an image's logits do
-    not depend on the batch within a plan ('auto': a 600 x 1066 frame carries more rows than 8 crops - 3 frames and 1 frame
-    both take the throughput plan)."""
+    not depend on the batch within a plan (under 'auto' one 600 x 1066 frame - 12.7 crops' worth of rows - takes the latency plan and
+    three take the throughput plan: equal to fp32 rounding only, checked at the end)."""
     from spec_amd.preprocess import camcalib_transform, camcalib_transform_batch
     cc, _ = models
     F = 3
@@ -47,6 +47,10 @@ def test_batched_full_resolution_camcalib_equals_per_frame(models, plan):
             one = cc(xf)
             for a, b in zip(one, batched):
                 assert torch.equal(a[0], b[f]), (plan, f)
+    if plan == 'throughput':      # the default plan switches between 1 and 3 frames of this size: same logits to fp32 rounding
+        one = cc(camcalib_transform(frames[0], 600))
+        for a, b in zip(one, batched):
+            assert rel_err(a[0].cpu().numpy(), b[0].cpu().numpy()) < 1e-5
 
 
 def test_full_resolution_camcalib_vs_oracle(models):

@@ -163,7 +163,7 @@ def test_tester_batched_equals_per_frame(tmp_path):
         for f, ref in results['per_frame'].items():
             for key, v in ref.items():
                 assert results[tag][f][key].shape == v.shape and np.array_equal(results[tag][f][key], v), (tag, f, key)
-    # the default of one-forward-per-frame is the latency plan for up to 8 detections: same results to fp32 rounding
+    # the default of one-forward-per-frame is the latency plan for up to 10 detections: same results to fp32 rounding
     for f, ref in results['per_frame'].items():
         for key in ('smpl_vertices', 'smpl_joints2d', 'pred_cam_t'):
             a, b = results['per_frame_default_plan'][f][key].astype(np.float64), ref[key].astype(np.float64)

@@ -125,10 +125,10 @@ def models():
 
 
 def test_plan_selection_and_launch_count(models):
-    """auto: latency up to 8 images, throughput beyond; one launch per layer either way."""
+    """auto: a single trunk takes the latency plan up to 16 images, throughput beyond; one launch per layer either way."""
     _, hm = models
     e = hm.engine(torch.device(DEV))
-    for B, want in ((1, True), (8, True), (9, False)):
+    for B, want in ((1, True), (16, True), (17, False)):
         x = t(synth.images(5, B)).to(DEV)
         e.profile(True)
         e.trunk(x)

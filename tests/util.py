@@ -69,7 +69,7 @@ def gpu_models(use_cam=True, use_cam_feats=True, device='cuda:0'):
 @contextlib.contextmanager
 def pinned_plan(plan, *modules):
     """Run a block with the trunk execution plan of ``modules`` pinned ('throughput' | 'latency' | 'auto').  Bit-identity
-    across batch sizes holds WITHIN a plan; 'auto' (the default) switches to the latency plan at 8 images or fewer."""
+    across batch sizes holds WITHIN a plan; 'auto' (the default) switches to the latency plan at 10 images or fewer (16 for a single trunk)."""
     old = [m.plan for m in modules]
     for m in modules:
         m.set_plan(plan)
