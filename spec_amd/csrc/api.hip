@@ -464,7 +464,11 @@ static int ensure_ws(specmi_handle* h, int B, int H, int W) {
     const bool grow_b = B > h->ws_B;
     if (!grow_act && !grow_b) return SPECMI_OK;
     HIPCHK(h, hipDeviceSynchronize());
-    free_pool(h->ws_allocs);
+    // the outgrown buffers stay alive until specmi_destroy (as the split-K workspace does): a hipGraph captured at a smaller
+    // batch / resolution has their addresses baked into its kernel nodes, and replaying it after an eager call at a larger size
+    // must not write into freed memory.  Growth is monotonic, so what is retired is bounded by the final size.
+    h->ws_retired.insert(h->ws_retired.end(), h->ws_allocs.begin(), h->ws_allocs.end());
+    h->ws_allocs.clear();
     if (elems < h->act_elems) elems = h->act_elems;
     const int Bw = B > h->ws_B ? B : h->ws_B;
     // the workspace is gone from here on: if an allocation below fails, the next call must not take the early return
@@ -983,6 +987,7 @@ int specmi_destroy(specmi_handle* h) {
     if (h->sk.ws) (void)hipFree(h->sk.ws);
     if (h->sk.cnt) (void)hipFree(h->sk.cnt);
     free_pool(h->sk_retired);
+    free_pool(h->ws_retired);
     if (h->resize_tab) (void)hipFree(h->resize_tab);
     hrnet_free(h->hrnet);
     delete h;

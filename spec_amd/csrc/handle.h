@@ -76,6 +76,7 @@ struct specmi_handle {
 
     // workspace (device), grown on demand
     std::vector<void*> ws_allocs;
+    std::vector<void*> ws_retired;      // outgrown workspaces, kept until destroy (captured graphs may still name them)
     float* act[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t act_elems = 0;
     float *xc = nullptr, *h1 = nullptr, *h2 = nullptr, *xf = nullptr;

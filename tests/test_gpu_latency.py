@@ -276,3 +276,24 @@ def test_fc_heads_small_batch_kernel(models):
         ref = res[('throughput', 1)][k].cpu().numpy()
         for key, v in res.items():
             assert rel_err(v[k].cpu().numpy(), ref) < 2e-5, (key, k)
+
+
+def test_graph_captured_before_workspace_growth_still_replays():
+    """A hipGraph has the workspace addresses baked in.  Growing the workspaces afterwards (an eager call at a larger batch) must not
+    free what the graph still writes to: outgrown buffers are retired, not released, until the handle is destroyed."""
+    from spec_amd.pipeline import SpecPipeline, GraphedPipeline
+    cc, hm = gpu_models(True, True, DEV)          # fresh handles: their workspaces start at the size of the first call
+    B = 2
+    x = t(synth.images(61, 48)).to(DEV)
+    sc, ce, iw, ih = [t(a).to(DEV) for a in synth.bbox_inputs(61, 48, 640., 480.)]
+    small = [a[:B].contiguous() for a in (x, sc, ce, iw, ih)]
+    pipe = SpecPipeline(cc, hm, grouped=True)
+    g = GraphedPipeline(pipe, *small)
+    ref = {k: v.clone() for k, v in g(*small).items() if k in ('smpl_vertices', 'smpl_joints2d', 'cam_vfov')}
+    big = pipe(x, sc, ce, iw, ih)                 # activations, split-K slabs, head rows: everything grows 24-fold
+    assert torch.isfinite(big['smpl_vertices']).all()
+    junk = [torch.full((64 << 20,), float('nan'), device=DEV) for _ in range(8)]     # would land in freed blocks
+    out = g(*small)
+    for k, v in ref.items():
+        assert torch.equal(out[k], v), k
+    del junk
