@@ -642,7 +642,10 @@ static OpLaunch prepare_op(specmi_handle* h, const TrunkOp& op, const float* ima
         // an image's bits are the same at batch 1 and 16.  Winograd only where an image alone brings enough 2x2 tiles to
         // fill its 32-tile rows (layer1 / layer2 at 224^2); layer3 / layer4 (49 / 16 tiles per image, U = 16/9 of the
         // weight bytes) run the direct kernel over K slices.
-        if (wino && ((a.OH + 1) / 2) * ((a.OW + 1) / 2) < opt_i(h, "latency_wino_min_tiles", 128)) wino = false;
+        // (wide layers need proportionally more tiles: layer4 of a 600 x 1066 frame has 170 tiles per image = 48 Winograd workgroups
+        // walking Cin = 512 for 75 us, the sliced direct kernel takes 45)
+        const int min_tiles = opt_i(h, "latency_wino_min_tiles", 128);
+        if (wino && ((a.OH + 1) / 2) * ((a.OW + 1) / 2) < (min_tiles > a.Cin || min_tiles == 0 || min_tiles >= 100000 ? min_tiles : a.Cin)) wino = false;
         if (!wino) L.sk = conv_igemm_sk_slices(a, opt_i(h, "latency_target_wgs", 256), opt_i(h, "latency_min_chunks", 4));
     }
     if (wino) {

@@ -268,12 +268,50 @@ __global__ void __launch_bounds__(256) avgpool_kernel(const float* __restrict__ 
     (void)inv;
 }
 
+// Large maps at small batch (CamCalib on a full frame: 19 x 34 = 646 positions, one image): one thread per (image, channel quad)
+// walks all positions serially - 37 us for 5 MB.  Here a workgroup = 64 channel quads x P parts of the map (P a function of HW ALONE,
+// so the summation order - part sums left to right, parts folded in order - never depends on the batch); P = 1 is the kernel above
+// (224^2 crops: HW = 49, bits unchanged).
+__global__ void __launch_bounds__(1024) avgpool_parts_kernel(const float* __restrict__ x, float* __restrict__ out, int HW,
+                                                             int C4, int ldo, int parts, int chunk) {
+    __shared__ f32x4 red[16][64];
+    const int lane = threadIdx.x, part = threadIdx.y;
+    const int c4 = blockIdx.x * 64 + lane, b = blockIdx.y;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (c4 < C4) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(x) + (size_t)b * HW * C4 + c4;
+        const int p0 = part * chunk, p1 = min(HW, p0 + chunk);
+#pragma unroll 8
+        for (int p = p0; p < p1; ++p) {
+            const f32x4 v = src[(size_t)p * C4];
+            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+        }
+    }
+    red[part][lane] = s;
+    __syncthreads();
+    if (part == 0 && c4 < C4) {
+        f32x4 t = red[0][lane];
+        for (int q = 1; q < parts; ++q) {
+            const f32x4 v = red[q][lane];
+            t[0] += v[0]; t[1] += v[1]; t[2] += v[2]; t[3] += v[3];
+        }
+        float* o = out + (size_t)b * ldo + c4 * 4;
+        o[0] = t[0] / (float)HW; o[1] = t[1] / (float)HW; o[2] = t[2] / (float)HW; o[3] = t[3] / (float)HW;
+    }
+}
+
 int launch_avgpool(const float* x, float* out, int B, int HW, int C, int ldo, const LaunchCtx& ctx) {
     if (C % 4) return (int)hipErrorInvalidValue;
     const int total = B * (C / 4);
     ProfScope ps(ctx, "avgpool_f32", 0.0, 4.0 * ((double)B * HW * C + (double)B * C));
-    hipLaunchKernelGGL(avgpool_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx.stream, x, out, HW, C / 4, ldo,
-                       total);
+    int parts = HW / 32;                       // a function of the map size only
+    parts = parts < 1 ? 1 : (parts > 16 ? 16 : parts);
+    if (parts == 1) {
+        hipLaunchKernelGGL(avgpool_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx.stream, x, out, HW, C / 4, ldo, total);
+    } else {
+        const int C4 = C / 4, chunk = (HW + parts - 1) / parts;
+        hipLaunchKernelGGL(avgpool_parts_kernel, dim3((C4 + 63) / 64, B), dim3(64, parts), 0, ctx.stream, x, out, HW, C4, ldo, parts, chunk);
+    }
     return (int)hipGetLastError();
 }
 
