@@ -86,7 +86,7 @@ def test_every_slice_count_and_ragged_rows(eng, S):
 
 
 @pytest.mark.parametrize('cin,cout,k,stride,hw,B', [(512, 512, 3, 1, 7, 1), (512, 512, 3, 1, 7, 5), (1024, 256, 1, 1, 14, 2), (128, 128, 3, 2, 56, 1),
-                                                    (2048, 512, 1, 1, 7, 16), (256, 64, 1, 1, 56, 1)])
+                                                    (2048, 512, 1, 1, 7, 16), (256, 64, 1, 1, 56, 1), (64, 64, 3, 1, 56, 1), (128, 128, 3, 1, 28, 3), (512, 2048, 1, 1, 7, 2)])
 def test_units_of_the_canonical_tree_are_bit_identical(eng, cin, cout, k, stride, hw, B):
     """How much of a layer's k-sum tree one workgroup computes - a leaf, a group of leaves, or the whole K - is chosen per batch
     size for speed; the association of the sum is the tree's, whoever adds: the three give the same bits."""
