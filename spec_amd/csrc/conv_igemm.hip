@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KA
         // The loop body is a whole (even, odd) pair and an odd chunk count ends in a peeled tail: with the odd chunk under an
         // `if` inside the loop the compiler's wait-count pass sees a path even -> even, assumes six fewer loads in flight and
         // waits for vmcnt(3) instead of vmcnt(9) at the top of every even chunk - the two-chunk prefetch distance collapses to
-        // less than one (a lone wave then runs the loop at 0.65 of the matrix pipe).
+        // less than one.
         int c = 0;
         for (; c + 2 <= p.nchunks; c += 2) {
             sk_chunk(c, even);
