@@ -8,30 +8,6 @@ from spec_amd import synth
 from tests.util import golden, gpu_models, oracle_models, rel_err, t, smpl_model
 torch.set_grad_enabled(False)
 DEV = 'cuda:0'
-print('--- GPU vs golden fixtures produced by the reference modules (relative max-norm error)')
-for tag, uc, ucf in (('camfeats', True, True), ('cam', True, False), ('nocam', False, False)):
-    g = golden(f'hmr_e2e_{tag}.npz'); _, hm = gpu_models(uc, ucf, DEV); B = int(g['batch'])
-    x = t(synth.images(int(g['seed_images']), B)).to(DEV)
-    out = hm(x, t(g['cam_rotmat']).to(DEV), t(g['cam_intrinsics']).to(DEV), t(g['bbox_scale']).to(DEV), t(g['bbox_center']).to(DEV), t(g['img_w']).to(DEV), t(g['img_h']).to(DEV)) if uc else hm(x)
-    print(tag, {k: f'{rel_err(out[k].cpu().numpy(), g["out_" + k]):.1e}' for k in out})
-g = golden('camcalib_e2e.npz'); cc, hm = gpu_models(True, True, DEV)
-lg = cc(t(synth.images(int(g['seed_images']), int(g['batch']))).to(DEV))
-print('camcalib logits', [f'{rel_err(l.cpu().numpy(), g[k]):.1e}' for l, k in zip(lg, ('logits_vfov', 'logits_pitch', 'logits_roll'))])
-from oracle.models import full_pipeline
-from spec_amd.pipeline import SpecPipeline
-occ, ohm = oracle_models(True, True)
-B = 8
-x = t(synth.images(31, B)); sc, ce, iw, ih = [t(a) for a in synth.bbox_inputs(31, B, 640., 480.)]
-ref = full_pipeline(occ, ohm, x, sc, ce, iw, ih)
-out = SpecPipeline(cc, hm)(x.to(DEV), sc.to(DEV), ce.to(DEV), iw.to(DEV), ih.to(DEV))
-print('--- full pipeline vs CPU oracle, B=8')
-print({k: f'{rel_err(out[k].cpu().numpy(), ref[k].numpy()):.1e}' for k in ('cam_vfov', 'cam_pitch', 'cam_roll', 'smpl_vertices', 'smpl_joints3d', 'smpl_joints2d', 'pred_cam_t', 'pred_pose', 'pred_shape', 'pred_cam')})
-J = smpl_model()['J_regressor'].astype(np.float64)
-ja = np.einsum('jv,bvc->bjc', J, out['smpl_vertices'].cpu().numpy().astype(np.float64)); jb = np.einsum('jv,bvc->bjc', J, ref['smpl_vertices'].numpy().astype(np.float64))
-ja -= ja[:, :1]; jb -= jb[:, :1]
-print('delta W-MPJPE (mm):', float(np.sqrt(((ja - jb) ** 2).sum(-1)).mean() * 1000))
-
-
 def elementwise(name, a, b, unit, floor):
     """Element-wise figures beside the tensor max-norm: absolute error percentiles, and the relative error of every element
     whose reference magnitude is above ``floor`` (near-zero coordinates make an element-wise relative error meaningless)."""
@@ -46,11 +22,38 @@ def elementwise(name, a, b, unit, floor):
           f'{b.min():.1f} .. {b.max():.1f})')
 
 
-print('--- element-wise error figures (the contract is 1e-4 in the tensor max-norm; these show what that hides)')
-elementwise('smpl_joints2d  full pipeline vs CPU oracle, B=8', out['smpl_joints2d'].cpu().numpy(), ref['smpl_joints2d'].numpy(), 'px', 1.0)
-elementwise('smpl_joints3d  full pipeline vs CPU oracle, B=8', out['smpl_joints3d'].cpu().numpy(), ref['smpl_joints3d'].numpy(), 'm', 1e-2)
-elementwise('smpl_vertices  full pipeline vs CPU oracle, B=8', out['smpl_vertices'].cpu().numpy(), ref['smpl_vertices'].numpy(), 'm', 1e-2)
-g = golden('hmr_e2e_camfeats.npz'); _, hm2 = gpu_models(True, True, DEV); B = int(g['batch'])
-x = t(synth.images(int(g['seed_images']), B)).to(DEV)
-o2 = hm2(x, t(g['cam_rotmat']).to(DEV), t(g['cam_intrinsics']).to(DEV), t(g['bbox_scale']).to(DEV), t(g['bbox_center']).to(DEV), t(g['img_w']).to(DEV), t(g['img_h']).to(DEV))
-elementwise('smpl_joints2d  GPU vs reference-composed fixture (camfeats)', o2['smpl_joints2d'].cpu().numpy(), g['out_smpl_joints2d'], 'px', 1.0)
+
+for PLAN in ('latency', 'throughput'):
+    print(f'================ execution plan: {PLAN} (include/specmi.h, option "plan") ================')
+    print('--- GPU vs golden fixtures produced by the reference modules (relative max-norm error)')
+    for tag, uc, ucf in (('camfeats', True, True), ('cam', True, False), ('nocam', False, False)):
+        g = golden(f'hmr_e2e_{tag}.npz'); _, hm = gpu_models(uc, ucf, DEV); hm.set_plan(PLAN); B = int(g['batch'])
+        x = t(synth.images(int(g['seed_images']), B)).to(DEV)
+        out = hm(x, t(g['cam_rotmat']).to(DEV), t(g['cam_intrinsics']).to(DEV), t(g['bbox_scale']).to(DEV), t(g['bbox_center']).to(DEV), t(g['img_w']).to(DEV), t(g['img_h']).to(DEV)) if uc else hm(x)
+        print(tag, {k: f'{rel_err(out[k].cpu().numpy(), g["out_" + k]):.1e}' for k in out})
+    g = golden('camcalib_e2e.npz'); cc, hm = gpu_models(True, True, DEV); cc.set_plan(PLAN); hm.set_plan(PLAN)
+    lg = cc(t(synth.images(int(g['seed_images']), int(g['batch']))).to(DEV))
+    print('camcalib logits', [f'{rel_err(l.cpu().numpy(), g[k]):.1e}' for l, k in zip(lg, ('logits_vfov', 'logits_pitch', 'logits_roll'))])
+    from oracle.models import full_pipeline
+    from spec_amd.pipeline import SpecPipeline
+    occ, ohm = oracle_models(True, True)
+    B = 8
+    x = t(synth.images(31, B)); sc, ce, iw, ih = [t(a) for a in synth.bbox_inputs(31, B, 640., 480.)]
+    ref = full_pipeline(occ, ohm, x, sc, ce, iw, ih)
+    out = SpecPipeline(cc, hm)(x.to(DEV), sc.to(DEV), ce.to(DEV), iw.to(DEV), ih.to(DEV))
+    print('--- full pipeline vs CPU oracle, B=8')
+    print({k: f'{rel_err(out[k].cpu().numpy(), ref[k].numpy()):.1e}' for k in ('cam_vfov', 'cam_pitch', 'cam_roll', 'smpl_vertices', 'smpl_joints3d', 'smpl_joints2d', 'pred_cam_t', 'pred_pose', 'pred_shape', 'pred_cam')})
+    J = smpl_model()['J_regressor'].astype(np.float64)
+    ja = np.einsum('jv,bvc->bjc', J, out['smpl_vertices'].cpu().numpy().astype(np.float64)); jb = np.einsum('jv,bvc->bjc', J, ref['smpl_vertices'].numpy().astype(np.float64))
+    ja -= ja[:, :1]; jb -= jb[:, :1]
+    print('delta W-MPJPE (mm):', float(np.sqrt(((ja - jb) ** 2).sum(-1)).mean() * 1000))
+
+
+    print('--- element-wise error figures (the contract is 1e-4 in the tensor max-norm; these show what that hides)')
+    elementwise('smpl_joints2d  full pipeline vs CPU oracle, B=8', out['smpl_joints2d'].cpu().numpy(), ref['smpl_joints2d'].numpy(), 'px', 1.0)
+    elementwise('smpl_joints3d  full pipeline vs CPU oracle, B=8', out['smpl_joints3d'].cpu().numpy(), ref['smpl_joints3d'].numpy(), 'm', 1e-2)
+    elementwise('smpl_vertices  full pipeline vs CPU oracle, B=8', out['smpl_vertices'].cpu().numpy(), ref['smpl_vertices'].numpy(), 'm', 1e-2)
+    g = golden('hmr_e2e_camfeats.npz'); _, hm2 = gpu_models(True, True, DEV); hm2.set_plan(PLAN); B = int(g['batch'])
+    x = t(synth.images(int(g['seed_images']), B)).to(DEV)
+    o2 = hm2(x, t(g['cam_rotmat']).to(DEV), t(g['cam_intrinsics']).to(DEV), t(g['bbox_scale']).to(DEV), t(g['bbox_center']).to(DEV), t(g['img_w']).to(DEV), t(g['img_h']).to(DEV))
+    elementwise('smpl_joints2d  GPU vs reference-composed fixture (camfeats)', o2['smpl_joints2d'].cpu().numpy(), g['out_smpl_joints2d'], 'px', 1.0)
