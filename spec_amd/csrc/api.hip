@@ -453,6 +453,19 @@ static int commit_smpl(specmi_handle* h) {
 // ------------------------------------------------------------------------------------------
 int conv_out(int x, int k, int s, int p) { return (x + 2 * p - k) / s + 1; }
 
+// Growing a workspace synchronises the device, frees and allocates - all of which a stream capture forbids.  Say so in words
+// instead of a bare HIP error: the remedy is one eager forward of the shape before capturing (GraphedPipeline / GraphedStep do it).
+static int sync_for_growth(specmi_handle* h, const char* what) {
+    const hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) return SPECMI_OK;
+    (void)hipGetLastError();
+    if (e == hipErrorStreamCaptureUnsupported || e == hipErrorStreamCaptureImplicit || e == hipErrorStreamCaptureInvalidated ||
+        e == hipErrorStreamCaptureIsolation || e == hipErrorStreamCaptureWrongThread || e == hipErrorStreamCaptureUnjoined)
+        return fail(h, SPECMI_ERR_STATE, "%s must grow for this batch / resolution, which is not possible while a stream is being "
+                    "captured: run one eager forward of this shape first (the capture is invalid now)", what);
+    return fail(h, SPECMI_ERR_HIP, "hipDeviceSynchronize failed while growing %s: %s", what, hipGetErrorString(e));
+}
+
 static int ensure_ws(specmi_handle* h, int B, int H, int W) {
     const int oh1 = conv_out(H, 7, 2, 3), ow1 = conv_out(W, 7, 2, 3);
     // largest activation: stem output (B,oh1,ow1,64) == layer1 output (B,oh1/2,ow1/2,256) rounded up
@@ -463,7 +476,7 @@ static int ensure_ws(specmi_handle* h, int B, int H, int W) {
     const bool grow_act = elems > h->act_elems;
     const bool grow_b = B > h->ws_B;
     if (!grow_act && !grow_b) return SPECMI_OK;
-    HIPCHK(h, hipDeviceSynchronize());
+    if (int rc0 = sync_for_growth(h, "the activation workspace")) return rc0;
     // the outgrown buffers stay alive until specmi_destroy (as the split-K workspace does): a hipGraph captured at a smaller
     // batch / resolution has their addresses baked into its kernel nodes, and replaying it after an eager call at a larger size
     // must not write into freed memory.  Growth is monotonic, so what is retired is bounded by the final size.
@@ -505,7 +518,7 @@ static int ensure_ws(specmi_handle* h, int B, int H, int W) {
 // stream capture forbids: the eager warm-up call of a shape (GraphedPipeline runs two) sizes it, captures find it large enough.
 static int ensure_sk(specmi_handle* h, size_t floats, int ncnt) {
     if (floats <= h->sk.floats && ncnt <= h->sk.ncnt) return SPECMI_OK;
-    HIPCHK(h, hipDeviceSynchronize());
+    if (int rc0 = sync_for_growth(h, "the split-K workspace")) return rc0;
     if (floats < h->sk.floats) floats = h->sk.floats;
     if (ncnt < h->sk.ncnt) ncnt = h->sk.ncnt;
     floats = (floats + ((size_t)1 << 20) - 1) >> 20 << 20;
@@ -819,7 +832,7 @@ static int run_trunk(specmi_handle* h, const float* images, int B, int H, int W,
         for (int b0 = 0; b0 < B; b0 += S) {
             const int nb = (B - b0 < S) ? B - b0 : S;
             for (size_t i = 0; i < first_full; ++i)
-                if ((rc = exec_op(h, ops[i], images, feat_out, b0, nb, H, W, s))) return rc;
+                if ((rc = exec_op(h, ops[i], images, feat_out, b0, nb, H, W, s, use_latency_plan(h, B, H, W)))) return rc;
         }
     }
     const bool lat = use_latency_plan(h, B, H, W);
