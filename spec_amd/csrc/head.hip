@@ -151,32 +151,40 @@ struct GemvArgs {
     int nheads, N, Kp, ldx, ldo, B;   // w: (N, Kp) row-major, zero padded beyond the true K; x rows ldx apart (>= Kp floats readable)
 };
 
+// NB = images per wave (1 / 2 / 4 / 8: the smallest that covers the batch, so that a single image does not pay for eight)
+template <int NB>
 __global__ void __launch_bounds__(256) fc_gemv_kernel(const GemvArgs a) {
     const GemvHead& hd = a.hd[blockIdx.y];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + wave;
-    const int b0 = blockIdx.z * 8;
+    const int b0 = blockIdx.z * NB;
     if (n >= a.N) return;
-    const int nb = min(8, a.B - b0);
+    const int nb = min(NB, a.B - b0);
     const float* wrow = hd.w + (size_t)n * a.Kp;
-    float acc[8];
+    float acc[NB];
 #pragma unroll
-    for (int b = 0; b < 8; ++b) acc[b] = 0.f;
+    for (int b = 0; b < NB; ++b) acc[b] = 0.f;
+    // rows past the batch re-read the last image (results discarded): no branch in the loop, so the nine loads of a k step are
+    // independent and several steps are in flight (with `if (b < nb)` around each image the loads serialised: 24 us at batch 8)
+    const float* xrow[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) xrow[b] = hd.x + (size_t)(b0 + (b < nb ? b : nb - 1)) * a.ldx;
+#pragma unroll 2
     for (int k = lane * 4; k < a.Kp; k += 256) {
         const float4 wv = *reinterpret_cast<const float4*>(wrow + k);
+        float4 xv[NB];
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            if (b < nb) {
-                const float4 xv = *reinterpret_cast<const float4*>(hd.x + (size_t)(b0 + b) * a.ldx + k);
-                acc[b] = fmaf(wv.x, xv.x, acc[b]);
-                acc[b] = fmaf(wv.y, xv.y, acc[b]);
-                acc[b] = fmaf(wv.z, xv.z, acc[b]);
-                acc[b] = fmaf(wv.w, xv.w, acc[b]);
-            }
+        for (int b = 0; b < NB; ++b) xv[b] = *reinterpret_cast<const float4*>(xrow[b] + k);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            acc[b] = fmaf(wv.x, xv[b].x, acc[b]);
+            acc[b] = fmaf(wv.y, xv[b].y, acc[b]);
+            acc[b] = fmaf(wv.z, xv[b].z, acc[b]);
+            acc[b] = fmaf(wv.w, xv[b].w, acc[b]);
         }
     }
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < NB; ++b) {
         float v = acc[b];
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -185,7 +193,7 @@ __global__ void __launch_bounds__(256) fc_gemv_kernel(const GemvArgs a) {
     if (lane < nb) {
         float v = 0.f;
 #pragma unroll
-        for (int b = 0; b < 8; ++b)
+        for (int b = 0; b < NB; ++b)
             if (lane == b) v = acc[b];
         const size_t o = (size_t)(b0 + lane) * a.ldo + n;
         v += hd.bias[n];
@@ -204,7 +212,12 @@ int launch_fc_gemv(const FcGemv* heads, int nheads, int N, int Kp, int ldx, int 
         a.hd[i] = GemvHead{f.x, f.w, f.bias, f.res, f.out};
     }
     ProfScope ps(ctx, "fc_gemv_f32", 2.0 * nheads * (double)B * N * Kp, 4.0 * nheads * ((double)N * Kp + (double)B * (Kp + N)));
-    hipLaunchKernelGGL(fc_gemv_kernel, dim3((N + 3) / 4, nheads, (B + 7) / 8), dim3(256), 0, ctx.stream, a);
+    // an image's sum is the same in every instantiation (lane-local k order, then the shuffle tree): NB only sets how many share a wave
+    const dim3 blk(256);
+    if (B == 1) hipLaunchKernelGGL(fc_gemv_kernel<1>, dim3((N + 3) / 4, nheads, B), blk, 0, ctx.stream, a);
+    else if (B == 2) hipLaunchKernelGGL(fc_gemv_kernel<2>, dim3((N + 3) / 4, nheads, 1), blk, 0, ctx.stream, a);
+    else if (B <= 4) hipLaunchKernelGGL(fc_gemv_kernel<4>, dim3((N + 3) / 4, nheads, 1), blk, 0, ctx.stream, a);
+    else hipLaunchKernelGGL(fc_gemv_kernel<8>, dim3((N + 3) / 4, nheads, (B + 7) / 8), blk, 0, ctx.stream, a);
     return (int)hipGetLastError();
 }
 
