@@ -112,3 +112,35 @@ def test_demo_pipeline_equals_per_frame_composition(models, graph):
     auto = DemoPipeline(cc, hm)(frames, boxes, fidx)
     for k in keys:
         assert rel_err(auto[k].cpu().numpy(), out[k].cpu().numpy()) < 2e-5, k
+
+
+def test_demo_pipeline_ragged_detections_and_empty_step(models):
+    """Frames with different numbers of detections (one frame with none), detections listed out of frame order, and a step without
+    any detection at all: every crop gets ITS frame's camera; an empty step returns empty outputs and the frames' cameras."""
+    from spec_amd.pipeline import DemoPipeline
+    cc, hm = models
+    F, H, W = 3, 300, 420
+    frames = _frames(21, F, H, W).to(DEV)
+    rng = np.random.default_rng(4)
+    fidx_host = np.array([2, 0, 2, 2, 0], dtype=np.int32)                 # frame 1 has no detection
+    n = len(fidx_host)
+    boxes = torch.from_numpy(np.stack([rng.uniform(0, W, n), rng.uniform(0, H, n), rng.uniform(60, 200, n), rng.uniform(100, 280, n)], 1)
+                             .astype(np.float32)).to(DEV)
+    with pinned_plan('throughput', cc, hm):
+        dp = DemoPipeline(cc, hm)
+        out = dp(frames, boxes, torch.from_numpy(fidx_host).to(DEV))
+        assert tuple(out['smpl_vertices'].shape) == (n, 6890, 3) and tuple(out['cam_rotmat'].shape) == (F, 3, 3)
+        # the same detections regrouped frame by frame: identical per-crop results
+        order = np.argsort(fidx_host, kind='stable')
+        out2 = dp(frames, boxes[torch.from_numpy(order).to(DEV)], torch.from_numpy(fidx_host[order]).to(DEV))
+        for k in ('smpl_vertices', 'smpl_joints2d', 'pred_cam_t'):
+            assert torch.equal(out2[k], out[k][torch.from_numpy(order).to(DEV)]), k
+        # a crop's projection uses its own frame's intrinsics: re-derive joints2d from joints3d, cam_t and (R, K) of that frame
+        fi = torch.from_numpy(fidx_host).long().to(DEV)
+        R, K = out['cam_rotmat'][fi].double(), out['cam_intrinsics'][fi].double()
+        P = torch.einsum('bij,bkj->bki', R, out['smpl_joints3d'].double()) + out['pred_cam_t'].double()[:, None]
+        P = P / P[..., 2:3]
+        p2 = torch.einsum('bij,bkj->bki', K, P)[..., :2]
+        assert ((p2 - out['smpl_joints2d'].double()).abs().max() / out['smpl_joints2d'].abs().max()) < 1e-5
+        empty = dp(frames, boxes[:0], torch.zeros(0, dtype=torch.int32, device=DEV))
+        assert tuple(empty['smpl_vertices'].shape) == (0, 6890, 3) and torch.equal(empty['cam_rotmat'], out['cam_rotmat'])
