@@ -651,7 +651,8 @@ def main():
             from spec_amd.pipeline import GraphedPipeline
             for b in (1, 8):
                 row = {'batch': b}
-                for tag, pp, plan in (('grouped', SpecPipeline(cc, hm, grouped=True), 'auto'),
+                for tag, pp, plan in (('auto', SpecPipeline(cc, hm), 'auto'),     # what a caller gets by default: launch structure by batch
+                                      ('grouped', SpecPipeline(cc, hm, grouped=True), 'auto'),
                                       ('two_streams', SpecPipeline(cc, hm, overlap=True, grouped=False), 'auto'),
                                       ('grouped_throughput_plan', SpecPipeline(cc, hm, grouped=True), 'throughput')):
                     for m in (cc, hm):
@@ -672,15 +673,17 @@ def main():
                     del g
                 for m in (cc, hm):
                     m.set_plan('auto')
-                ms = row['grouped_ms']
+                ms = row['auto_ms']
                 # whole-step executed FLOPs against the fp32 MFMA roof and the weights of both networks against HBM
                 row.update({'ms_per_step': ms, 'images_per_s': round(b * 1e3 / ms, 1), 'plan': 'latency (plan = auto, batch <= 10)',
+                            'structure': 'grouped launches, one stream' if (b <= 2 or 9 <= b <= 16) else 'two trunks on two streams',
                             'speedup_vs_throughput_plan': round(row['grouped_throughput_plan_ms'] / ms, 3),
                             'algorithmic_TFLOPs': round(b * 2 * TRUNK_GFLOP_PER_IMAGE / ms, 2),
                             'frac_of_mfma_peak_algorithmic': round(b * 2 * TRUNK_GFLOP_PER_IMAGE / ms / PEAK_FP32_MFMA_TFLOPS, 4),
-                            'launch': 'both trunks per layer as one grouped launch, one stream, hipGraph replay (bit-identical to two '
-                                      'streams); every convolution with K >= 512 as K slices of one launch, the last slice to arrive '
-                                      'folds the canonical sum tree (batch-invariant within the plan)'})
+                            'launch': 'hipGraph replay; SpecPipeline(grouped=auto): both trunks per layer as one grouped launch at batch '
+                                      '1-2 and 9-16, two trunks on two streams otherwise (bit-identical either way); every convolution with '
+                                      'K >= 512 as K slices of one launch, the last slice to arrive folds the canonical sum tree '
+                                      '(batch-invariant within the plan); FC heads as one GEMV launch'})
                 small.append(row)
         except Exception as e:
             log('[bench] small-batch latency failed:', repr(e))
