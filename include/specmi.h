@@ -129,7 +129,8 @@ const char* specmi_version(void);
  *   across batch sizes on both sides of the switch pin a plan.
  *   Tuning / tests: "latency_target_wgs" (256), "latency_min_chunks" (4), "latency_wino_min_tiles" (128), "latency_fill_wgs" (250),
  *   "latency_force_unit" (0 = by batch, 1 / 2 / 3 = a leaf / a group / the whole K per workgroup: same bits),
- *   "conv2d_sk" (specmi_conv2d only: 0 = throughput kernel, -1 = the latency plan's rule, n > 1 = n leaves). */
+ *   "conv2d_sk" (specmi_conv2d only: 0 = throughput kernel, -1 = the latency plan's rule, n > 1 = n leaves),
+ *   "smpl_skin_split" (-1 = by batch: three waves per 32-vertex group up to 64 images, one beyond; 0 / 1 = never / always: same bits). */
 int specmi_set_option_i32(specmi_handle* h, const char* name, int value);
 int specmi_set_option_f32(specmi_handle* h, const char* name, float value);
 

@@ -963,6 +963,7 @@ static int run_smpl(specmi_handle* h, const float* rotmat, const float* betas, c
     a.focal_length = opt_f(h, "focal_length", 5000.f);
     a.img_res = (float)opt_i(h, "img_res", 224);
     a.normalize_joints2d = use_cam ? 0 : 1;  // spec/models/hmr.py:111 vs :119
+    a.skin_split = opt_i(h, "smpl_skin_split", -1);
     LaunchCtx ctx{s, &h->prof, "smpl"};
     LAUNCHCHK(h, launch_smpl(h->smpl, a, ctx), "smpl");
     return SPECMI_OK;
@@ -1299,6 +1300,7 @@ int specmi_smpl_native(specmi_handle* h, const float* pose, int pose_is_axis_ang
     a.vertices = vertices; a.joints3d = a.joints2d = a.cam_t = nullptr;
     a.pose_feat = h->pf_ws; a.A = h->A_ws; a.posed_j = h->pj_ws;
     a.B = B; a.mode = 1; a.focal_length = 0.f; a.img_res = 0.f; a.normalize_joints2d = 0;
+    a.skin_split = opt_i(h, "smpl_skin_split", -1);
     LaunchCtx ctx{s, &h->prof, "smpl.native"};
     LAUNCHCHK(h, launch_smpl_native(h->smpl, a, joints24, ctx), "smpl_native");
     return SPECMI_OK;

@@ -143,7 +143,7 @@ __device__ __forceinline__ void build_cam_RK(float pt, float rl, float f, float 
 // regressor's composed map (spec/models/hmr.py:96) are M = batch-row GEMMs: on the matrix-core kernel each is a launch of 4-24
 // tiles that are 1/64 ... 8/64 full plus a fold of K slices - 11-12 us per GEMM for 0.2 us of arithmetic, and three graph nodes
 // where one will do.  Here: ONE launch for up to three heads (blockIdx.y), one WAVE per output column, lanes across K (16-byte
-// loads of the row-major weight row: 1 KiB per instruction, coalesced), all images of a block of 8 per wave, fixed lane-local k
+// loads of the row-major weight row: 1 KiB per instruction, coalesced), one or two images per wave, fixed lane-local k
 // order and a fixed xor-shuffle tree - an image's result does not depend on the batch it travels in.
 struct GemvHead { const float* x; const float* w; const float* bias; const float* res; float* out; };
 struct GemvArgs {
@@ -151,7 +151,10 @@ struct GemvArgs {
     int nheads, N, Kp, ldx, ldo, B;   // w: (N, Kp) row-major, zero padded beyond the true K; x rows ldx apart (>= Kp floats readable)
 };
 
-// NB = images per wave (1 / 2 / 4 / 8: the smallest that covers the batch, so that a single image does not pay for eight)
+// NB = images per wave (1 or 2; more images = more waves, blockIdx.z).  The kernel is pure latency - a wave's whole k range is
+// 9 steps of (1 + NB) 16-byte loads - so GKU steps are requested before the first is used (8 images per wave at two steps in
+// flight took 16 us at batch 8 for 1.4 MB of weights).
+constexpr int GKU = 9;
 template <int NB>
 __global__ void __launch_bounds__(256) fc_gemv_kernel(const GemvArgs a) {
     const GemvHead& hd = a.hd[blockIdx.y];
@@ -164,24 +167,35 @@ __global__ void __launch_bounds__(256) fc_gemv_kernel(const GemvArgs a) {
     float acc[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[b] = 0.f;
-    // rows past the batch re-read the last image (results discarded): no branch in the loop, so the nine loads of a k step are
-    // independent and several steps are in flight (with `if (b < nb)` around each image the loads serialised: 24 us at batch 8)
+    // rows past the batch re-read the last image (results discarded) and k steps past the row re-read its last step with weight
+    // 0 (acc + 0 * x = acc): no branch around a load, so all of them are independent and in flight together
     const float* xrow[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) xrow[b] = hd.x + (size_t)(b0 + (b < nb ? b : nb - 1)) * a.ldx;
-#pragma unroll 2
-    for (int k = lane * 4; k < a.Kp; k += 256) {
-        const float4 wv = *reinterpret_cast<const float4*>(wrow + k);
-        float4 xv[NB];
+    for (int k0 = lane * 4; k0 < a.Kp; k0 += 256 * GKU) {
+        float4 wv[GKU], xv[GKU][NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) xv[b] = *reinterpret_cast<const float4*>(xrow[b] + k);
+        for (int u = 0; u < GKU; ++u) {
+            const int k = min(k0 + u * 256, a.Kp - 4);
+            wv[u] = *reinterpret_cast<const float4*>(wrow + k);
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            acc[b] = fmaf(wv.x, xv[b].x, acc[b]);
-            acc[b] = fmaf(wv.y, xv[b].y, acc[b]);
-            acc[b] = fmaf(wv.z, xv[b].z, acc[b]);
-            acc[b] = fmaf(wv.w, xv[b].w, acc[b]);
+            for (int b = 0; b < NB; ++b) xv[u][b] = *reinterpret_cast<const float4*>(xrow[b] + k);
         }
+#pragma unroll
+        for (int u = 0; u < GKU; ++u) {
+            const bool in = k0 + u * 256 < a.Kp;
+            const float wx = in ? wv[u].x : 0.f, wy = in ? wv[u].y : 0.f, wz = in ? wv[u].z : 0.f, ww = in ? wv[u].w : 0.f;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                acc[b] = fmaf(wx, xv[u][b].x, acc[b]);
+                acc[b] = fmaf(wy, xv[u][b].y, acc[b]);
+                acc[b] = fmaf(wz, xv[u][b].z, acc[b]);
+                acc[b] = fmaf(ww, xv[u][b].w, acc[b]);
+            }
+        }
+        // all loads of the body first, then the arithmetic (the scheduler otherwise puts each load next to its use: serial round trips)
+        __builtin_amdgcn_sched_group_barrier(0x020, GKU * (1 + NB), 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, GKU * NB * 8, 0);
     }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -214,10 +228,8 @@ int launch_fc_gemv(const FcGemv* heads, int nheads, int N, int Kp, int ldx, int 
     ProfScope ps(ctx, "fc_gemv_f32", 2.0 * nheads * (double)B * N * Kp, 4.0 * nheads * ((double)N * Kp + (double)B * (Kp + N)));
     // an image's sum is the same in every instantiation (lane-local k order, then the shuffle tree): NB only sets how many share a wave
     const dim3 blk(256);
-    if (B == 1) hipLaunchKernelGGL(fc_gemv_kernel<1>, dim3((N + 3) / 4, nheads, B), blk, 0, ctx.stream, a);
-    else if (B == 2) hipLaunchKernelGGL(fc_gemv_kernel<2>, dim3((N + 3) / 4, nheads, 1), blk, 0, ctx.stream, a);
-    else if (B <= 4) hipLaunchKernelGGL(fc_gemv_kernel<4>, dim3((N + 3) / 4, nheads, 1), blk, 0, ctx.stream, a);
-    else hipLaunchKernelGGL(fc_gemv_kernel<8>, dim3((N + 3) / 4, nheads, (B + 7) / 8), blk, 0, ctx.stream, a);
+    if (B == 1) hipLaunchKernelGGL(fc_gemv_kernel<1>, dim3((N + 3) / 4, nheads, 1), blk, 0, ctx.stream, a);
+    else hipLaunchKernelGGL(fc_gemv_kernel<2>, dim3((N + 3) / 4, nheads, (B + 1) / 2), blk, 0, ctx.stream, a);
     return (int)hipGetLastError();
 }
 

@@ -33,6 +33,7 @@ constexpr int IT = 32;                     // images per tile = columns of one M
 constexpr int KQ = SMPL_KQ;                // K = 224 = 207 pose features + 10 betas + 1 (template) + 6 zeros = 112 MFMA steps = 28 quads
 constexpr int FEAT_TILE = KQ * 64 * 4;     // floats of one image tile of features  [quad][lane][4]   (224 per image)
 constexpr int SKIN_LD = 98;                // floats per image row of the output transpose (96 + 2: even, so rows stay 8-byte aligned)
+constexpr int SKIN_SPLIT_MAX_TILES = 2;    // image tiles up to which the skin kernel runs three waves per vertex group (measured: DESIGN.md section 4)
 constexpr int A_TILE = 12 * 3 * 64 * 4;    // floats of one image tile of transforms [entry][quad][lane][4] (288 per image)
 
 
@@ -118,17 +119,24 @@ __global__ void __launch_bounds__(64) smpl_pose_kernel(const float* __restrict__
     }
 }
 
-// grid (ceil(groups / 4), image tiles); wave w of a workgroup owns vertex group 4 blockIdx.x + w and needs nothing from the
-// other waves (its LDS slice is private: no barrier).
-__global__ void __launch_bounds__(256) smpl_skin_kernel(const float* __restrict__ dirsT, const float* __restrict__ wT,
-                                                         const float* __restrict__ feat, const float* __restrict__ Afrag,
-                                                         float* __restrict__ verts, long ld_verts, int V, int B, int G) {
-    const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= G) return;
+// SPLIT = false: grid (ceil(groups / 4), image tiles), 256 threads; wave w of a workgroup owns vertex group 4 blockIdx.x + w
+// and needs nothing from the other waves (its LDS slice is private: no barrier).
+// SPLIT = true (few image tiles: the 216 vertex groups x 1 wave leave most SIMDs idle and one wave's 480 dependent-by-pipe
+// MFMAs are the whole kernel time): grid (groups, image tiles), 192 threads; wave c of a workgroup computes coordinate c of
+// v_posed (its own 112-step chain) and row c of the blended transform, the three v_posed coordinates are exchanged through
+// LDS.  Every accumulator sees the same operands in the same order as in the other variant: the results are the same bits.
+template <bool SPLIT>
+__global__ void __launch_bounds__(SPLIT ? 192 : 256) smpl_skin_kernel(const float* __restrict__ dirsT, const float* __restrict__ wT,
+                                                                      const float* __restrict__ feat, const float* __restrict__ Afrag,
+                                                                      float* __restrict__ verts, long ld_verts, int V, int B, int G) {
+    constexpr int NC = SPLIT ? 1 : 3;          // coordinates of v_posed this wave accumulates
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = SPLIT ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+    if (g >= G) return;                        // (SPLIT: the grid is exactly G wide, no workgroup is cut by this)
+    const int c0 = SPLIT ? wave : 0;
     const int tile = blockIdx.y;
     const f32x4* __restrict__ fq = reinterpret_cast<const f32x4*>(feat + (size_t)tile * FEAT_TILE) + lane;     // [quad][64]
-    const f32x4* __restrict__ dq = reinterpret_cast<const f32x4*>(dirsT + (size_t)g * 3 * FEAT_TILE) + lane;   // [coord][quad][64]
+    const f32x4* __restrict__ dq = reinterpret_cast<const f32x4*>(dirsT + (size_t)g * 3 * FEAT_TILE) + (size_t)c0 * KQ * 64 + lane;   // [coord][quad][64]
 
     // v_posed[vertex][image] per coordinate: A operand = the model's directions (row = vertex), B operand = features (column = image)
     f32x16 vp[3];
@@ -137,38 +145,48 @@ __global__ void __launch_bounds__(256) smpl_skin_kernel(const float* __restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) vp[c][r] = 0.f;
     constexpr int PD = 3;                      // quads in flight ahead of the MFMAs (12 MFMAs = 768 cycles each)
-    f32x4 fb[PD], d0[PD], d1[PD], d2[PD];
+    f32x4 fb[PD], dd[NC][PD];
 #pragma unroll
     for (int i = 0; i < PD; ++i) {
-        fb[i] = fq[i * 64]; d0[i] = dq[i * 64]; d1[i] = dq[(KQ + i) * 64]; d2[i] = dq[(2 * KQ + i) * 64];
+        fb[i] = fq[i * 64];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) dd[k][i] = dq[(k * KQ + i) * 64];
     }
 #pragma unroll
     for (int s4 = 0; s4 < KQ; ++s4) {
         const int cur = s4 % PD;
-        const f32x4 f = fb[cur], a0 = d0[cur], a1 = d1[cur], a2 = d2[cur];
+        const f32x4 f = fb[cur];
+        f32x4 av[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) av[k] = dd[k][cur];
         if (s4 + PD < KQ) {
-            fb[cur] = fq[(s4 + PD) * 64]; d0[cur] = dq[(s4 + PD) * 64];
-            d1[cur] = dq[(KQ + s4 + PD) * 64]; d2[cur] = dq[(2 * KQ + s4 + PD) * 64];
+            fb[cur] = fq[(s4 + PD) * 64];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) dd[k][cur] = dq[(k * KQ + s4 + PD) * 64];
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            vp[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], f[q], vp[0], 0, 0, 0);
-            vp[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], f[q], vp[1], 0, 0, 0);
-            vp[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[q], f[q], vp[2], 0, 0, 0);
-        }
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < NC; ++k) vp[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k][q], f[q], vp[k], 0, 0, 0);
     }
 
     // blended transform entry e = 4 c + d of (vertex, image): sum_j w[vertex][j] A[image][j][e]; then the skinned coordinate c
     const f32x4* __restrict__ wq = reinterpret_cast<const f32x4*>(wT + (size_t)g * 768) + lane;                // [quad (3)][64]
     const f32x4* __restrict__ aq = reinterpret_cast<const f32x4*>(Afrag + (size_t)tile * A_TILE) + lane;       // [entry][quad][64]
     const f32x4 w0 = wq[0], w1 = wq[64], w2 = wq[128];
-    // the wave's 32 images x 32 vertices x 3 coordinates go through LDS (wave-private: no barrier) so that global memory sees,
-    // per image, the 384 contiguous bytes of the 32 vertices instead of 4-byte pieces 80 KB apart
+    // the 32 images x 32 vertices x 3 coordinates go through LDS (wave-private without SPLIT: no barrier) so that global
+    // memory sees, per image, the 384 contiguous bytes of the 32 vertices instead of 4-byte pieces 80 KB apart
     extern __shared__ __attribute__((aligned(16))) float skin_lds[];
-    float* const tw = skin_lds + (threadIdx.x >> 6) * (IT * SKIN_LD);
+    float* const tw = skin_lds + (SPLIT ? 0 : wave * (IT * SKIN_LD));
+    float* const xch = skin_lds + IT * SKIN_LD;                      // SPLIT: v_posed exchange [coordinate][register][lane]
+    if (SPLIT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[(wave * 16 + r) * 64 + lane] = vp[0][r];
+    }
     const int vloc0 = 4 * (lane >> 5);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int k = 0; k < NC; ++k) {
+        const int c = c0 + k;
         f32x16 T[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
@@ -182,6 +200,13 @@ __global__ void __launch_bounds__(256) smpl_skin_kernel(const float* __restrict_
 #pragma unroll
             for (int q = 0; q < 4; ++q) T[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[q], b2[q], T[d], 0, 0, 0);
         }
+        if (SPLIT) {
+            __syncthreads();                                         // the three coordinates of v_posed are in LDS
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) vp[cc][r] = xch[(cc * 16 + r) * 64 + lane];
+        }
         // accumulator r of this lane = image lane % 32, vertex vloc0 + (r & 3) + 8 (r >> 2) of the group
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -189,23 +214,25 @@ __global__ void __launch_bounds__(256) smpl_skin_kernel(const float* __restrict_
             tw[(lane & 31) * SKIN_LD + (vloc0 + (r & 3) + 8 * (r >> 2)) * 3 + c] = o;
         }
     }
-    // one wave's LDS instructions execute in order: the reads below see the writes above
+    if (SPLIT) __syncthreads();                                      // rows of tw hold all three coordinates
+    // (without SPLIT one wave's LDS instructions execute in order: the reads below see the writes above)
     const int nimg = min(IT, B - tile * IT);
     const int nfl = min(96, (V - g * 32) * 3);                       // floats of this group that exist
     float* const obase = verts + (size_t)tile * IT * ld_verts + (size_t)g * 96;
+    const int i0 = SPLIT ? wave : 0, istep = SPLIT ? 3 : 1;          // SPLIT: the three waves take every third image
     if (((ld_verts & 1) == 0) && ((reinterpret_cast<uintptr_t>(verts) & 7) == 0)) {
         // rows of the output start on 8-byte boundaries: 48 lanes x 8 bytes per image
         const bool on = 2 * lane + 1 < nfl;
         const bool half = 2 * lane + 1 == nfl;                        // (V * 3 odd: the last float alone)
 #pragma unroll 4
-        for (int i = 0; i < nimg; ++i) {
+        for (int i = i0; i < nimg; i += istep) {
             const f32x2 t = *reinterpret_cast<const f32x2*>(tw + i * SKIN_LD + 2 * (lane < 48 ? lane : 0));
             float* const o = obase + (size_t)i * ld_verts + 2 * lane;
             if (on) *reinterpret_cast<f32x2*>(o) = t;
             else if (half) o[0] = t[0];
         }
     } else {
-        for (int i = 0; i < nimg; ++i) {
+        for (int i = i0; i < nimg; i += istep) {
             float* const o = obase + (size_t)i * ld_verts;
             if (lane < nfl) o[lane] = tw[i * SKIN_LD + lane];
             if (lane + 64 < nfl) o[lane + 64] = tw[i * SKIN_LD + lane + 64];
@@ -228,24 +255,55 @@ struct JointArgs {
     int V, mode, normalize; float focal, img_res;
 };
 
-__global__ void __launch_bounds__(256) smpl_joints_kernel(const JointArgs a) {
-    __shared__ float red[4][27];
+// One workgroup per image is latency-bound (12 independent loads per vertex and thread): 8 waves x 7 vertices in flight put
+// the whole mesh in two rounds (16 waves leave 128 registers per lane, not enough for that).  JT is part of the arithmetic
+// (it fixes which vertices a lane sums and the 8-partial fold).
+constexpr int JT = 512;
+__global__ void __launch_bounds__(JT) smpl_joints_kernel(const JointArgs a) {
+    __shared__ float red[JT / 64][27];
     __shared__ float J54[54][3];
     __shared__ float ct[3];
     const int b = blockIdx.x, t = threadIdx.x;
     const float* vb = a.verts + (size_t)b * a.ld_verts;
+    // everything the tail needs is requested before the vertex loop, so that its latency (two dependent round trips for the
+    // vertex-picked joints) hides behind the loop's
+    float pre = 0.f;
+    if (t < 72) pre = a.posed_j[(size_t)b * 72 + t];
+    else if (t < 72 + 63) pre = vb[(size_t)a.extra_ids[(t - 72) / 3] * 3 + (t - 72) % 3];
+    const int jm = t < 49 ? a.joint_map[t] : 0;
+    // (block-uniform addresses: scalar loads, no vector registers held across the loop)
+    const float cam_s = a.cam[b * 3 + 0], cam_x = a.cam[b * 3 + 1], cam_y = a.cam[b * 3 + 2];
+    float cam_f = 0.f, bb_s = 0.f, bb_x = 0.f, bb_y = 0.f, im_w = 0.f, im_h = 0.f;
+    if (a.mode == 0) {
+        cam_f = a.K[(size_t)b * 9]; bb_s = a.bbox_scale[b]; bb_x = a.bbox_center[b * 2 + 0]; bb_y = a.bbox_center[b * 2 + 1];
+        im_w = a.img_w[b]; im_h = a.img_h[b];
+    }
     float acc[9][3];
 #pragma unroll
     for (int e = 0; e < 9; ++e) acc[e][0] = acc[e][1] = acc[e][2] = 0.f;
-#pragma unroll 4   // 12 independent loads per iteration: keep several iterations in flight (one workgroup per image is latency-bound)
-    for (int v = t; v < a.V; v += 256) {
-        const float x = vb[v * 3 + 0], y = vb[v * 3 + 1], z = vb[v * 3 + 2];
+    // JU vertices per lane requested before the first is used (12 independent loads each; written out because the unroller
+    // interleaves loads and uses, and this kernel is pure latency).  Past-the-end slots read vertex V - 1 with weight 0.
+    constexpr int JU = 7;
+    for (int v0 = t; v0 < a.V; v0 += JT * JU) {
+        float x[JU], y[JU], z[JU], wgt[JU][9];
 #pragma unroll
-        for (int e = 0; e < 9; ++e) {
-            const float wgt = a.J_extra[(size_t)e * a.V + v];
-            acc[e][0] = fmaf(wgt, x, acc[e][0]);
-            acc[e][1] = fmaf(wgt, y, acc[e][1]);
-            acc[e][2] = fmaf(wgt, z, acc[e][2]);
+        for (int u = 0; u < JU; ++u) {
+            const int v = v0 + u * JT, vc = min(v, a.V - 1);
+            x[u] = vb[vc * 3 + 0]; y[u] = vb[vc * 3 + 1]; z[u] = vb[vc * 3 + 2];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) wgt[u][e] = a.J_extra[(size_t)e * a.V + vc];
+        }
+        __builtin_amdgcn_sched_barrier(0);   // the scheduler otherwise sinks loads next to their uses (serial round trips)
+#pragma unroll
+        for (int u = 0; u < JU; ++u) {
+            const bool in = v0 + u * JT < a.V;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) {
+                const float w = in ? wgt[u][e] : 0.f;
+                acc[e][0] = fmaf(w, x[u], acc[e][0]);
+                acc[e][1] = fmaf(w, y[u], acc[e][1]);
+                acc[e][2] = fmaf(w, z[u], acc[e][2]);
+            }
         }
     }
 #pragma unroll
@@ -255,31 +313,32 @@ __global__ void __launch_bounds__(256) smpl_joints_kernel(const JointArgs a) {
             const float s = wsum(acc[e][c]);
             if ((t & 63) == 0) red[t >> 6][e * 3 + c] = s;
         }
-    if (t < 72) J54[t / 3][t % 3] = a.posed_j[(size_t)b * 72 + t];
-    if (t >= 72 && t < 72 + 63) {
-        const int i = t - 72, e = i / 3, c = i % 3;
-        J54[24 + e][c] = vb[(size_t)a.extra_ids[e] * 3 + c];
-    }
-    if (t == 255) {
-        const float s = a.cam[b * 3 + 0], tx = a.cam[b * 3 + 1], ty = a.cam[b * 3 + 2];
+    if (t < 72) J54[t / 3][t % 3] = pre;
+    else if (t < 72 + 63) J54[24 + (t - 72) / 3][(t - 72) % 3] = pre;
+    if (t == 255) {   // (wave 3: neither of the J54 writers above)
+        const float s = cam_s, tx = cam_x, ty = cam_y;
         if (a.mode == 0) {  // convert_pare_to_full_img_cam, res = 224 literal
-            const float f = a.K[(size_t)b * 9];
-            const float bh = a.bbox_scale[b] * 200.0f;
+            const float f = cam_f;
+            const float bh = bb_s * 200.0f;
             const float r = bh / 224.0f;
             const float tz = 2.0f * f / (r * 224.0f * s);
-            const float cx = 2.0f * (a.bbox_center[b * 2 + 0] - (a.img_w[b] / 2.0f)) / (s * bh);
-            const float cy = 2.0f * (a.bbox_center[b * 2 + 1] - (a.img_h[b] / 2.0f)) / (s * bh);
+            const float cx = 2.0f * (bb_x - (im_w / 2.0f)) / (s * bh);
+            const float cy = 2.0f * (bb_y - (im_h / 2.0f)) / (s * bh);
             ct[0] = tx + cx; ct[1] = ty + cy; ct[2] = tz;
         } else {            // convert_weak_perspective_to_perspective
             ct[0] = tx; ct[1] = ty; ct[2] = 2.0f * a.focal / (a.img_res * s + 1e-9f);
         }
     }
     __syncthreads();
-    if (t < 27) J54[45 + t / 3][t % 3] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    if (t < 27) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < JT / 64; ++w) s += red[w][t];
+        J54[45 + t / 3][t % 3] = s;
+    }
     __syncthreads();
     if (t < 3 && a.cam_t) a.cam_t[(size_t)b * a.ld_camt + t] = ct[t];
     if (t < 49) {
-        const int jm = a.joint_map[t];
         const float X0 = J54[jm][0], X1 = J54[jm][1], X2 = J54[jm][2];
         if (a.joints3d) {
             float* o = a.joints3d + (size_t)b * a.ld_j3d + t * 3;
@@ -335,6 +394,18 @@ int launch_rodrigues(const float* aa, float* rot, int n, const LaunchCtx& ctx) {
     return (int)hipGetLastError();
 }
 
+// The skinning launch of both entry points.  a.skin_split: -1 = by the number of image tiles, 0 / 1 = never / always the
+// three-waves-per-vertex-group variant (same bits either way; tests force both).
+static void launch_skin(const SmplDev& m, const SmplArgs& a, long ld_verts, int tiles, int G, const LaunchCtx& ctx) {
+    const bool split = a.skin_split < 0 ? tiles <= SKIN_SPLIT_MAX_TILES : a.skin_split != 0;
+    if (split)
+        hipLaunchKernelGGL(smpl_skin_kernel<true>, dim3(G, tiles), dim3(192), (IT * SKIN_LD + 3 * 16 * 64) * sizeof(float), ctx.stream,
+                           m.dirsT, m.wT, a.pose_feat, a.A, a.vertices, ld_verts, m.V, a.B, G);
+    else
+        hipLaunchKernelGGL(smpl_skin_kernel<false>, dim3((G + 3) / 4, tiles), dim3(256), 4 * IT * SKIN_LD * sizeof(float), ctx.stream,
+                           m.dirsT, m.wT, a.pose_feat, a.A, a.vertices, ld_verts, m.V, a.B, G);
+}
+
 // smplx.SMPL.forward(pose2rot=False) without the 49-joint wrapper: vertices + the 24 posed kinematic-chain joints
 // (`.joints[:, :24]` of the reference's smpl_native / body_model_orig, spec/trainer.py:249-254, compute_error.py:156-160)
 int launch_smpl_native(const SmplDev& m, const SmplArgs& a, float* joints24, const LaunchCtx& ctx) {
@@ -352,8 +423,7 @@ int launch_smpl_native(const SmplDev& m, const SmplArgs& a, float* joints24, con
         // tile of IT images - that re-use is served by L2 - and is not counted)
         const double bytes = 4.0 * ((double)B * V * 3 + (double)V * (3.0 * 207 + 3 + 30 + 24) + (double)B * (207 + 10 + 288));
         ProfScope ps(ctx, "smpl_skin_lbs", flops, bytes);
-        hipLaunchKernelGGL(smpl_skin_kernel, dim3((G + 3) / 4, tiles), dim3(256), 4 * IT * SKIN_LD * sizeof(float), ctx.stream, m.dirsT,
-                           m.wT, a.pose_feat, a.A, a.vertices, ld_verts, V, B, G);
+        launch_skin(m, a, ld_verts, tiles, G, ctx);
     }
     return (int)hipGetLastError();
 }
@@ -373,8 +443,7 @@ int launch_smpl(const SmplDev& m, const SmplArgs& a, const LaunchCtx& ctx) {
         // tile of IT images - that re-use is served by L2 - and is not counted)
         const double bytes = 4.0 * ((double)B * V * 3 + (double)V * (3.0 * 207 + 3 + 30 + 24) + (double)B * (207 + 10 + 288));
         ProfScope ps(ctx, "smpl_skin_lbs", flops, bytes);
-        hipLaunchKernelGGL(smpl_skin_kernel, dim3((G + 3) / 4, tiles), dim3(256), 4 * IT * SKIN_LD * sizeof(float), ctx.stream, m.dirsT,
-                           m.wT, a.pose_feat, a.A, a.vertices, ld_verts, V, B, G);
+        launch_skin(m, a, ld_verts, tiles, G, ctx);
     }
     {
         JointArgs j;
@@ -386,7 +455,7 @@ int launch_smpl(const SmplDev& m, const SmplArgs& a, const LaunchCtx& ctx) {
         j.V = V; j.mode = a.mode; j.normalize = a.normalize_joints2d; j.focal = a.focal_length; j.img_res = a.img_res;
         // algorithmic bytes: every mesh once + the 9 x V extra-joint regressor once (its per-image re-reads are L2 hits) + outputs
         ProfScope ps(ctx, "smpl_joints_project", 2.0 * B * V * 27.0, 4.0 * ((double)B * V * 3 + 9.0 * V + (double)B * 49 * 5));
-        hipLaunchKernelGGL(smpl_joints_kernel, dim3(B), dim3(256), 0, ctx.stream, j);
+        hipLaunchKernelGGL(smpl_joints_kernel, dim3(B), dim3(JT), 0, ctx.stream, j);
     }
     return (int)hipGetLastError();
 }

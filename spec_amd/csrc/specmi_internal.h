@@ -231,6 +231,7 @@ struct SmplArgs {
     float focal_length;
     float img_res;
     int normalize_joints2d;
+    int skin_split = -1;   // -1: by batch, 0 / 1: never / always three waves per vertex group (same bits)
 };
 int launch_smpl(const SmplDev& m, const SmplArgs& a, const LaunchCtx& ctx);
 // vertices (optional) + the 24 posed kinematic joints (optional; a.posed_j receives them otherwise)

@@ -495,3 +495,34 @@ def test_smpl_batch_variants_bit_identical(hmr_engine):
         out = hmr_engine.smpl(*[a[:B].contiguous().to(DEV) for a in args])
         for k in ('smpl_vertices', 'smpl_joints3d', 'smpl_joints2d', 'pred_cam_t'):
             assert torch.equal(out[k], full[k][:B]), (B, k)
+
+
+def test_smpl_skin_split_bit_identical(hmr_engine):
+    """The three-waves-per-vertex-group skinning variant (few image tiles) and the one-wave variant give the same bits, on
+    both sides of the automatic switch (64 images), with ragged last tiles, and through smpl_native."""
+    Bmax = 70
+    R, betas, cam = _rand_pose(Bmax, 321)
+    g = torch.Generator().manual_seed(10)
+    camR = _rand_pose(1, 97)[0][0, :1].expand(Bmax, 3, 3).contiguous()
+    K = torch.zeros(Bmax, 3, 3)
+    K[:, 0, 0] = K[:, 1, 1] = 400 + 300 * torch.rand(Bmax, generator=g)
+    K[:, 0, 2], K[:, 1, 2] = 320.0, 240.0
+    scale = 0.8 + 0.5 * torch.rand(Bmax, generator=g)
+    center = torch.stack([250 + 100 * torch.rand(Bmax, generator=g), 200 + 80 * torch.rand(Bmax, generator=g)], 1)
+    args = [R, betas, cam, camR, K, scale, center, torch.full((Bmax,), 640.0), torch.full((Bmax,), 480.0)]
+    try:
+        ref = {}
+        for split in (0, 1, -1):
+            hmr_engine.set_option('smpl_skin_split', split)
+            for B in (1, 7, 33, 64, 70):
+                out = hmr_engine.smpl(*[a[:B].contiguous().to(DEV) for a in args])
+                v, j24 = hmr_engine.smpl_native(R[:B].to(DEV), betas[:B].to(DEV))
+                got = (out['smpl_vertices'].clone(), out['smpl_joints3d'].clone(), v.clone(), j24.clone())
+                if split == 0:
+                    ref[B] = got
+                    assert torch.equal(got[0], got[2])
+                else:
+                    for a, b in zip(got, ref[B]):
+                        assert torch.equal(a, b), (split, B)
+    finally:
+        hmr_engine.set_option('smpl_skin_split', -1)
