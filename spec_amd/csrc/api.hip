@@ -891,22 +891,29 @@ static OutLd out_ld(specmi_handle* h) {
     return o;
 }
 
+// defer != nullptr: head_final is not launched; *defer describes it for the SMPL pose kernel, which does its work (run_smpl)
 static int run_head(specmi_handle* h, const float* feat, int B, int fh, int fw, const float* R, const float* K,
                     const float* img_h, float* pred_pose, float* pred_shape, float* pred_cam, float* pred_pose_6d,
-                    const OutLd& old, hipStream_t s) {
+                    const OutLd& old, hipStream_t s, HeadFinal* defer = nullptr) {
     int rc;
     const int ucf = opt_i(h, "use_cam_feats", 0);
     const int F = h->feat_ch, LD = h->xc_ld;
     if (ucf && (!R || !K || !img_h))
         return fail(h, SPECMI_ERR_ARG, "use_cam_feats needs cam_rotmat, cam_intrinsics and img_h");
     {
-        LaunchCtx ctx{s, &h->prof, "head.avgpool"};
-        LAUNCHCHK(h, launch_avgpool(feat, h->xc, B, fh * fw, F, LD, ctx), "avgpool");
-    }
-    {
-        LaunchCtx ctx{s, &h->prof, "head.init"};
-        LAUNCHCHK(h, launch_head_init(h->xc, h->init_pose, h->init_shape, h->init_cam, R, K, img_h, ucf, B, F, LD, ctx),
-                  "head_init");
+        // the IEF state columns are written by extra workgroups of the pooling launch (option "head_fuse" bit 0, default on; large
+        // maps pool in parts and keep head_init as its own launch)
+        const HeadInit hi{h->xc, h->init_pose, h->init_shape, h->init_cam, R, K, img_h, ucf, F, LD};
+        bool init_done = false;
+        {
+            LaunchCtx ctx{s, &h->prof, "head.avgpool"};
+            LAUNCHCHK(h, launch_avgpool(feat, h->xc, B, fh * fw, F, LD, ctx, (opt_i(h, "head_fuse", 3) & 1) ? &hi : nullptr, &init_done), "avgpool");
+        }
+        if (!init_done) {
+            LaunchCtx ctx{s, &h->prof, "head.init"};
+            LAUNCHCHK(h, launch_head_init(h->xc, h->init_pose, h->init_shape, h->init_cam, R, K, img_h, ucf, B, F, LD, ctx),
+                      "head_init");
+        }
     }
     const float* state = h->xc + F;
     long ld_state = LD;
@@ -933,7 +940,12 @@ static int run_head(specmi_handle* h, const float* feat, int B, int fh, int fw, 
             if ((rc = fc(h->dec, h->h2, 1024, st, st, LD, "head.dec"))) return rc;
         }
     }
-    {
+    if (defer) {
+        defer->state = state; defer->ld_state = ld_state;
+        defer->pred_pose = pred_pose; defer->pred_shape = pred_shape; defer->pred_cam = pred_cam; defer->pred_pose_6d = pred_pose_6d;
+        defer->ld_pose = old.pose; defer->ld_shape = old.shape; defer->ld_cam = old.cam; defer->ld_p6d = old.p6d;
+        defer->rot_ws = h->rot_ws; defer->betas_ws = h->betas_ws; defer->cam_ws = h->cam_ws;
+    } else {
         LaunchCtx ctx{s, &h->prof, "head.final"};
         const long ld[4] = {old.pose, old.shape, old.cam, old.p6d};
         LAUNCHCHK(h, launch_head_final(state, ld_state, pred_pose, pred_shape, pred_cam, pred_pose_6d, ld, h->rot_ws,
@@ -946,7 +958,7 @@ static int run_head(specmi_handle* h, const float* feat, int B, int fh, int fw, 
 static int run_smpl(specmi_handle* h, const float* rotmat, const float* betas, const float* cam, int B, const float* R,
                     const float* K, const float* bbox_scale, const float* bbox_center, const float* img_w,
                     const float* img_h, float* vertices, float* joints3d, float* joints2d, float* cam_t,
-                    const OutLd& old, hipStream_t s) {
+                    const OutLd& old, hipStream_t s, const HeadFinal* final_ = nullptr) {
     const int use_cam = opt_i(h, "use_cam", 0);
     if (use_cam && (!R || !K || !bbox_scale || !bbox_center || !img_w || !img_h))
         return fail(h, SPECMI_ERR_ARG, "use_cam needs cam_rotmat, cam_intrinsics, bbox_scale, bbox_center, img_w, img_h");
@@ -964,6 +976,7 @@ static int run_smpl(specmi_handle* h, const float* rotmat, const float* betas, c
     a.img_res = (float)opt_i(h, "img_res", 224);
     a.normalize_joints2d = use_cam ? 0 : 1;  // spec/models/hmr.py:111 vs :119
     a.skin_split = opt_i(h, "smpl_skin_split", -1);
+    a.final_ = final_;
     LaunchCtx ctx{s, &h->prof, "smpl"};
     LAUNCHCHK(h, launch_smpl(h->smpl, a, ctx), "smpl");
     return SPECMI_OK;
@@ -1316,10 +1329,13 @@ int specmi_hmr_forward(specmi_handle* h, const float* images, int B, int H, int 
     const float* f; int fh, fw, rc;
     if ((rc = run_trunk(h, images, B, H, W, nullptr, &f, &fh, &fw, s))) return rc;
     const OutLd old = out_ld(h);
-    if ((rc = run_head(h, f, B, fh, fw, R, K, img_h, out->pred_pose, out->pred_shape, out->pred_cam, out->pred_pose_6d, old, s)))
+    HeadFinal fin;
+    const bool fuse = (opt_i(h, "head_fuse", 3) & 2) != 0;     // head_final's work inside the SMPL pose kernel (same bits, one node less)
+    if ((rc = run_head(h, f, B, fh, fw, R, K, img_h, out->pred_pose, out->pred_shape, out->pred_cam, out->pred_pose_6d, old, s,
+                       fuse ? &fin : nullptr)))
         return rc;
     return run_smpl(h, h->rot_ws, h->betas_ws, h->cam_ws, B, R, K, bbox_scale, bbox_center, img_w, img_h,
-                    out->smpl_vertices, out->smpl_joints3d, out->smpl_joints2d, out->pred_cam_t, old, s);
+                    out->smpl_vertices, out->smpl_joints3d, out->smpl_joints2d, out->pred_cam_t, old, s, fuse ? &fin : nullptr);
 }
 
 int specmi_hmr_regress(specmi_handle* h, const float* feat, int B, int fh, int fw, const float* R, const float* K,
@@ -1332,10 +1348,13 @@ int specmi_hmr_regress(specmi_handle* h, const float* feat, int B, int fh, int f
     int rc;
     if ((rc = ensure_ws(h, B, 32, 32))) return rc;
     const OutLd old = out_ld(h);
-    if ((rc = run_head(h, feat, B, fh, fw, R, K, img_h, out->pred_pose, out->pred_shape, out->pred_cam, out->pred_pose_6d, old, s)))
+    HeadFinal fin;
+    const bool fuse = (opt_i(h, "head_fuse", 3) & 2) != 0;     // head_final's work inside the SMPL pose kernel (same bits, one node less)
+    if ((rc = run_head(h, feat, B, fh, fw, R, K, img_h, out->pred_pose, out->pred_shape, out->pred_cam, out->pred_pose_6d, old, s,
+                       fuse ? &fin : nullptr)))
         return rc;
     return run_smpl(h, h->rot_ws, h->betas_ws, h->cam_ws, B, R, K, bbox_scale, bbox_center, img_w, img_h,
-                    out->smpl_vertices, out->smpl_joints3d, out->smpl_joints2d, out->pred_cam_t, old, s);
+                    out->smpl_vertices, out->smpl_joints3d, out->smpl_joints2d, out->pred_cam_t, old, s, fuse ? &fin : nullptr);
 }
 
 int specmi_conv2d(specmi_handle* h, const float* x, int B, int H, int W, int Cin, const float* w_host,

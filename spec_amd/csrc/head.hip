@@ -16,35 +16,14 @@
 
 namespace specmi {
 
-__global__ void __launch_bounds__(256) head_init_kernel(float* __restrict__ xc, const float* __restrict__ init_pose,
-                                                         const float* __restrict__ init_shape,
-                                                         const float* __restrict__ init_cam,
-                                                         const float* __restrict__ R, const float* __restrict__ K,
-                                                         const float* __restrict__ img_h, int use_cam_feats, int B,
-                                                         int state_off, int ld) {
-    const int b = blockIdx.x;
-    float* row = xc + (size_t)b * ld + state_off;
-    for (int i = threadIdx.x; i < ld - state_off; i += blockDim.x) {
-        float v = 0.f;
-        if (i < 144) v = init_pose[i];
-        else if (i < 154) v = init_shape[i - 144];
-        else if (i < 157) v = init_cam[i - 154];
-        else if (use_cam_feats && i < 163) {
-            const int e = i - 157;                   // rotmat[:, :, :2] row-major: (row, col) = (e/2, e%2)
-            v = R[(size_t)b * 9 + (e >> 1) * 3 + (e & 1)];
-        } else if (use_cam_feats && i == 163) {
-            v = 2.0f * atanf(img_h[b] / (2.0f * K[(size_t)b * 9]));
-        }
-        row[i] = v;
-    }
-}
+__global__ void __launch_bounds__(256) head_init_kernel(const HeadInit a) { head_init_row(a, blockIdx.x, threadIdx.x, blockDim.x); }
 
 int launch_head_init(float* xc, const float* init_pose, const float* init_shape, const float* init_cam,
                      const float* cam_rotmat, const float* cam_intrinsics, const float* img_h, int use_cam_feats,
                      int B, int state_off, int ld, const LaunchCtx& ctx) {
     ProfScope ps(ctx, "head_init", 0.0, 4.0 * B * (ld - state_off));
-    hipLaunchKernelGGL(head_init_kernel, dim3(B), dim3(256), 0, ctx.stream, xc, init_pose, init_shape, init_cam,
-                       cam_rotmat, cam_intrinsics, img_h, use_cam_feats, B, state_off, ld);
+    const HeadInit a{xc, init_pose, init_shape, init_cam, cam_rotmat, cam_intrinsics, img_h, use_cam_feats, state_off, ld};
+    hipLaunchKernelGGL(head_init_kernel, dim3(B), dim3(256), 0, ctx.stream, a);
     return (int)hipGetLastError();
 }
 
@@ -71,19 +50,8 @@ __global__ void __launch_bounds__(256) head_final_kernel(const float* __restrict
     }
     if (t >= 192 && t < 216) {
         const int j = t - 192;
-        const float* p = s + 6 * j;  // view(-1,3,2): a1 = p[0],p[2],p[4]; a2 = p[1],p[3],p[5]
-        const float a1x = p[0], a1y = p[2], a1z = p[4];
-        const float a2x = p[1], a2y = p[3], a2z = p[5];
-        const float n1 = fmaxf(sqrtf(a1x * a1x + a1y * a1y + a1z * a1z), 1e-12f);
-        const float b1x = a1x / n1, b1y = a1y / n1, b1z = a1z / n1;
-        const float d = b1x * a2x + b1y * a2y + b1z * a2z;
-        const float ux = a2x - d * b1x, uy = a2y - d * b1y, uz = a2z - d * b1z;
-        const float n2 = fmaxf(sqrtf(ux * ux + uy * uy + uz * uz), 1e-12f);
-        const float b2x = ux / n2, b2y = uy / n2, b2z = uz / n2;
-        const float b3x = b1y * b2z - b1z * b2y;
-        const float b3y = b1z * b2x - b1x * b2z;
-        const float b3z = b1x * b2y - b1y * b2x;
-        const float Rm[9] = {b1x, b2x, b3x, b1y, b2y, b3y, b1z, b2z, b3z};  // columns b1 b2 b3
+        float Rm[9];
+        rot6d_joint(s + 6 * j, Rm);
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             if (pred_pose) pred_pose[(size_t)b * ld_pose + j * 9 + k] = Rm[k];

@@ -152,19 +152,64 @@ int launch_stem(const float* x, const float* w, const float* scale, const float*
                 float* out, int B, int H, int W, int OH, int OW, int relu, const LaunchCtx& ctx, const StemPair* pair = nullptr);
 int launch_maxpool3x3s2(const float* x, float* out, int B, int H, int W, int C, int OH, int OW,
                         const LaunchCtx& ctx, const float* x1 = nullptr, float* out1 = nullptr);
-// x (B,HW,C) -> out[b*ldo + c] = mean_hw
-int launch_avgpool(const float* x, float* out, int B, int HW, int C, int ldo, const LaunchCtx& ctx);
+// IEF state row of image b at xc + b*ld: [xf (F) | pose6d 144 | shape 10 | cam 3 | rot6d(R) 6 | vfov 1 | 0-pad], F = trunk
+// features (2048 for ResNet-50: ld = 2240), state_off = F  (head.hip: head_init_kernel; stem.hip: extra workgroups of the avg-pool)
+struct HeadInit {
+    float* xc; const float *init_pose, *init_shape, *init_cam, *R, *K, *img_h;
+    int use_cam_feats, state_off, ld;
+};
+// columns state_off .. ld of row b, by `nthreads` threads
+__device__ __forceinline__ void head_init_row(const HeadInit& a, int b, int tid, int nthreads) {
+    float* row = a.xc + (size_t)b * a.ld + a.state_off;
+    for (int i = tid; i < a.ld - a.state_off; i += nthreads) {
+        float v = 0.f;
+        if (i < 144) v = a.init_pose[i];
+        else if (i < 154) v = a.init_shape[i - 144];
+        else if (i < 157) v = a.init_cam[i - 154];
+        else if (a.use_cam_feats && i < 163) {
+            const int e = i - 157;                   // rotmat[:, :, :2] row-major: (row, col) = (e/2, e%2)
+            v = a.R[(size_t)b * 9 + (e >> 1) * 3 + (e & 1)];
+        } else if (a.use_cam_feats && i == 163) {
+            v = 2.0f * atanf(a.img_h[b] / (2.0f * a.K[(size_t)b * 9]));
+        }
+        row[i] = v;
+    }
+}
+// x (B,HW,C) -> out[b*ldo + c] = mean_hw.  init != nullptr: the same launch also writes the IEF state columns of every row
+// (B more workgroups; one graph node less on the small-batch path) - returns 1 in *init_done if it did
+int launch_avgpool(const float* x, float* out, int B, int HW, int C, int ldo, const LaunchCtx& ctx, const HeadInit* init = nullptr,
+                   bool* init_done = nullptr);
 
 // ----------------------------------------------------------------------------------------
 // heads  (head.hip)
 // ----------------------------------------------------------------------------------------
-// IEF state row of image b at xc + b*ld: [xf (F) | pose6d 144 | shape 10 | cam 3 | rot6d(R) 6 | vfov 1 | 0-pad], F = trunk
-// features (2048 for ResNet-50: ld = 2240), state_off = F
 int launch_head_init(float* xc, const float* init_pose, const float* init_shape,
                      const float* init_cam, const float* cam_rotmat, const float* cam_intrinsics,
                      const float* img_h, int use_cam_feats, int B, int state_off, int ld, const LaunchCtx& ctx);
-// state: 157 regressor outputs per image at stride ld_state; ld[4] = per-image strides of pred_pose / pred_shape /
-// pred_cam / pred_pose_6d (216 / 10 / 3 / 144 when dense)
+// rot6d_to_rotmat of one joint (pare: Gram-Schmidt, F.normalize eps 1e-12); p = the joint's 6 numbers viewed (3, 2):
+// a1 = p[0], p[2], p[4]; a2 = p[1], p[3], p[5]; Rm row-major with columns b1 b2 b3
+__device__ __forceinline__ void rot6d_joint(const float* p, float* Rm) {
+    const float a1x = p[0], a1y = p[2], a1z = p[4];
+    const float a2x = p[1], a2y = p[3], a2z = p[5];
+    const float n1 = fmaxf(sqrtf(a1x * a1x + a1y * a1y + a1z * a1z), 1e-12f);
+    const float b1x = a1x / n1, b1y = a1y / n1, b1z = a1z / n1;
+    const float d = b1x * a2x + b1y * a2y + b1z * a2z;
+    const float ux = a2x - d * b1x, uy = a2y - d * b1y, uz = a2z - d * b1z;
+    const float n2 = fmaxf(sqrtf(ux * ux + uy * uy + uz * uz), 1e-12f);
+    const float b2x = ux / n2, b2y = uy / n2, b2z = uz / n2;
+    const float b3x = b1y * b2z - b1z * b2y;
+    const float b3y = b1z * b2x - b1x * b2z;
+    const float b3z = b1x * b2y - b1y * b2x;
+    Rm[0] = b1x; Rm[1] = b2x; Rm[2] = b3x; Rm[3] = b1y; Rm[4] = b2y; Rm[5] = b3y; Rm[6] = b1z; Rm[7] = b2z; Rm[8] = b3z;
+}
+// state: 157 regressor outputs per image at stride ld_state; ld_* = per-image strides of pred_pose / pred_shape /
+// pred_cam / pred_pose_6d (216 / 10 / 3 / 144 when dense); null outputs are skipped
+struct HeadFinal {
+    const float* state = nullptr; long ld_state = 0;
+    float *pred_pose = nullptr, *pred_shape = nullptr, *pred_cam = nullptr, *pred_pose_6d = nullptr;
+    long ld_pose = 216, ld_shape = 10, ld_cam = 3, ld_p6d = 144;
+    float *rot_ws = nullptr, *betas_ws = nullptr, *cam_ws = nullptr;
+};
 int launch_head_final(const float* state, long ld_state, float* pred_pose, float* pred_shape, float* pred_cam,
                       float* pred_pose_6d, const long ld[4], float* rotmat_ws, float* betas_ws, float* cam_ws,
                       int B, const LaunchCtx& ctx);
@@ -232,6 +277,9 @@ struct SmplArgs {
     float img_res;
     int normalize_joints2d;
     int skin_split = -1;   // -1: by batch, 0 / 1: never / always three waves per vertex group (same bits)
+    // non-null: the pose kernel first does head_final's work for its image (rot6d -> rotmat, output gather) and takes rotmat /
+    // betas from there instead of a.rotmat / a.betas (one graph node less; same bits)
+    const HeadFinal* final_ = nullptr;
 };
 int launch_smpl(const SmplDev& m, const SmplArgs& a, const LaunchCtx& ctx);
 // vertices (optional) + the 24 posed kinematic joints (optional; a.posed_j receives them otherwise)

@@ -249,8 +249,14 @@ int launch_maxpool3x3s2(const float* x, float* out, int B, int H, int W, int C, 
 }
 
 // ------------------------------------------------------------------------------------------
+// workgroups past the pooling ones (nblk_pool .. nblk_pool + B - 1, only launched with an IEF head behind the pool) write the
+// state columns of one row each: head_init's work without its graph node
 __global__ void __launch_bounds__(256) avgpool_kernel(const float* __restrict__ x, float* __restrict__ out, int HW,
-                                                       int C4, int ldo, int total) {
+                                                       int C4, int ldo, int total, int nblk_pool, const HeadInit init) {
+    if ((int)blockIdx.x >= nblk_pool) {
+        head_init_row(init, blockIdx.x - nblk_pool, threadIdx.x, blockDim.x);
+        return;
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int c4 = i % C4, b = i / C4;
@@ -300,14 +306,19 @@ __global__ void __launch_bounds__(1024) avgpool_parts_kernel(const float* __rest
     }
 }
 
-int launch_avgpool(const float* x, float* out, int B, int HW, int C, int ldo, const LaunchCtx& ctx) {
+int launch_avgpool(const float* x, float* out, int B, int HW, int C, int ldo, const LaunchCtx& ctx, const HeadInit* init, bool* init_done) {
     if (C % 4) return (int)hipErrorInvalidValue;
+    if (init_done) *init_done = false;
     const int total = B * (C / 4);
     ProfScope ps(ctx, "avgpool_f32", 0.0, 4.0 * ((double)B * HW * C + (double)B * C));
     int parts = HW / 32;                       // a function of the map size only
     parts = parts < 1 ? 1 : (parts > 16 ? 16 : parts);
     if (parts == 1) {
-        hipLaunchKernelGGL(avgpool_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx.stream, x, out, HW, C / 4, ldo, total);
+        const int nblk = (total + 255) / 256;
+        const bool fuse = init && init_done;
+        hipLaunchKernelGGL(avgpool_kernel, dim3(nblk + (fuse ? B : 0)), dim3(256), 0, ctx.stream, x, out, HW, C / 4, ldo, total, nblk,
+                           fuse ? *init : HeadInit{});
+        if (fuse) *init_done = true;
     } else {
         const int C4 = C / 4, chunk = (HW + parts - 1) / parts;
         hipLaunchKernelGGL(avgpool_parts_kernel, dim3((C4 + 63) / 64, B), dim3(64, parts), 0, ctx.stream, x, out, HW, C4, ldo, parts, chunk);

@@ -297,3 +297,32 @@ def test_graph_captured_before_workspace_growth_still_replays():
     for k, v in ref.items():
         assert torch.equal(out[k], v), k
     del junk
+
+
+@pytest.mark.parametrize('use_cam,ucf', [(True, True), (False, False)])
+def test_fused_head_nodes_bit_identical(use_cam, ucf):
+    """Option "head_fuse" (bit 0 / bit 1, default 3): the IEF state columns are written by extra workgroups of the pooling
+    launch, and head_final's work (rot6d -> rotmat, the pred_* gather) is done by the SMPL pose kernel - two graph nodes less
+    on the small-batch path.  Same arithmetic, same bits as the separate kernels, on both plans and with a ragged batch."""
+    from spec_amd import synth
+    _, hm = gpu_models(use_cam, ucf, DEV)
+    eng = hm.engine(torch.device(DEV))
+    for B, plan in ((1, 'latency'), (5, 'latency'), (19, 'throughput')):
+        hm.set_plan(plan)
+        x = t(synth.images(70 + B, B)).to(DEV)
+        args = [x]
+        if use_cam:
+            g = torch.Generator().manual_seed(B)
+            R = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))[0].contiguous()
+            K = torch.zeros(B, 3, 3); K[:, 0, 0] = K[:, 1, 1] = 500 + 200 * torch.rand(B, generator=g); K[:, 0, 2], K[:, 1, 2] = 320., 240.
+            sc, ce, iw, ih = [t(a) for a in synth.bbox_inputs(5, B, 640., 480.)]
+            args += [a.to(DEV) for a in (R, K, sc, ce, iw, ih)]
+        outs = []
+        for fuse in (0, 1, 2, 3):
+            eng.set_option('head_fuse', fuse)
+            outs.append({k: v.clone() for k, v in hm(*args).items()})
+        eng.set_option('head_fuse', 3)
+        for o in outs[1:]:
+            assert outs[0].keys() == o.keys()
+            for k in outs[0]:
+                assert torch.equal(outs[0][k], o[k]), (B, plan, k)
