@@ -676,7 +676,7 @@ def main():
                 ms = row['auto_ms']
                 # whole-step executed FLOPs against the fp32 MFMA roof and the weights of both networks against HBM
                 row.update({'ms_per_step': ms, 'images_per_s': round(b * 1e3 / ms, 1), 'plan': 'latency (plan = auto, batch <= 10)',
-                            'structure': 'grouped launches, one stream' if (b <= 2 or 9 <= b <= 16) else 'two trunks on two streams',
+                            'structure': 'grouped launches, one stream' if (b <= 2 or 11 <= b <= 16) else 'two trunks on two streams',
                             'speedup_vs_throughput_plan': round(row['grouped_throughput_plan_ms'] / ms, 3),
                             'algorithmic_TFLOPs': round(b * 2 * TRUNK_GFLOP_PER_IMAGE / ms, 2),
                             'frac_of_mfma_peak_algorithmic': round(b * 2 * TRUNK_GFLOP_PER_IMAGE / ms / PEAK_FP32_MFMA_TFLOPS, 4),

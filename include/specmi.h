@@ -127,7 +127,7 @@ const char* specmi_version(void);
  *   unsharded).  BETWEEN plans the last bits differ (other association of the same products, other algorithm on layer3 / layer4
  *   conv2); both meet the 1e-4 contract on every reference fixture (tests/test_gpu_e2e.py).  Callers that need bit-reproducibility
  *   across batch sizes on both sides of the switch pin a plan.
- *   Tuning / tests: "latency_target_wgs" (256), "latency_min_chunks" (4), "latency_wino_min_tiles" (128), "latency_fill_wgs" (250),
+ *   Tuning / tests: "latency_target_wgs" (256), "latency_min_chunks" (4), "latency_wino_min_tiles" (128), "latency_fill_wgs" (240),
  *   "latency_force_unit" (0 = by batch, 1 / 2 / 3 = a leaf / a group / the whole K per workgroup: same bits),
  *   "conv2d_sk" (specmi_conv2d only: 0 = throughput kernel, -1 = the latency plan's rule, n > 1 = n leaves),
  *   "smpl_skin_split" (-1 = by batch: three waves per 32-vertex group up to 64 images, one beyond; 0 / 1 = never / always: same bits),

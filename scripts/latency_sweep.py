@@ -15,6 +15,7 @@ ap.add_argument('--minchunks', default='2,4,8')
 ap.add_argument('--wino', default='0,128,100000')
 ap.add_argument('--fill', default='200')
 ap.add_argument('--reps', type=int, default=200)
+ap.add_argument('--grouped', default='1', help="1 = grouped launches, 0 = two trunks on two streams, auto = SpecPipeline's own choice")
 args = ap.parse_args()
 torch.set_grad_enabled(False)
 dev = torch.device('cuda:0')
@@ -23,7 +24,7 @@ cc, hm, _, _ = bench.build_models(dev)
 
 def time_step(b, reps):
     x, sc, ce, iw, ih = bench.make_inputs(b, dev, 7)
-    g = GraphedPipeline(SpecPipeline(cc, hm, grouped=True), x, sc, ce, iw, ih)
+    g = GraphedPipeline(SpecPipeline(cc, hm, grouped={'1': True, '0': False}.get(args.grouped, 'auto')), x, sc, ce, iw, ih)
     ins = g.static_in
     for _ in range(10):
         g(*ins)

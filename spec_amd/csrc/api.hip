@@ -708,7 +708,7 @@ static int launch_op(specmi_handle* h, const TrunkOp& op, const OpLaunch& L, con
         const int groups = partner ? 2 : 1;
         int rc;
         SkPlan pl = conv_igemm_sk_plan(L.a, groups, opt_i(h, "latency_target_wgs", 256), opt_i(h, "latency_min_chunks", 4),
-                                       opt_i(h, "latency_fill_wgs", 250));
+                                       opt_i(h, "latency_fill_wgs", 240));
         const int fu = opt_i(h, "latency_force_unit", 0);   // tests: 1 leaf / 2 group / 3 whole K per workgroup, whatever the batch
         if (fu) pl.unit = fu == 1 ? 1 : (fu == 2 ? pl.G : pl.leaves);
         if ((rc = ensure_sk(h, conv_igemm_sk_ws_floats(L.a, pl.leaves / pl.unit, groups), conv_igemm_sk_tiles(L.a, groups)))) return rc;
@@ -1414,7 +1414,7 @@ int specmi_conv2d(specmi_handle* h, const float* x, int B, int H, int W, int Cin
         if (split && conv_bf16s_supported(a)) lrc = launch_conv_bf16s(a, dsplit, terms, ctx);
         else if (S != 0) {
             SkPlan pl = conv_igemm_sk_plan(a, 1, opt_i(h, "latency_target_wgs", 256), opt_i(h, "latency_min_chunks", 4),
-                                           opt_i(h, "latency_fill_wgs", 250));
+                                           opt_i(h, "latency_fill_wgs", 240));
             if (S > 0) {
                 pl.leaves = S; pl.G = 1;
                 for (int g = 2; g <= 4; ++g)

@@ -37,9 +37,10 @@ class SpecPipeline:
         (``specmi_trunk_forward_pair``) instead of two trunks on two streams: half the launches, no stream join - what small
         batches want; results are bit-identical either way.  Falls back to ``overlap`` when the shapes differ.
         ``'auto'`` (default) groups where it measured faster on MI355X (scripts/grouped_sweep.py, round 4,
-        profiles/r04_e_grouped_sweep.jsonl): batch 1-2 (0.70 vs 0.79 ms at batch 1) and 9-16 (throughput plan: 2.45 vs 2.59 ms at
-        batch 16); at batch 3-8 the latency plan's sliced kernels run better as two trunks on two streams (1.52 vs 1.62 ms at batch
-        8: one trunk's launch gaps and reduction tails hide under the other's kernels), beyond 16 two streams are ahead as before.
+        profiles/r04_e_grouped_sweep.jsonl, r04_z_fill_sweep.txt): batch 1-2 (0.65 vs 0.74 ms at batch 1) and 11-16 (throughput
+        plan: 2.45 vs 2.59 ms at batch 16); at batch 3-10 the latency plan's sliced kernels run better as two trunks on two streams
+        (1.44 vs 1.54 ms at batch 8, 1.55 vs 1.59 at 10: one trunk's launch gaps and reduction tails hide under the other's
+        kernels), beyond 16 two streams are ahead as before.
         ``packed=True``: the kernels write every per-image output straight into ONE (B, 21294)-float record (the
         all-gather payload of config 4); the returned tensors are views of it and ``out['record']`` is the record
         itself, so collecting results over RCCL needs no packing copy."""
@@ -78,7 +79,7 @@ class SpecPipeline:
             v = eng.record_views(record)
             angles = (v['cam_vfov'], v['cam_pitch'], v['cam_roll'])
         nb = images.shape[0]
-        want_group = (nb <= 2 or 9 <= nb <= 16) if self.grouped == 'auto' else bool(self.grouped)
+        want_group = (nb <= 2 or 11 <= nb <= 16) if self.grouped == 'auto' else bool(self.grouped)
         can_group = (want_group and self.hmr.use_cam and cam_in.shape == images.shape and
                      getattr(self.hmr, '_backbone_id', 50) == getattr(self.camcalib, '_backbone_depth', 50) and
                      getattr(self.hmr, 'conv_precision', 0) == 0 and getattr(self.camcalib, 'conv_precision', 0) == 0)
