@@ -325,6 +325,21 @@ int specmi_regress_joints(specmi_handle* h, const float* vertices, int B, int V,
  * -> out (B,N,3), out[b,n] = R[b] points[b,n]. */
 int specmi_rotate_points(specmi_handle* h, const float* R, const float* points, int B, int N, float* out, void* stream);
 
+/* ---- in-launch hand-off state (round 5) ---------------------------------------------------
+ * The latency / single plans hand data between workgroups INSIDE a launch (split-K tile tickets, the completion counters of the
+ * persistent multi-layer walker: spec_amd/csrc/conv_persist.hip).  Those protocols keep a few device counters that every launch
+ * leaves at zero.  They have no counterpart in the reference (spec/tester.py:109-151 runs stock torch ops). */
+
+/* Synchronises the device.  *persist_err: 0 = the handle's persistent launches all completed their hand-offs; 1 = a bounded spin
+ * gave up (the results of that launch are garbage: a protocol error or a grid that was not co-resident - more than two persistent
+ * forwards in flight on one device); < 0 = the control block was not left clean. */
+int specmi_sync_status(specmi_handle* h, int32_t* persist_err);
+/* Zeroes the hand-off counters on `stream`.  The library does this itself at specmi_commit and after any forward that returned
+ * an error; a caller that destroyed a captured graph mid-replay (or killed a launch some other way) calls it before the next forward. */
+int specmi_sync_reset(specmi_handle* h, void* stream);
+/* Tests only: overwrites every hand-off counter with `value` (synchronises). */
+int specmi_debug_poison_sync(specmi_handle* h, uint32_t value);
+
 /* ---- profiling -------------------------------------------------------------------------- */
 
 /* When on, every kernel launch is bracketed by HIP events on the launch stream. */

@@ -21,7 +21,7 @@ def source_hash() -> str:
     h = hashlib.sha256()
     csrc = os.path.join(_HERE, 'csrc')
     for name in sorted(os.listdir(csrc)):
-        if name.endswith(('.hip', '.h')):
+        if name.endswith(('.hip', '.h', '.inc')):
             with open(os.path.join(csrc, name), 'rb') as f:
                 h.update(name.encode() + b'\0' + f.read())
     with open(os.path.join(os.path.dirname(_HERE), 'include', 'specmi.h'), 'rb') as f:
@@ -116,6 +116,9 @@ PROTOTYPES = {
     'specmi_regress_joints': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                         C.c_void_p]),
     'specmi_rotate_points': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'specmi_sync_status': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    'specmi_sync_reset': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'specmi_debug_poison_sync': (C.c_int, [C.c_void_p, C.c_uint32]),
     'specmi_profile_enable': (C.c_int, [C.c_void_p, C.c_int]),
     'specmi_profile_read': (C.c_int, [C.c_void_p, C.POINTER(ProfEntry), C.c_int, C.POINTER(C.c_int)]),
 }

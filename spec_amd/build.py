@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libspecmi.so')
-SOURCES = ['api.hip', 'hrnet.hip', 'conv_igemm.hip', 'conv_wino.hip', 'conv_bf16s.hip', 'stem.hip', 'head.hip', 'smpl.hip', 'eval.hip', 'preprocess.hip']
+SOURCES = ['api.hip', 'hrnet.hip', 'conv_igemm.hip', 'conv_persist.hip', 'conv_wino.hip', 'conv_bf16s.hip', 'stem.hip', 'head.hip', 'smpl.hip', 'eval.hip', 'preprocess.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
 
@@ -37,7 +37,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objdir = os.path.join(LIBDIR, 'obj')
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, 'specmi_internal.h'), os.path.join(CSRC, 'handle.h'),
+    headers = [os.path.join(CSRC, 'specmi_internal.h'), os.path.join(CSRC, 'handle.h'), os.path.join(CSRC, 'conv_igemm_tile.h'),
+               os.path.join(CSRC, 'conv_igemm_body.inc'),
                os.path.join(os.path.dirname(HERE), 'include', 'specmi.h')]
 
     def compile_one(src):

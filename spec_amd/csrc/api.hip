@@ -466,6 +466,15 @@ static int sync_for_growth(specmi_handle* h, const char* what) {
     return fail(h, SPECMI_ERR_HIP, "hipDeviceSynchronize failed while growing %s: %s", what, hipGetErrorString(e));
 }
 
+// The in-launch hand-offs (split-K tile tickets, the persistent walker's completion counters) rely on counters that every
+// launch leaves at zero.  A launch that dies mid-flight does not: zero them whenever that may have happened (after any failed
+// forward), at specmi_commit and on demand (specmi_sync_reset).  Enqueued on `s`.
+static void reset_sync_state(specmi_handle* h, hipStream_t s) {
+    if (h->sk.cnt) (void)hipMemsetAsync(h->sk.cnt, 0, (size_t)h->sk.ncnt * 4, s);
+    if (h->pctl) (void)hipMemsetAsync(h->pctl, 0, sizeof(PersistCtl), s);
+    (void)hipGetLastError();
+}
+
 static int ensure_ws(specmi_handle* h, int B, int H, int W) {
     const int oh1 = conv_out(H, 7, 2, 3), ow1 = conv_out(W, 7, 2, 3);
     // largest activation: stem output (B,oh1,ow1,64) == layer1 output (B,oh1/2,ow1/2,256) rounded up
@@ -479,11 +488,15 @@ static int ensure_ws(specmi_handle* h, int B, int H, int W) {
     if (int rc0 = sync_for_growth(h, "the activation workspace")) return rc0;
     // the outgrown buffers stay alive until specmi_destroy (as the split-K workspace does): a hipGraph captured at a smaller
     // batch / resolution has their addresses baked into its kernel nodes, and replaying it after an eager call at a larger size
-    // must not write into freed memory.  Growth is monotonic, so what is retired is bounded by the final size.
+    // must not write into freed memory.  Growth is geometric (a dimension that must grow grows to at least 1.5x its old size), so
+    // an ascending sweep of batch sizes or resolutions retires a geometric series: at most ~3x the final size in total
+    // instead of one full copy per step.
     h->ws_retired.insert(h->ws_retired.end(), h->ws_allocs.begin(), h->ws_allocs.end());
     h->ws_allocs.clear();
+    if (grow_act && h->act_elems && elems < h->act_elems + h->act_elems / 2) elems = h->act_elems + h->act_elems / 2;
     if (elems < h->act_elems) elems = h->act_elems;
-    const int Bw = B > h->ws_B ? B : h->ws_B;
+    int Bw = B > h->ws_B ? B : h->ws_B;
+    if (grow_b && h->ws_B && Bw < h->ws_B + h->ws_B / 2) Bw = h->ws_B + h->ws_B / 2;
     // the workspace is gone from here on: if an allocation below fails, the next call must not take the early return
     // above on the strength of the old sizes and launch kernels on freed memory
     h->act_elems = 0; h->ws_B = 0;
@@ -521,6 +534,7 @@ static int ensure_sk(specmi_handle* h, size_t floats, int ncnt) {
     if (int rc0 = sync_for_growth(h, "the split-K workspace")) return rc0;
     if (floats < h->sk.floats) floats = h->sk.floats;
     if (ncnt < h->sk.ncnt) ncnt = h->sk.ncnt;
+    if (h->sk.floats && floats > h->sk.floats && floats < h->sk.floats + h->sk.floats / 2) floats = h->sk.floats + h->sk.floats / 2;   // geometric: see ensure_ws
     floats = (floats + ((size_t)1 << 20) - 1) >> 20 << 20;
     ncnt = round_up(ncnt < 4096 ? 4096 : ncnt, 4096);
     // the outgrown buffers stay alive until specmi_destroy: a hipGraph captured earlier (GraphedPipeline at another batch
@@ -607,7 +621,8 @@ struct OpLaunch {
 };
 
 static OpLaunch prepare_op(specmi_handle* h, const TrunkOp& op, const float* images, float* feat_out, int b0, int nb,
-                           int Himg, int Wimg, bool latency = false) {
+                           int Himg, int Wimg, int mode = 0) {
+    const bool latency = mode != 0;
     auto buf = [&](int idx) -> float* { return idx == -2 ? feat_out : h->act[idx]; };
     OpLaunch L;
     L.kind = op.kind;
@@ -659,6 +674,7 @@ static OpLaunch prepare_op(specmi_handle* h, const TrunkOp& op, const float* ima
         // walking Cin = 512 for 75 us, the sliced direct kernel takes 45)
         const int min_tiles = opt_i(h, "latency_wino_min_tiles", 128);
         if (wino && ((a.OH + 1) / 2) * ((a.OW + 1) / 2) < (min_tiles > a.Cin || min_tiles == 0 || min_tiles >= 100000 ? min_tiles : a.Cin)) wino = false;
+        if (mode == 2) wino = false;   // 'single': batch 1-2, the direct kernel wins on layer1 / layer2 too
         if (!wino) L.sk = conv_igemm_sk_slices(a, opt_i(h, "latency_target_wgs", 256), opt_i(h, "latency_min_chunks", 4));
     }
     if (wino) {
@@ -668,19 +684,28 @@ static OpLaunch prepare_op(specmi_handle* h, const TrunkOp& op, const float* ima
     return L;
 }
 
-// plan: 0 auto, 1 throughput, 2 latency.  auto = latency while the call carries no more pixels than N images of 224 x 224,
-// N = option "latency_max_batch" (10) for the trunk PAIR and "latency_max_batch_single" (16) for one trunk - measured per batch size
+// plan: 0 auto, 1 throughput, 2 latency, 3 single.  Returns the trunk mode of this call: 0 throughput kernels, 1 latency (sliced
+// direct kernels on layer3 / layer4, Winograd where an image fills its rows), 2 single (round 5: batch 1-2, the reference's demo
+// granularity, scripts/camcalib_demo.py:95-102 - every 3x3 convolution on the sliced direct kernel, which is faster there by
+// 21 / 12 us at batch 1 / 2 (profiles/r04_b_latency_layers.txt) and leaves the whole trunk behind the max-pool as one run of
+// implicit-GEMM layers for the persistent walker).  auto = single up to "single_max_batch" (2) images' worth of pixels, latency up
+// to N = "latency_max_batch" (10) for the trunk PAIR / "latency_max_batch_single" (16) for one trunk - measured per batch size
 // (profiles/r04_l_plan_crossover.jsonl: pair 1.67 vs 1.78 ms at 10 images, 2.18 vs 2.15 at 12; one trunk after the other 3.08 vs
 // 3.32 ms still at 16; a single CamCalib frame at 600 x 1066 = 12.7 crops' worth of rows: 2.10 vs 2.27 ms for the demo's one-frame step)
-static bool use_latency_plan(specmi_handle* h, int B, int H, int W, bool pair = false) {
+static int trunk_mode(specmi_handle* h, int B, int H, int W, bool pair = false) {
     const int plan = opt_i(h, "plan", 0);
+    if (plan == 1) return 0;
+    if (plan == 2) return 1;
+    if (plan == 3) return 2;
+    const long px = (long)B * H * W, crop = 224L * 224;
+    if (px <= (long)opt_i(h, "single_max_batch", 2) * crop) return 2;
     const int nmax = pair ? opt_i(h, "latency_max_batch", 10) : opt_i(h, "latency_max_batch_single", 16);
-    return plan == 2 || (plan == 0 && (long)B * H * W <= (long)nmax * 224 * 224);
+    return px <= (long)nmax * crop ? 1 : 0;
 }
 // the FC layers behind the trunk see batch rows only: the small-batch GEMV kernel (head.hip) up to "latency_max_batch" rows
 static bool use_latency_heads(specmi_handle* h, int B) {
     const int plan = opt_i(h, "plan", 0);
-    return opt_i(h, "fc_gemv", 1) && (plan == 2 || (plan == 0 && B <= opt_i(h, "latency_max_batch", 10)));
+    return opt_i(h, "fc_gemv", 1) && (plan == 2 || plan == 3 || (plan == 0 && B <= opt_i(h, "latency_max_batch", 10)));
 }
 
 // partner != nullptr: the same op of a second network, launched together (one grouped launch); the caller has checked
@@ -729,8 +754,8 @@ static int launch_op(specmi_handle* h, const TrunkOp& op, const OpLaunch& L, con
 }
 
 static int exec_op(specmi_handle* h, const TrunkOp& op, const float* images, float* feat_out, int b0, int nb,
-                   int Himg, int Wimg, hipStream_t s, bool latency = false) {
-    const OpLaunch L = prepare_op(h, op, images, feat_out, b0, nb, Himg, Wimg, latency);
+                   int Himg, int Wimg, hipStream_t s, int mode = 0) {
+    const OpLaunch L = prepare_op(h, op, images, feat_out, b0, nb, Himg, Wimg, mode);
     return launch_op(h, op, L, nullptr, nb, Himg, Wimg, s);
 }
 
@@ -805,6 +830,120 @@ static void plan_trunk(specmi_handle* h, int H, int W, bool to_caller, TrunkPlan
     P.final_buf = final_buf; P.fh = ch; P.fw = cw;
 }
 
+// ---- persistent runs (conv_persist.hip) ----------------------------------------------------------------------------------
+// Ops [i0, i1) of a trunk (Lb == nullptr) or of a trunk pair - all implicit-GEMM convolutions of the latency / single plan - as
+// ONE launch.  Returns SPECMI_OK, an error, or -1: "not for the walker" (a shape it does not take: the caller launches the
+// layers one by one).
+static int persist_run(specmi_handle* h, const std::vector<OpLaunch>& La, const std::vector<OpLaunch>* Lb, const std::vector<TrunkOp>& ops,
+                       size_t i0, size_t i1, float* feat_a, float* feat_b, hipStream_t s) {
+    const int nl = (int)(i1 - i0);
+    const int groups = Lb ? 2 : 1;
+    std::vector<PersistLayerHost> lay((size_t)nl);
+    float *out0 = nullptr, *out1 = nullptr;
+    const int fill = opt_i(h, "persist_fill_wgs", opt_i(h, "latency_fill_wgs", 240));
+    const int fu = opt_i(h, "latency_force_unit", 0);
+    for (int l = 0; l < nl; ++l) {
+        PersistLayerHost& P = lay[(size_t)l];
+        P.a = La[i0 + l].a;
+        P.pair = Lb != nullptr;
+        if (Lb) P.b = (*Lb)[i0 + l].a;
+        P.pl = conv_igemm_sk_plan(P.a, groups, opt_i(h, "latency_target_wgs", 256), opt_i(h, "latency_min_chunks", 4), fill);
+        if (fu) P.pl.unit = fu == 1 ? 1 : (fu == 2 ? P.pl.G : P.pl.leaves);
+        if (ops[i0 + l].out_buf == -2) {
+            // the caller's feature buffer changes from call to call (and between the warm-up and the capture of a graph): it is a
+            // launch argument, the table holds a placeholder
+            if ((reinterpret_cast<uintptr_t>(feat_a) & 15) || (Lb && (reinterpret_cast<uintptr_t>(feat_b) & 15))) return -1;
+            P.out_arg = 1;
+            out0 = feat_a; out1 = feat_b;
+            P.a.out = nullptr;
+            if (Lb) P.b.out = nullptr;
+        }
+    }
+    const int nwg = opt_i(h, "persist_wgs", Lb ? 512 : 256);
+    const int l2pf = opt_i(h, "persist_l2_prefetch", 0);
+    size_t ws_need = 0;
+    int cnt_need = 0;
+    if (persist_fill_table(lay.data(), nl, SkWs{}, nwg, l2pf, nullptr, &ws_need, &cnt_need)) return -1;
+    int rc;
+    if ((rc = ensure_sk(h, ws_need ? ws_need : 1, cnt_need))) return rc;
+    std::vector<unsigned char> img(persist_table_bytes(nl));
+    if (persist_fill_table(lay.data(), nl, h->sk, nwg, l2pf, img.data(), &ws_need, &cnt_need)) return -1;
+    const specmi_handle::PersistTable* tab = nullptr;
+    for (const auto& t : h->persist_tables)
+        if (t.nl == nl && t.img.size() == img.size() && memcmp(t.img.data(), img.data(), img.size()) == 0) { tab = &t; break; }
+    if (!tab || !h->pctl) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); st = hipStreamCaptureStatusNone; }
+        if (st != hipStreamCaptureStatusNone)
+            return fail(h, SPECMI_ERR_STATE, "the layer table of this batch / resolution is not on the device yet, which is not possible while "
+                        "a stream is being captured: run one eager forward of this shape first (the capture is invalid now)");
+        if (!h->pctl) {
+            HIPCHK(h, hipMalloc((void**)&h->pctl, sizeof(PersistCtl)));
+            HIPCHK(h, hipMemset(h->pctl, 0, sizeof(PersistCtl)));
+        }
+        if (!tab) {
+            specmi_handle::PersistTable t;
+            t.nl = nl;
+            HIPCHK(h, hipMalloc(&t.dev, img.size()));
+            HIPCHK(h, hipMemcpy(t.dev, img.data(), img.size(), hipMemcpyHostToDevice));
+            t.img = std::move(img);
+            h->persist_tables.push_back(std::move(t));
+            tab = &h->persist_tables.back();
+        }
+    }
+    LaunchCtx ctx{s, &h->prof, ops[i0].label.c_str()};
+    LAUNCHCHK(h, launch_persist(tab->dev, nl, h->pctl, out0, out1, nwg, (unsigned)opt_i(h, "persist_spin_limit", 400000), ctx, 0.0, 0.0),
+              "persistent trunk run");
+    return SPECMI_OK;
+}
+
+// Launch ops [first, n) of a trunk (hb == nullptr) or of a trunk pair.  mode != 0 and option "persist" (default 1): maximal runs of
+// implicit-GEMM convolutions go to the persistent walker (one launch per run of up to 64 layers), everything else - the stem,
+// the max-pool, Winograd layers, the optional split-bf16 path - is launched op by op as before.
+static int launch_ops(specmi_handle* ha, specmi_handle* hb, const TrunkPlan& Pa, const TrunkPlan* Pb, const float* img_a, const float* img_b,
+                      int B, int H, int W, float* feat_a, float* feat_b, size_t first, int mode, hipStream_t s) {
+    const size_t n = Pa.ops.size();
+    std::vector<OpLaunch> La(n), Lb(hb ? n : 0);
+    for (size_t i = first; i < n; ++i) {
+        La[i] = prepare_op(ha, Pa.ops[i], img_a, feat_a, 0, B, H, W, mode);
+        if (!hb) continue;
+        Lb[i] = prepare_op(hb, Pb->ops[i], img_b, feat_b, 0, B, H, W, mode);
+        OpLaunch &A = La[i], &Bp = Lb[i];
+        if (A.kind == 2 && Bp.kind == 2 && A.family != 2 && Bp.family != 2 && (Bp.family != A.family || Bp.sk != A.sk)) {
+            // the kernel choice reads per-handle options ("winograd", "latency_*"): the pair follows the first handle
+            Bp.family = A.family; Bp.sk = A.sk;
+            Bp.a.w = A.family == 1 ? Pb->ops[i].c->wino : (Pb->ops[i].fused ? Pb->ops[i].fused->f_w : Pb->ops[i].c->w);
+            if (A.family == 1 && !Bp.a.w) return fail(ha, SPECMI_ERR_ARG, "op %zu: the second trunk has no Winograd filters", i);
+        }
+        const TrunkOp &oa = Pa.ops[i], &ob = Pb->ops[i];
+        if (A.kind != Bp.kind || A.family != Bp.family || oa.H != ob.H || oa.W != ob.W || oa.OH != ob.OH || oa.OW != ob.OW ||
+            (A.kind == 2 && (oa.c->cin != ob.c->cin || oa.c->cout != ob.c->cout || oa.c->k != ob.c->k || oa.c->stride != ob.c->stride ||
+                             (oa.fused != nullptr) != (ob.fused != nullptr) || oa.relu != ob.relu)))
+            return fail(ha, SPECMI_ERR_ARG, "op %zu (%s) differs between the two trunks: grouped launches need identical layer shapes",
+                        i, oa.label.c_str());
+    }
+    // (the built-in launch profiler wants one record per layer: it sees the per-layer launches)
+    const bool persist = mode != 0 && opt_i(ha, "persist", 1) && !ha->prof.on;
+    const size_t min_run = (size_t)opt_i(ha, "persist_min_run", 2);
+    auto eligible = [&](size_t i) { return La[i].kind == 2 && La[i].family == 0 && !La[i].a.force_variant; };
+    int rc;
+    size_t i = first;
+    while (i < n) {
+        if (persist && eligible(i)) {
+            size_t j = i;
+            while (j < n && eligible(j) && j - i < (size_t)kPersistMaxLayers) ++j;
+            if (j - i >= min_run) {
+                rc = persist_run(ha, La, hb ? &Lb : nullptr, Pa.ops, i, j, feat_a, feat_b, s);
+                if (rc == SPECMI_OK) { i = j; continue; }
+                if (rc != -1) return rc;
+            }
+        }
+        if ((rc = launch_op(ha, Pa.ops[i], La[i], hb ? &Lb[i] : nullptr, B, H, W, s))) return rc;
+        ++i;
+    }
+    return SPECMI_OK;
+}
+
 // images NCHW -> layer4 map NHWC in *feat (a workspace buffer unless feat_out given).
 // Option "trunk_subbatch" = S > 0: the stem, the max-pool and the first "trunk_subbatch_layers"
 // ResNet stages are run S images at a time (activations of a slice are <= 103 MB at S = 32 and stay
@@ -826,18 +965,17 @@ static int run_trunk(specmi_handle* h, const float* images, int B, int H, int W,
     const int final_buf = P.final_buf, ch = P.fh, cw = P.fw;
     const int S = opt_i(h, "trunk_subbatch", 0);
     const int Lsplit = opt_i(h, "trunk_subbatch_layers", 2);
+    const int mode = trunk_mode(h, B, H, W);
     size_t first_full = 0;
     if (S > 0 && S < B) {
         while (first_full < ops.size() && stage_of[first_full] <= Lsplit) ++first_full;
         for (int b0 = 0; b0 < B; b0 += S) {
             const int nb = (B - b0 < S) ? B - b0 : S;
             for (size_t i = 0; i < first_full; ++i)
-                if ((rc = exec_op(h, ops[i], images, feat_out, b0, nb, H, W, s, use_latency_plan(h, B, H, W)))) return rc;
+                if ((rc = exec_op(h, ops[i], images, feat_out, b0, nb, H, W, s, mode))) return rc;
         }
     }
-    const bool lat = use_latency_plan(h, B, H, W);
-    for (size_t i = first_full; i < ops.size(); ++i)
-        if ((rc = exec_op(h, ops[i], images, feat_out, 0, B, H, W, s, lat))) return rc;
+    if ((rc = launch_ops(h, nullptr, P, nullptr, images, nullptr, B, H, W, feat_out, nullptr, first_full, mode, s))) return rc;
     *feat = final_buf == -2 ? feat_out : h->act[final_buf];
     *fh = ch; *fw = cw;
     return SPECMI_OK;
@@ -858,25 +996,8 @@ static int run_trunk_pair(specmi_handle* ha, specmi_handle* hb, const float* img
     plan_trunk(ha, H, W, true, Pa);
     plan_trunk(hb, H, W, true, Pb);
     if (Pa.ops.size() != Pb.ops.size()) return fail(ha, SPECMI_ERR_ARG, "the two trunks have different depths");
-    const bool lat = use_latency_plan(ha, B, H, W, true);   // the first handle's options decide for the pair
-    for (size_t i = 0; i < Pa.ops.size(); ++i) {
-        const OpLaunch La = prepare_op(ha, Pa.ops[i], img_a, feat_a, 0, B, H, W, lat);
-        OpLaunch Lb = prepare_op(hb, Pb.ops[i], img_b, feat_b, 0, B, H, W, lat);
-        if (La.kind == 2 && Lb.kind == 2 && La.family != 2 && Lb.family != 2 && (Lb.family != La.family || Lb.sk != La.sk)) {
-            // the kernel choice reads per-handle options ("winograd", "latency_*"): the pair follows the first handle
-            Lb.family = La.family; Lb.sk = La.sk;
-            Lb.a.w = La.family == 1 ? Pb.ops[i].c->wino : (Pb.ops[i].fused ? Pb.ops[i].fused->f_w : Pb.ops[i].c->w);
-            if (La.family == 1 && !Lb.a.w) return fail(ha, SPECMI_ERR_ARG, "op %zu: the second trunk has no Winograd filters", i);
-        }
-        const TrunkOp &oa = Pa.ops[i], &ob = Pb.ops[i];
-        if (La.kind != Lb.kind || La.family != Lb.family || oa.H != ob.H || oa.W != ob.W || oa.OH != ob.OH || oa.OW != ob.OW ||
-            (La.kind == 2 && (oa.c->cin != ob.c->cin || oa.c->cout != ob.c->cout || oa.c->k != ob.c->k || oa.c->stride != ob.c->stride ||
-                              (oa.fused != nullptr) != (ob.fused != nullptr) || oa.relu != ob.relu)))
-            return fail(ha, SPECMI_ERR_ARG, "op %zu (%s) differs between the two trunks: grouped launches need identical layer shapes",
-                        i, oa.label.c_str());
-        if ((rc = launch_op(ha, oa, La, &Lb, B, H, W, s))) return rc;
-    }
-    return SPECMI_OK;
+    const int mode = trunk_mode(ha, B, H, W, true);   // the first handle's options decide for the pair
+    return launch_ops(ha, hb, Pa, &Pb, img_a, img_b, B, H, W, feat_a, feat_b, 0, mode, s);
 }
 
 // per-image strides of the HMR outputs: dense, or all equal to option "output_ld" (the outputs are then columns of
@@ -1018,6 +1139,8 @@ int specmi_destroy(specmi_handle* h) {
     if (h->sk.cnt) (void)hipFree(h->sk.cnt);
     free_pool(h->sk_retired);
     free_pool(h->ws_retired);
+    for (auto& t : h->persist_tables) if (t.dev) (void)hipFree(t.dev);
+    if (h->pctl) (void)hipFree(h->pctl);
     if (h->resize_tab) (void)hipFree(h->resize_tab);
     hrnet_free(h->hrnet);
     delete h;
@@ -1065,6 +1188,8 @@ int specmi_commit(specmi_handle* h) {
     if (!h) return SPECMI_ERR_ARG;
     DeviceGuard guard;
     HIPCHK(h, guard.enter(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    reset_sync_state(h, nullptr);
     HIPCHK(h, hipDeviceSynchronize());
     free_pool(h->param_allocs);
     h->committed = false;
@@ -1152,7 +1277,9 @@ int specmi_trunk_forward(specmi_handle* h, const float* images, int B, int H, in
     ENTER(h); NEED_COMMIT(h);
     if (!images || !feat || B <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
     const float* f; int fh, fw;
-    return run_trunk(h, images, B, H, W, feat, &f, &fh, &fw, (hipStream_t)stream);
+    const int rc = run_trunk(h, images, B, H, W, feat, &f, &fh, &fw, (hipStream_t)stream);
+    if (rc) reset_sync_state(h, (hipStream_t)stream);
+    return rc;
 }
 
 int specmi_trunk_forward_pair(specmi_handle* ha, specmi_handle* hb, const float* images_a, const float* images_b, int B, int H,
@@ -1165,7 +1292,9 @@ int specmi_trunk_forward_pair(specmi_handle* ha, specmi_handle* hb, const float*
     if (ha->hrnet || hb->hrnet || ha->blocks.size() != hb->blocks.size() || ha->blocks.empty() ||
         ha->blocks[0].basic != hb->blocks[0].basic)
         return fail(ha, SPECMI_ERR_ARG, "grouped trunk launches need two ResNet trunks of the same depth");
-    return run_trunk_pair(ha, hb, images_a, images_b, B, H, W, feat_a, feat_b, (hipStream_t)stream);
+    const int rc = run_trunk_pair(ha, hb, images_a, images_b, B, H, W, feat_a, feat_b, (hipStream_t)stream);
+    if (rc) reset_sync_state(ha, (hipStream_t)stream);
+    return rc;
 }
 
 static int run_camcalib_head(specmi_handle* h, const float* f, int B, int fh, int fw, float* lv, float* lp, float* lr, hipStream_t s);
@@ -1187,8 +1316,9 @@ int specmi_camcalib_forward(specmi_handle* h, const float* images, int B, int H,
     if (!images || !lv || !lp || !lr || B <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
     hipStream_t s = (hipStream_t)stream;
     const float* f; int fh, fw, rc;
-    if ((rc = run_trunk(h, images, B, H, W, nullptr, &f, &fh, &fw, s))) return rc;
-    return run_camcalib_head(h, f, B, fh, fw, lv, lp, lr, s);
+    if ((rc = run_trunk(h, images, B, H, W, nullptr, &f, &fh, &fw, s)) || (rc = run_camcalib_head(h, f, B, fh, fw, lv, lp, lr, s)))
+        reset_sync_state(h, s);
+    return rc;
 }
 
 static int run_camcalib_head(specmi_handle* h, const float* f, int B, int fh, int fw, float* lv, float* lp, float* lr, hipStream_t s) {
@@ -1550,6 +1680,46 @@ int specmi_rotate_points(specmi_handle* h, const float* R, const float* points, 
     if (!R || !points || !out || B <= 0 || N <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
     LaunchCtx ctx{(hipStream_t)stream, &h->prof, "eval.rotate_points"};
     LAUNCHCHK(h, launch_rotate_points(R, points, B, N, out, ctx), "rotate_points");
+    return SPECMI_OK;
+}
+
+int specmi_sync_status(specmi_handle* h, int32_t* persist_err) {
+    ENTER(h);
+    if (!persist_err) return fail(h, SPECMI_ERR_ARG, "null argument");
+    HIPCHK(h, hipDeviceSynchronize());
+    *persist_err = 0;
+    if (h->pctl) {
+        PersistCtl c;
+        HIPCHK(h, hipMemcpy(&c, h->pctl, sizeof(c), hipMemcpyDeviceToHost));
+        *persist_err = (int32_t)c.err;
+        if (!c.err) {   // a finished launch leaves the control block clean: anything else is a protocol error too
+            if (c.exit) *persist_err = -1;
+            for (int i = 0; i < 2 * kPersistMaxLayers; ++i)
+                if (c.done[i]) *persist_err = -2;
+        }
+    }
+    return SPECMI_OK;
+}
+
+int specmi_sync_reset(specmi_handle* h, void* stream) {
+    ENTER(h);
+    reset_sync_state(h, (hipStream_t)stream);
+    return SPECMI_OK;
+}
+
+int specmi_debug_poison_sync(specmi_handle* h, uint32_t value) {
+    ENTER(h);
+    HIPCHK(h, hipDeviceSynchronize());
+    if (h->sk.cnt) {
+        std::vector<unsigned> v((size_t)h->sk.ncnt, value);
+        HIPCHK(h, hipMemcpy(h->sk.cnt, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (h->pctl) {
+        PersistCtl c;
+        for (int i = 0; i < 2 * kPersistMaxLayers; ++i) c.done[i] = value;
+        c.exit = value; c.err = 0;
+        HIPCHK(h, hipMemcpy(h->pctl, &c, sizeof(c), hipMemcpyHostToDevice));
+    }
     return SPECMI_OK;
 }
 

@@ -51,668 +51,22 @@
 //     n-fastest, so tiles sharing an A row-panel hit the same 4 MiB L2.
 //   * epilogue: accumulators are transposed through LDS so that HBM sees 16-byte,
 //     row-contiguous stores / residual reads with scale/shift/ReLU fused.
-#include <type_traits>
-
-#include "specmi_internal.h"
+#include "conv_igemm_tile.h"
 
 namespace specmi {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-struct KArgs {
-    const float* x;
-    const float* w;
-    const float* scale;
-    const float* shift;
-    const float* res;
-    float* out;
-    unsigned x_bytes, w_bytes;  // buffer extents (< 2^31)
-    // optional second A source of a 1x1 layer (K = Cin + Cin2): the block input of a fused downsample branch
-    const float* x2;
-    unsigned x2_bytes;
-    int H2, W2, ldx2, stride2, cpc1;   // cpc1 = 32-channel chunks that come from x
-    int H, W, ldx;
-    int OW, OHW, Cout, Npad, ldo;
-    int KH, KW, stride, pad;
-    int M, nbn, nchunks, cpc;  // cpc = chunks per filter tap = Cin / 32
-    int xcd_cols;              // > 0: XCD x owns tile columns [x * xcd_cols, (x + 1) * xcd_cols) and walks all tile rows (see the tile order)
-    unsigned mg_ohw, sh_ohw, mg_ow, sh_ow;  // magic multipliers: n / OHW, n / OW for n < 2^31
-    int relu;
-    // SPLITK: blockIdx.y = K slice z of nchunks chunks; the raw accumulators of slice z of tile t (t = blockIdx.x + gridDim.x *
-    // blockIdx.z) go to sk_ws[(t * S + z) * BM * BN ..] in accumulator order, sk_cnt[t] counts the slices that have arrived
-    float* sk_ws;
-    unsigned* sk_cnt;
-    int sk_leaf, sk_G, sk_unit;   // chunks per leaf; leaves per group; leaves per workgroup (1, sk_G or all: nchunks = sk_unit * sk_leaf)
-    int vec_ok;  // out/res rows are 16-byte aligned: float4 epilogue traffic allowed
-    // grouped launch (gridDim.z = 2): blockIdx.z = 1 runs the SAME layer shape of a second network on its own tensors - the
-    // two ResNet-50 trunks of the path (CamCalib + SPEC) as one launch per layer: half the launches, and the partially
-    // filled last round of workgroups of one network is filled by the other
-    struct { const float *x, *w, *scale, *shift, *res, *x2; float* out; } g1;
-#ifdef SPECMI_TUNE
-    int ablate;  // perf ablation bits (wrong results!): 1 no global loads in loop, 2 no LDS restage, 4 no epilogue stores
-    unsigned long long* tprof;  // per-phase cycle counters (s_memtime)
-#endif
-};
-
-#ifdef SPECMI_TUNE
-#define TUNE_ABLATE(bit) (p.ablate & (bit))
-#define TUNE_T(var) const long long var = __builtin_amdgcn_s_memtime()
-#else
-#define TUNE_ABLATE(bit) 0
-#define TUNE_T(var)
-#endif
-
-constexpr unsigned kOutOfRange = 0x80000000u;  // >= any buffer extent: the load returns zeros
-
+// One workgroup = one (tile, K slice, network) of one layer: the body lives in conv_igemm_tile.h (shared with the persistent
+// multi-layer walker of conv_persist.hip)
 template <int BM, int BN, int WGM, int WGN, bool IS1X1, int BK, bool DUAL = false, bool SPLITK = false, bool BDIR = false>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_f32_kernel(const KArgs p) {
-    static_assert(!SPLITK || BDIR, "split-K exists for the 64x64 kernel that streams its B fragments");
-    static_assert(!(DUAL && !IS1X1), "");
-    static_assert(!DUAL || IS1X1, "the second A source exists for 1x1 layers only");
-    constexpr int LDA = BK + 4;
-    constexpr int KQ = BK / 4;   // 16-byte k-quads per chunk row
-    constexpr int NQ = BK / 8;   // 8-k sub-chunks per chunk
-    constexpr int NT = 64 * WGM * WGN;                         // threads: WGM x WGN waves
-    constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);  // 32x32 MFMA tiles per wave
-    constexpr int AI = BM * KQ / NT, BI = BN * KQ / NT;        // float4 loads per thread per chunk
-    constexpr int ARS = NT / KQ;                               // A rows covered per load pass
-    constexpr int A_STAGE = BM * LDA, B_STAGE = KQ * BN * 4;
-    static_assert(TM >= 1 && TN >= 1 && AI >= 1 && BI >= 1, "tile too small for the wave grid");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;
-    float* Bs = smem + 2 * A_STAGE;
-
-    const int tid = threadIdx.x;
-    const bool grp = blockIdx.z != 0;          // wave-uniform: scalar selects
-    const float* const px = grp ? p.g1.x : p.x;
-    const float* const pw = grp ? p.g1.w : p.w;
-    const float* const pscale = grp ? p.g1.scale : p.scale;
-    const float* const pshift = grp ? p.g1.shift : p.shift;
-    const float* const pres = grp ? p.g1.res : p.res;
-    const float* const px2 = grp ? p.g1.x2 : p.x2;
-    float* const pout = grp ? p.g1.out : p.out;
-#ifdef SPECMI_TUNE
-    const long long t_start = __builtin_amdgcn_s_memtime();
-    long long tp[4] = {0, 0, 0, 0};
-    (void)tp;
-#endif
-
-    // ---- XCD-aware tile order (bijective for any grid size) ------------------------------
-    const int nblk = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, q8 = nblk >> 3, r8 = nblk & 7;
-    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    int tile_m = L / p.nbn, tile_n = L - tile_m * p.nbn;
-    if (p.xcd_cols) {
-        // Weight panel larger than an XCD's 4 MiB L2 and many tile columns (layer4 conv3: 512 / 3072 x 2048 = 4 / 12 MiB, 32
-        // columns): with the row-major order every XCD streams the WHOLE panel again for each few tile rows (measured 0.45 / 2.0 GB
-        // of L2 misses per launch against 0.24 / 0.19 GB algorithmic, profiles/r03_v_layer_traffic.txt).  Here an XCD owns a
-        // fixed eighth of the columns - its slice of the panel stays in its L2 - and walks all tile rows; the (smaller) A
-        // operand is then read by all eight XCDs instead.  nbn % 8 == 0, so the grid splits evenly.
-        tile_n = xcd * p.xcd_cols + (bid >> 3) % p.xcd_cols;
-        tile_m = (bid >> 3) / p.xcd_cols;
-    }
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    // ---- buffer descriptors (wave-uniform) and per-thread row offsets -----------------------
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(px), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pw), 0, p.w_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t x2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DUAL ? px2 : px), 0, DUAL ? p.x2_bytes : p.x_bytes, 0x00020000);
-    const int a_kq = tid % KQ, a_r = tid / KQ;
-    unsigned a_voff[AI];   // byte offset of (row's tap-(0,0) pixel, quad a_kq); out-of-range when the row is past M (1x1)
-    unsigned a_mask[AI];   // 3x3: bit t = filter tap t lies inside the image for this row
-    unsigned a_voff2[DUAL ? AI : 1];   // DUAL: the row's pixel in the second source (its own size / stride / channel count)
-    // The tile prologue sits on every workgroup's critical path, so the pixel decode avoids the
-    // ~40-instruction integer divide: 1x1/stride-1 rows address the input with m itself, other
-    // shapes divide by OH*OW and OW with host-computed magic multipliers.
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-        const int m = m0 + a_r + ARS * i;
-        const bool ok = m < p.M;
-        const int mm = ok ? m : 0;
-        if (DUAL) {
-            if (p.stride2 == 1) {
-                a_voff2[i] = ok ? (unsigned)(mm * p.ldx2 * 4 + a_kq * 16) : kOutOfRange;
-            } else {
-                const int b2 = p.OHW == 1 ? mm : (int)(__umulhi((unsigned)mm, p.mg_ohw) >> p.sh_ohw);
-                const int rem2 = mm - b2 * p.OHW;
-                const int oy2 = p.OW == 1 ? rem2 : (int)(__umulhi((unsigned)rem2, p.mg_ow) >> p.sh_ow);
-                const int ox2 = rem2 - oy2 * p.OW;
-                const int pix2 = (b2 * p.H2 + oy2 * p.stride2) * p.W2 + ox2 * p.stride2;
-                a_voff2[i] = ok ? (unsigned)(pix2 * p.ldx2 * 4 + a_kq * 16) : kOutOfRange;
-            }
-        }
-        if (IS1X1 && p.stride == 1) {
-            a_voff[i] = ok ? (unsigned)(mm * p.ldx * 4 + a_kq * 16) : kOutOfRange;
-            a_mask[i] = 0;
-            continue;
-        }
-        const int b = p.OHW == 1 ? mm : (int)(__umulhi((unsigned)mm, p.mg_ohw) >> p.sh_ohw);
-        const int rem = mm - b * p.OHW;
-        const int oy = p.OW == 1 ? rem : (int)(__umulhi((unsigned)rem, p.mg_ow) >> p.sh_ow);
-        const int ox = rem - oy * p.OW;
-        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-        const int pix0 = (b * p.H + iy0) * p.W + ix0;
-        const unsigned off = (unsigned)(pix0 * p.ldx * 4 + a_kq * 16);   // wraps for padded rows; only used on valid taps
-        if (IS1X1) {
-            a_voff[i] = ok ? off : kOutOfRange;
-            a_mask[i] = 0;
-        } else {
-            a_voff[i] = off;
-            unsigned colbits = 0, mk = 0;   // tap (ky,kx) is inside the image iff row ky and column kx are
-            for (int kx = 0; kx < p.KW; ++kx) colbits |= ((unsigned)(ix0 + kx) < (unsigned)p.W ? 1u : 0u) << kx;
-            for (int ky = 0; ky < p.KH; ++ky)
-                if ((unsigned)(iy0 + ky) < (unsigned)p.H) mk |= colbits << (ky * p.KW);
-            a_mask[i] = ok ? mk : 0u;
-        }
-    }
-    unsigned b_voff[BI];
-#pragma unroll
-    for (int i = 0; i < BI; ++i) {
-        const int e = tid + NT * i;
-        const int kq = e / BN, n = e % BN;
-        b_voff[i] = (unsigned)(((kq * p.Npad) + n0 + n) * 16);
-    }
-
-    f32x4 ra[AI], rb[BI];
-    // chunk c = (tap, 32-channel slice); the per-chunk part of every address is scalar
-    const int cbase = SPLITK ? (int)blockIdx.y * p.nchunks : 0;   // first chunk of this workgroup's K slice
-    auto load_chunk = [&](int cl) {
-        const int c = cl + cbase;
-        const int tap = IS1X1 ? 0 : c / p.cpc;
-        const int c0 = IS1X1 ? c : c - tap * p.cpc;
-        unsigned tap_bytes = 0;
-        if (!IS1X1) {
-            const int ky = tap / p.KW, kx = tap - ky * p.KW;
-            tap_bytes = (unsigned)((ky * p.W + kx) * p.ldx * 4);
-        }
-        const bool second = DUAL && c >= p.cpc1;   // wave-uniform: chunks past cpc1 read the second source
-        const unsigned s_a = (unsigned)((second ? c0 - p.cpc1 : c0) * BK * 4);
-        const unsigned s_b = (unsigned)(c * KQ * p.Npad * 16);
-        if (!TUNE_ABLATE(16)) {
-#pragma unroll
-            for (int i = 0; i < AI; ++i) {
-                unsigned voff = a_voff[i];
-                if (!IS1X1) voff = ((a_mask[i] >> tap) & 1u) ? voff + tap_bytes : kOutOfRange;
-                if (DUAL) {   // one load either way: descriptor picked with scalar selects, offset with one v_cndmask
-                    ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(second ? x2rs : xrs, second ? a_voff2[i] : voff, s_a, 0));
-                } else {
-                    ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, s_a, 0));
-                }
-            }
-        }
-        if (!BDIR && !TUNE_ABLATE(32)) {
-#pragma unroll
-            for (int i = 0; i < BI; ++i)
-                rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, b_voff[i], s_b, 0));
-        }
-    };
-    auto store_chunk = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < AI; ++i)
-            *reinterpret_cast<f32x4*>(&As[buf * A_STAGE + (a_r + ARS * i) * LDA + a_kq * 4]) = ra[i];
-        if (!BDIR) {
-#pragma unroll
-            for (int i = 0; i < BI; ++i)
-                *reinterpret_cast<f32x4*>(&Bs[buf * B_STAGE + (tid + NT * i) * 4]) = rb[i];
-        }
-    };
-
-    // ---- wave / lane coordinates -------------------------------------------------------------
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int l31 = lane & 31, hh = lane >> 5;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // BDIR: the B (weight) fragments never touch LDS - every wave streams its own [32 k][32 n] blocks straight
-    // from L2 into rolling registers (the packed layout [K/4][Npad][4] is already the fragment layout:
-    // lane (n, k half) reads quad 2q + hh of column n), one chunk ahead
-    f32x4 fbq[BDIR ? NQ : 1][TN];
-    const unsigned fb_voff = (unsigned)((hh * p.Npad + n0 + wn * (BN / WGN) + l31) * 16);
-    auto load_bfrag = [&](int c, int q) {
-        const int ca = c + cbase;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-            fbq[BDIR ? q : 0][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                wrs, fb_voff + (unsigned)(j * 32 * 16), (unsigned)((ca * KQ + 2 * q) * p.Npad * 16), 0));
-    };
-
-    // ---- epilogue coordinates (known up front so the residual can be prefetched) ------------
-    constexpr int LDC = BN + 4;
-    constexpr int QPR = BN / 4;         // float4 quads per tile row
-    constexpr int RPP = NT / QPR;       // rows per pass
-    constexpr int NP = BM / RPP;        // passes over the tile rows
-    const int cq = tid % QPR, r0 = tid / QPR;
-    const int n = n0 + cq * 4;
-    const bool full = (n + 3 < p.Cout) && p.vec_ok;
-    f32x4 rr[NP];
-
-    if constexpr (!SPLITK) {
-        load_chunk(0);
-        if (BDIR) {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) load_bfrag(0, q);
-        }
-        store_chunk(0);
-        __syncthreads();
-    }
-
-    // ---- one K chunk, hand-scheduled ---------------------------------------------------------
-    // A wave issues in order, and an fp32 MFMA occupies the matrix pipe for 64 cycles while its
-    // issue takes ~4: whatever is placed BETWEEN two MFMAs in program order executes for free
-    // under the first one.  So the chunk is written as 16 steps (q, s) of TM*TN MFMAs with the
-    // other work slotted between them - next chunk's buffer loads after step 0, the fragment
-    // reads of sub-chunk q+1 inside sub-chunk q, the LDS writes of the staged next chunk in the
-    // last four steps - and sched_barrier keeps hipcc from regrouping it.
-    auto read_frags = [&](const float* Ab, const float* Bb, int q, f32x4 (&fa)[TM], f32x4 (&fb)[TN]) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDA + q * 8);
-        if (!BDIR) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bb + (q * 2 * BN + j * 32) * 4);
-        }
-    };
-    auto chunk = [&](int c, auto prefetch) {
-        constexpr bool PF = decltype(prefetch)::value;
-        const int buf = c & 1;
-        const float* Ab = As + buf * A_STAGE + (wm * (BM / WGM) + l31) * LDA + hh * 4;
-        const float* Bb = Bs + buf * B_STAGE + (hh * BN + wn * (BN / WGN) + l31) * 4;
-        float* Asn = As + (buf ^ 1) * A_STAGE;
-        float* Bsn = Bs + (buf ^ 1) * B_STAGE;
-        f32x4 fa[2][TM], fb[2][TN];
-        read_frags(Ab, Bb, 0, fa[0], fb[0]);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1][i][s], BDIR ? fbq[BDIR ? q : 0][j][s] : fb[q & 1][j][s], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (BDIR && PF && s == 3) load_bfrag(c + 1, q);   // rolling: these registers are next read one chunk from now
-                if (q == 0 && s == 0) {
-                    if (PF) {
-                        if (!TUNE_ABLATE(1)) load_chunk(c + 1);
-                    } else if (!SPLITK && pres && full) {   // last chunk: fetch the residual rows of the epilogue
-#pragma unroll
-                        for (int ps = 0; ps < NP; ++ps) {
-                            const int m = m0 + r0 + ps * RPP;
-                            const size_t o = (m < p.M) ? (size_t)m * p.ldo + n : (size_t)n;
-                            rr[ps] = *reinterpret_cast<const f32x4*>(pres + o);
-                        }
-                    }
-                }
-                if (s == 1 && q < NQ - 1) read_frags(Ab, Bb, q + 1, fa[(q + 1) & 1], fb[(q + 1) & 1]);
-                if (PF && q == NQ - 1 && !TUNE_ABLATE(2)) {   // stage the next chunk: stores spread over the last 4 steps
-#pragma unroll
-                    for (int t = 0; t < AI + (BDIR ? 0 : BI); ++t) {
-                        if ((t & 3) != s) continue;
-                        if (t < AI)
-                            *reinterpret_cast<f32x4*>(&Asn[(a_r + ARS * t) * LDA + a_kq * 4]) = ra[t];
-                        else
-                            *reinterpret_cast<f32x4*>(&Bsn[(tid + NT * (t - AI)) * 4]) = rb[t - AI];
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
-
-    TUNE_T(t_loop);
-    if constexpr (!SPLITK) {
-        const int last = p.nchunks - 1;
-        for (int c = 0; c < last; ++c) {
-            chunk(c, std::true_type{});
-            __syncthreads();
-        }
-        chunk(last, std::false_type{});
-        __syncthreads();
-    } else {
-        // ---- split-K pipeline: a slice is 2-12 chunks on a CU that holds one or two workgroups - nothing hides a load
-        // but distance.  Operands are fetched TWO chunks ahead (a chunk's MFMAs take ~0.4 us on a lone wave, the Infinity
-        // Cache / HBM answer in 0.7-1 us): two register sets alternate by chunk parity (the loop is unrolled by two so that
-        // the set is a compile-time index), A of chunk c+1 moves from registers into the other LDS stage during chunk c.
-        // Loads past the end of the slice get an out-of-range offset: they return 0 without touching memory.
-        f32x4 ra2[2][AI], fb2[2][NQ][TN];
-        auto sk_load_a = [&](int cl, auto slot) {
-            constexpr int SL = decltype(slot)::value;
-            const bool oob = cl >= p.nchunks;
-            const int c = cl + cbase;
-            const int tap = IS1X1 ? 0 : c / p.cpc;
-            const int c0 = IS1X1 ? c : c - tap * p.cpc;
-            unsigned tap_bytes = 0;
-            if (!IS1X1) {
-                const int ky = tap / p.KW, kx = tap - ky * p.KW;
-                tap_bytes = (unsigned)((ky * p.W + kx) * p.ldx * 4);
-            }
-            const bool second = DUAL && c >= p.cpc1;
-            const unsigned s_a = oob ? 0u : (unsigned)((second ? c0 - p.cpc1 : c0) * BK * 4);
-#pragma unroll
-            for (int i = 0; i < AI; ++i) {
-                unsigned voff = a_voff[i];
-                if (!IS1X1) voff = ((a_mask[i] >> (tap & 31)) & 1u) ? voff + tap_bytes : kOutOfRange;
-                if (DUAL) voff = second ? a_voff2[i] : voff;
-                if (oob) voff = kOutOfRange;
-                if (DUAL) {
-                    ra2[SL][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(second ? x2rs : xrs, voff, s_a, 0));
-                } else {
-                    ra2[SL][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, s_a, 0));
-                }
-            }
-        };
-        auto sk_load_b = [&](int cl, int q, auto slot) {
-            constexpr int SL = decltype(slot)::value;
-            const bool oob = cl >= p.nchunks;
-            const int ca = cl + cbase;
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                fb2[SL][q][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                    wrs, oob ? kOutOfRange : fb_voff + (unsigned)(j * 32 * 16), oob ? 0u : (unsigned)((ca * KQ + 2 * q) * p.Npad * 16), 0));
-        };
-        auto sk_chunk = [&](int c, auto par) {
-            constexpr int P = decltype(par)::value;   // == c & 1
-            const float* Ab = As + P * A_STAGE + (wm * (BM / WGM) + l31) * LDA + hh * 4;
-            float* Asn = As + (P ^ 1) * A_STAGE;
-            f32x4 fa[2][TM];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDA);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-#pragma unroll
-                for (int s_ = 0; s_ < 4; ++s_) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1][i][s_], fb2[P][q][j][s_], acc[i][j], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (s_ == 3) sk_load_b(c + 2, q, par);          // this set's next use is two chunks from now
-                    if (q == 0 && s_ == 0) sk_load_a(c + 2, par);   // (its previous content went to LDS during chunk c - 1)
-                    if (s_ == 1 && q < NQ - 1) {
-#pragma unroll
-                        for (int i = 0; i < TM; ++i) fa[(q + 1) & 1][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDA + (q + 1) * 8);
-                    }
-                    if (q == NQ - 1) {   // chunk c + 1: registers -> the other stage, spread over the last four steps
-#pragma unroll
-                        for (int t_ = 0; t_ < AI; ++t_)
-                            if ((t_ & 3) == s_) *reinterpret_cast<f32x4*>(&Asn[(a_r + ARS * t_) * LDA + a_kq * 4]) = ra2[P ^ 1][t_];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        };
-        const std::integral_constant<int, 0> even{};
-        const std::integral_constant<int, 1> odd{};
-        sk_load_a(0, even);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) sk_load_b(0, q, even);
-        sk_load_a(1, odd);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) sk_load_b(1, q, odd);
-#pragma unroll
-        for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(a_r + ARS * i) * LDA + a_kq * 4]) = ra2[0][i];
-        __syncthreads();
-        // canonical boundaries (file header): leaf chain -> group fold -> result fold, every fold from +0, left to right
-        f32x16 accG[TM][TN], accR[TM][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { accG[i][j][r] = 0.f; accR[i][j][r] = 0.f; }
-        int lc = 0, gl = 0;
-        auto leaf_end = [&]() {
-            if (++lc < p.sk_leaf) return;
-            lc = 0;
-            if (p.sk_unit == 1) return;          // the slab is the leaf itself
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { accG[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.f; }
-            if (++gl < p.sk_G) return;
-            gl = 0;
-            if (p.sk_unit == p.sk_G) return;     // the slab is the group
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { accR[i][j][r] += accG[i][j][r]; accG[i][j][r] = 0.f; }
-        };
-        // The loop body is a whole (even, odd) pair and an odd chunk count ends in a peeled tail: with the odd chunk under an
-        // `if` inside the loop the compiler's wait-count pass sees a path even -> even, assumes six fewer loads in flight and
-        // waits for vmcnt(3) instead of vmcnt(9) at the top of every even chunk - the two-chunk prefetch distance collapses to
-        // less than one.
-        int c = 0;
-        for (; c + 2 <= p.nchunks; c += 2) {
-            sk_chunk(c, even);
-            __syncthreads();
-            leaf_end();
-            sk_chunk(c + 1, odd);
-            __syncthreads();
-            leaf_end();
-        }
-        if (c < p.nchunks) {
-            sk_chunk(c, even);
-            __syncthreads();
-            leaf_end();
-        }
-        if (p.sk_unit != 1) {
-            const bool grp_level = p.sk_unit == p.sk_G;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = grp_level ? accG[i][j][r] : accR[i][j][r];
-        }
-    }
-    TUNE_T(t_epi);
-
-    // ---- epilogue -------------------------------------------------------------------------
-    // The accumulators go through LDS once so that the HBM side is whole-row traffic: the
-    // MFMA C/D layout (col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)) would give
-    // 4-byte stores at a row stride; after the transpose every lane moves 16 contiguous bytes.
-    // All waves have passed the barrier above, so the A/B stages are free to reuse.
-    float* Cs = smem;
-    float* const outp = pout;
-    if (SPLITK && gridDim.y > 1) {
-        // Partial tile -> workspace in accumulator order (16 bytes per lane, consecutive lanes consecutive: coalesced), then
-        // the arrival ticket.  Per-XCD L2s are not coherent with each other and a CU's L1 is never refreshed by another CU's
-        // stores, so the hand-off is the write-through form (MI355X_MICROARCH.md, inter-workgroup visibility): sc1 stores
-        // leave the XCD's L2 for memory, every wave drains its stores (vmcnt 0), ONE lane takes the ticket with a relaxed
-        // agent-scope atomic, and the last arriver reads all slabs with sc1 loads (no L1, fresh from the fabric) - no
-        // cache-wide write-back / invalidate (a __threadfence() per workgroup measured 35 us per launch here).
-        const unsigned S = gridDim.y;
-        const size_t tile = (size_t)blockIdx.z * gridDim.x + blockIdx.x;
-        constexpr unsigned SLAB = BM * BN * 4;   // bytes
-        constexpr int NQD = TM * TN * 4;          // 16-byte quads per lane
-        float* const tile_ws = p.sk_ws + tile * S * (size_t)(BM * BN);
-        const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(tile_ws, 0, S * SLAB, 0x00020000);
-        const unsigned soff = (unsigned)blockIdx.y * SLAB;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][r4 * 4 + e];
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srs,
-                                                           (unsigned)((((i * TN + j) * 4 + r4) * NT + tid) * 16), soff, /*sc1*/ 16);
-                }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slab stores have left for memory
-        __syncthreads();
-        int* const flag = reinterpret_cast<int*>(smem);     // (the one LDS array: the stages are free after the loop's last barrier)
-        if (tid == 0) {
-            const unsigned ticket = __hip_atomic_fetch_add(p.sk_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last_in = ticket == S - 1;
-            // every slice has arrived: the counter is free again for the next launch / graph replay
-            if (last_in) __hip_atomic_store(p.sk_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *flag = last_in;
-        }
-        __syncthreads();
-        if (!*flag) return;
-        __syncthreads();   // (the flag word is about to be overwritten by the transpose)
-        // the rest of the canonical tree, whichever slice arrived last: leaf slabs fold G at a time into groups and the
-        // groups into the result; group slabs fold into the result.  All slabs of a group (<= 4 x NQD loads) are in flight at once.
-        const unsigned gsz = p.sk_unit == 1 ? (unsigned)p.sk_G : 1u;
-        f32x4 tot[NQD];
-#pragma unroll
-        for (int u = 0; u < NQD; ++u)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) tot[u][e] = 0.f;
-        auto slab = [&](unsigned z, int u) {
-            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, (unsigned)((u * NT + tid) * 16), z * SLAB, 16));
-        };
-        if (gsz == 4) {
-            for (unsigned z = 0; z < S; z += 4) {
-                f32x4 v[4][NQD];
-#pragma unroll
-                for (int zz = 0; zz < 4; ++zz)
-#pragma unroll
-                    for (int u = 0; u < NQD; ++u) v[zz][u] = slab(z + zz, u);
-#pragma unroll
-                for (int u = 0; u < NQD; ++u)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float tg = 0.f;
-#pragma unroll
-                        for (int zz = 0; zz < 4; ++zz) tg += v[zz][u][e];
-                        tot[u][e] += tg;
-                    }
-            }
-        } else if (gsz > 1) {
-            for (unsigned z = 0; z < S; z += gsz) {
-                f32x4 tg[NQD];
-#pragma unroll
-                for (int u = 0; u < NQD; ++u)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) tg[u][e] = 0.f;
-                for (unsigned zz = 0; zz < gsz; ++zz) {
-                    f32x4 v[NQD];
-#pragma unroll
-                    for (int u = 0; u < NQD; ++u) v[u] = slab(z + zz, u);
-#pragma unroll
-                    for (int u = 0; u < NQD; ++u)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) tg[u][e] += v[u][e];
-                }
-#pragma unroll
-                for (int u = 0; u < NQD; ++u)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) tot[u][e] += tg[u][e];
-            }
-        } else {
-            unsigned z = 0;
-            for (; z + 4 <= S; z += 4) {
-                f32x4 v[4][NQD];
-#pragma unroll
-                for (int zz = 0; zz < 4; ++zz)
-#pragma unroll
-                    for (int u = 0; u < NQD; ++u) v[zz][u] = slab(z + zz, u);
-#pragma unroll
-                for (int zz = 0; zz < 4; ++zz)
-#pragma unroll
-                    for (int u = 0; u < NQD; ++u)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) tot[u][e] += v[zz][u][e];
-            }
-            for (; z < S; ++z) {
-                f32x4 v[NQD];
-#pragma unroll
-                for (int u = 0; u < NQD; ++u) v[u] = slab(z, u);
-#pragma unroll
-                for (int u = 0; u < NQD; ++u)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) tot[u][e] += v[u][e];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[i][j][r4 * 4 + e] = tot[(i * TN + j) * 4 + r4][e];
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * (BM / WGM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                Cs[row * LDC + wn * (BN / WGN) + j * 32 + l31] = acc[i][j][r];
-            }
-    __syncthreads();
-
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(pscale + n);
-    const f32x4 sh = *reinterpret_cast<const f32x4*>(pshift + n);
-    if (full) {
-        // the residual rows were fetched under the last chunk's MFMAs (rr)
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps) {
-            const int row = r0 + ps * RPP;
-            const int m = m0 + row;
-            const f32x4 a = *reinterpret_cast<const f32x4*>(Cs + row * LDC + cq * 4);
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaf(a[e], sc[e], sh[e]);
-            if (pres) {
-                if (SPLITK) rr[ps] = *reinterpret_cast<const f32x4*>(pres + ((m < p.M) ? (size_t)m * p.ldo + n : (size_t)n));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += rr[ps][e];
-            }
-            if (p.relu) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-            if (m < p.M && !TUNE_ABLATE(4)) *reinterpret_cast<f32x4*>(outp + (size_t)m * p.ldo + n) = v;
-        }
-    } else {
-        for (int ps = 0; ps < NP; ++ps) {
-            const int row = r0 + ps * RPP;
-            const int m = m0 + row;
-            if (m >= p.M) break;
-            const size_t o = (size_t)m * p.ldo + n;
-            for (int e = 0; e < 4; ++e) {
-                if (n + e < p.Cout) {
-                    float t = fmaf(Cs[row * LDC + cq * 4 + e], sc[e], sh[e]);
-                    if (pres) t += pres[o + e];
-                    if (p.relu) t = fmaxf(t, 0.f);
-                    outp[o + e] = t;
-                }
-            }
-        }
-    }
-#ifdef SPECMI_TUNE
-    if (p.tprof && (tid & 63) == 0) {
-        const long long t_end = __builtin_amdgcn_s_memtime();
-        atomicAdd(p.tprof + 0, (unsigned long long)tp[0]);
-        atomicAdd(p.tprof + 1, (unsigned long long)tp[1]);
-        atomicAdd(p.tprof + 2, (unsigned long long)tp[2]);
-        atomicAdd(p.tprof + 3, (unsigned long long)tp[3]);
-        atomicAdd(p.tprof + 4, (unsigned long long)(t_loop - t_start));
-        atomicAdd(p.tprof + 5, (unsigned long long)(t_epi - t_loop));
-        atomicAdd(p.tprof + 6, (unsigned long long)(t_end - t_epi));
-        atomicAdd(p.tprof + 7, 1ull);
-    }
-#endif
+    constexpr bool PERSIST = false;
+    TileCtx t;
+    t.bid = blockIdx.x; t.nblk = gridDim.x;
+    t.y = blockIdx.y; t.S = gridDim.y;
+    t.z = blockIdx.z;
+    t.ws = p.sk_ws; t.cnt = p.sk_cnt;
+    t.tile = blockIdx.z * gridDim.x + blockIdx.x;
+#include "conv_igemm_body.inc"
 }
 
 template <int BM, int BN, int WGM, int WGN, bool IS1X1, int BK = 32, bool DUAL = false, bool SPLITK = false, bool BDIR = false>
@@ -919,16 +273,10 @@ size_t conv_igemm_sk_ws_floats(const ConvArgs& a, int S, int groups) {
 }
 int conv_igemm_sk_tiles(const ConvArgs& a, int groups) { return ((a.B * a.OH * a.OW + 63) / 64) * (a.Npad / 64) * groups; }
 
-// One launch, gridDim.y = pl.leaves / pl.unit slabs per tile; sk.ws holds conv_igemm_sk_ws_floats(a, slabs, groups) floats,
-// sk.cnt one zeroed counter per (tile, group) - the kernel leaves them zeroed
-int launch_conv_igemm_sk(const ConvArgs& a, const SkPlan& pl, const SkWs& sk, const LaunchCtx& ctx, const ConvArgs* b) {
+int conv_igemm_sk_check(const ConvArgs& a, const SkPlan& pl, const ConvArgs* b) {
     const int nch = a.KH * a.KW * (a.Cin / 32) + (a.x2 ? a.Cin2 / 32 : 0);
-    const int groups = b ? 2 : 1;
     if (pl.leaves < 1 || nch % pl.leaves != 0 || pl.G < 1 || pl.leaves % pl.G != 0 || (pl.unit != 1 && pl.unit != pl.G && pl.unit != pl.leaves) ||
         a.Cin % 32 != 0 || a.Npad % 64 != 0 || a.ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(a.x) & 15))
-        return (int)hipErrorInvalidValue;
-    const int S = pl.leaves / pl.unit;
-    if (S > 1 && (!sk.ws || !sk.cnt || conv_igemm_sk_ws_floats(a, S, groups) > sk.floats || conv_igemm_sk_tiles(a, groups) > sk.ncnt))
         return (int)hipErrorInvalidValue;
     if (a.x2 && (a.KH != 1 || a.KW != 1 || a.pad != 0 || a.Cin2 % 32 != 0 || a.ldx2 % 4 != 0 || (reinterpret_cast<uintptr_t>(a.x2) & 15)))
         return (int)hipErrorInvalidValue;
@@ -942,9 +290,31 @@ int launch_conv_igemm_sk(const ConvArgs& a, const SkPlan& pl, const SkWs& sk, co
     if (a.x2 && (size_t)a.H2 * a.W2 * a.ldx2 * 4 > img_bytes) img_bytes = (size_t)a.H2 * a.W2 * a.ldx2 * 4;
     const size_t limit = (size_t)1 << 31;
     if (img_bytes * a.B >= limit || (size_t)nch * 32 * a.Npad * 4 >= limit) return (int)hipErrorInvalidValue;   // small-M path: no batch splitting
+    return 0;
+}
+
+void conv_igemm_make_sk_kargs(const ConvArgs& a, const SkPlan& pl, const ConvArgs* b, KArgs& k) {
+    const int nch = a.KH * a.KW * (a.Cin / 32) + (a.x2 ? a.Cin2 / 32 : 0);
+    double flops, bytes;
+    make_kargs(a, b, k, &flops, &bytes);
+    k.sk_leaf = nch / pl.leaves; k.sk_G = pl.G; k.sk_unit = pl.unit;
+    k.nchunks = k.sk_leaf * pl.unit;
+    k.nbn = a.Npad / 64;
+    k.xcd_cols = 0;
+}
+
+// One launch, gridDim.y = pl.leaves / pl.unit slabs per tile; sk.ws holds conv_igemm_sk_ws_floats(a, slabs, groups) floats,
+// sk.cnt one zeroed counter per (tile, group) - the kernel leaves them zeroed
+int launch_conv_igemm_sk(const ConvArgs& a, const SkPlan& pl, const SkWs& sk, const LaunchCtx& ctx, const ConvArgs* b) {
+    const int groups = b ? 2 : 1;
+    if (int rc = conv_igemm_sk_check(a, pl, b)) return rc;
+    const int S = pl.leaves / pl.unit;
+    if (S > 1 && (!sk.ws || !sk.cnt || conv_igemm_sk_ws_floats(a, S, groups) > sk.floats || conv_igemm_sk_tiles(a, groups) > sk.ncnt))
+        return (int)hipErrorInvalidValue;
     KArgs k;
     double flops, bytes;
     make_kargs(a, b, k, &flops, &bytes);
+    const int nch = a.KH * a.KW * (a.Cin / 32) + (a.x2 ? a.Cin2 / 32 : 0);
     k.sk_leaf = nch / pl.leaves; k.sk_G = pl.G; k.sk_unit = pl.unit;
     k.nchunks = k.sk_leaf * pl.unit;
     k.sk_ws = sk.ws; k.sk_cnt = sk.cnt;

@@ -91,6 +91,12 @@ struct specmi_handle {
     SkWs sk;                            // split-K partial tiles + arrival counters (ensure_sk; never allocated under graph capture:
                                         // the warm-up call of a shape sizes it)
     std::vector<void*> sk_retired;      // outgrown split-K buffers, kept until destroy (captured graphs may still name them)
+    // persistent multi-layer launches (conv_persist.hip): device tables keyed by their host image (a table names workspace
+    // buffers, weights and shapes - everything but the caller's feature buffer, which travels as a launch argument - so equal
+    // images mean the cached device copy is still right; captured graphs keep naming superseded tables: never freed before destroy)
+    struct PersistTable { std::vector<unsigned char> img; void* dev = nullptr; int nl = 0; };
+    std::vector<PersistTable> persist_tables;
+    PersistCtl* pctl = nullptr;         // device control block of this handle's persistent launches (one launch at a time per handle)
 
     Profiler prof;
 };

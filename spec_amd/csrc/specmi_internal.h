@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <map>
 #include <string>
 #include <vector>
@@ -122,6 +123,28 @@ int conv_igemm_sk_tiles(const ConvArgs& a, int groups);
 int launch_conv_igemm_sk(const ConvArgs& a, const SkPlan& pl, const SkWs& sk, const LaunchCtx& ctx, const ConvArgs* b = nullptr);
 // pick the tile the launcher would use (for tests / labels)
 const char* conv_igemm_variant(const ConvArgs& a);
+
+// ----------------------------------------------------------------------------------------
+// a run of consecutive sliced convolutions as ONE persistent launch  (conv_persist.hip)
+// ----------------------------------------------------------------------------------------
+constexpr int kPersistMaxLayers = 64;
+struct PersistCtl {                            // device; zero between launches (the kernel leaves it so)
+    unsigned done[2 * kPersistMaxLayers];      // finished tiles of (layer, network)
+    unsigned exit;                             // workgroups that have left
+    unsigned err;                              // != 0: a bounded spin gave up (protocol error; results of that launch are garbage)
+};
+struct PersistLayerHost {
+    ConvArgs a, b;       // the fused convolution of network 0 / network 1 (pair)
+    bool pair = false;
+    SkPlan pl;           // canonical tree + unit (leaves = 1: unsliced)
+    int out_arg = 0;     // 1: the output pointer comes with the launch (caller-owned feature buffer), not from the table
+};
+size_t persist_table_bytes(int nl);
+// img == nullptr: only sizes what sk must hold.  Otherwise writes the table (host image, persist_table_bytes(nl)) for a grid of nwg
+int persist_fill_table(const PersistLayerHost* layers, int nl, const SkWs& sk, int nwg, int l2_prefetch, void* img,
+                       size_t* ws_floats_needed, int* cnt_needed);
+int launch_persist(const void* dev_table, int nl, PersistCtl* ctl, float* out0, float* out1, int nwg, unsigned spin_limit,
+                   const LaunchCtx& ctx, double flops, double bytes);
 
 // ----------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution as Winograd F(2x2,3x3) on fp32 MFMA  (conv_wino.hip)

@@ -64,6 +64,18 @@ class Engine:
         else:
             _lib.check(self.h, self.lib.specmi_set_option_i32(self.h, name.encode(), int(value)))
 
+    def sync_status(self) -> int:
+        """Synchronises; 0 = every in-launch hand-off of this handle's persistent launches completed (include/specmi.h)."""
+        err = C.c_int32(0)
+        _lib.check(self.h, self.lib.specmi_sync_status(self.h, C.byref(err)))
+        return int(err.value)
+
+    def sync_reset(self):
+        _lib.check(self.h, self.lib.specmi_sync_reset(self.h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def debug_poison_sync(self, value: int = 0xDEADBEEF):
+        _lib.check(self.h, self.lib.specmi_debug_poison_sync(self.h, C.c_uint32(value)))
+
     def set_tensor(self, name: str, value):
         if isinstance(value, torch.Tensor):
             value = value.detach().cpu().numpy()
