@@ -892,7 +892,8 @@ static int persist_run(specmi_handle* h, const std::vector<OpLaunch>& La, const 
         }
     }
     LaunchCtx ctx{s, &h->prof, ops[i0].label.c_str()};
-    LAUNCHCHK(h, launch_persist(tab->dev, nl, h->pctl, out0, out1, nwg, (unsigned)opt_i(h, "persist_spin_limit", 400000), ctx, 0.0, 0.0),
+    LAUNCHCHK(h, launch_persist(tab->dev, nl, h->pctl, out0, out1, nwg, (unsigned)opt_i(h, "persist_spin_limit", 400000), ctx, 0.0, 0.0,
+                                opt_i(h, "persist_allow_full", 0) != 0),
               "persistent trunk run");
     return SPECMI_OK;
 }

@@ -155,7 +155,7 @@ int persist_fill_table(const PersistLayerHost* layers, int nl, const SkWs& sk, i
 }
 
 int launch_persist(const void* dev_table, int nl, PersistCtl* ctl, float* out0, float* out1, int nwg, unsigned spin_limit,
-                   const LaunchCtx& ctx, double flops, double bytes) {
+                   const LaunchCtx& ctx, double flops, double bytes, bool allow_full) {
     constexpr size_t ab = (size_t)(2 * 64 * 36) * sizeof(float);
     constexpr size_t cb = (size_t)64 * 68 * sizeof(float);
     constexpr size_t smem = ab > cb ? ab : cb;
@@ -175,7 +175,8 @@ int launch_persist(const void* dev_table, int nl, PersistCtl* ctl, float* out0, 
         max_wgs[dev] = per_cu * prop.multiProcessorCount;
     }
     // two such launches may run side by side (two handles on two streams): each takes at most half of the slots
-    if (nwg > max_wgs[dev] / 2) return (int)hipErrorLaunchOutOfResources;
+    // (allow_full: experiments with the whole chip's slots - the caller guarantees that nothing else persistent is in flight)
+    if (nwg > (allow_full ? max_wgs[dev] : max_wgs[dev] / 2)) return (int)hipErrorLaunchOutOfResources;
     ProfScope ps(ctx, "conv_persist_f32<64x64,2x2>", flops, bytes);
     hipLaunchKernelGGL(conv_persist_kernel, dim3(nwg), dim3(256), smem, ctx.stream, static_cast<const PLayer*>(dev_table), nl, ctl,
                        out0, out1, spin_limit);

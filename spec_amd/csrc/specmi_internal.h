@@ -144,7 +144,7 @@ size_t persist_table_bytes(int nl);
 int persist_fill_table(const PersistLayerHost* layers, int nl, const SkWs& sk, int nwg, int l2_prefetch, void* img,
                        size_t* ws_floats_needed, int* cnt_needed);
 int launch_persist(const void* dev_table, int nl, PersistCtl* ctl, float* out0, float* out1, int nwg, unsigned spin_limit,
-                   const LaunchCtx& ctx, double flops, double bytes);
+                   const LaunchCtx& ctx, double flops, double bytes, bool allow_full = false);
 
 // ----------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution as Winograd F(2x2,3x3) on fp32 MFMA  (conv_wino.hip)
