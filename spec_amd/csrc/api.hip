@@ -736,6 +736,22 @@ static int launch_op(specmi_handle* h, const TrunkOp& op, const OpLaunch& L, con
                                        opt_i(h, "latency_fill_wgs", 240));
         const int fu = opt_i(h, "latency_force_unit", 0);   // tests: 1 leaf / 2 group / 3 whole K per workgroup, whatever the batch
         if (fu) pl.unit = fu == 1 ? 1 : (fu == 2 ? pl.G : pl.leaves);
+        // The wave-split unit (conv_wsplit.hip, round 5): a 32x32 tile per workgroup, the G leaves of a group on its waves side by
+        // side - four times the tiles, slabs of 4 KB per GROUP or none.  Same canonical tree, same bits.  "wsplit": 0 never,
+        // 1 (default) by the rule below, 2 / 3 always with one group / all groups per workgroup (tests, per-layer tables).
+        const int wsplit = opt_i(h, "wsplit", 1);
+        if (wsplit && !fu) {
+            SkPlan pw = pl;
+            const int t32 = conv_wsplit_tiles(L.a, groups);
+            // all groups in one workgroup (no slab) as soon as the 32x32 tiles alone fill the chip
+            pw.unit = (wsplit == 3 || (wsplit == 1 && t32 >= opt_i(h, "wsplit_fill_wgs", 200))) ? pl.leaves : pl.G;
+            const long rows = (long)L.a.B * L.a.OH * L.a.OW;
+            if (conv_wsplit_supported(L.a, pw) && (wsplit > 1 || rows <= (long)opt_i(h, "wsplit_max_rows", 4096))) {
+                if ((rc = ensure_sk(h, conv_wsplit_ws_floats(L.a, pw.leaves / pw.unit, groups), conv_wsplit_tiles(L.a, groups)))) return rc;
+                LAUNCHCHK(h, launch_conv_wsplit(L.a, pw, h->sk, ctx, partner ? &partner->a : nullptr), op.label.c_str());
+                return SPECMI_OK;
+            }
+        }
         if ((rc = ensure_sk(h, conv_igemm_sk_ws_floats(L.a, pl.leaves / pl.unit, groups), conv_igemm_sk_tiles(L.a, groups)))) return rc;
         LAUNCHCHK(h, launch_conv_igemm_sk(L.a, pl, h->sk, ctx, partner ? &partner->a : nullptr), op.label.c_str());
         return SPECMI_OK;
@@ -924,7 +940,7 @@ static int launch_ops(specmi_handle* ha, specmi_handle* hb, const TrunkPlan& Pa,
                         i, oa.label.c_str());
     }
     // (the built-in launch profiler wants one record per layer: it sees the per-layer launches)
-    const bool persist = mode != 0 && opt_i(ha, "persist", 1) && !ha->prof.on;
+    const bool persist = mode != 0 && opt_i(ha, "persist", 0) && !ha->prof.on;   // opt-in: measured slower than the per-layer launches (profiles/r05_a_*)
     const size_t min_run = (size_t)opt_i(ha, "persist_min_run", 2);
     auto eligible = [&](size_t i) { return La[i].kind == 2 && La[i].family == 0 && !La[i].a.force_variant; };
     int rc;

@@ -121,6 +121,12 @@ SkPlan conv_igemm_sk_plan(const ConvArgs& a, int groups, int target_wgs, int min
 size_t conv_igemm_sk_ws_floats(const ConvArgs& a, int slabs, int groups);
 int conv_igemm_sk_tiles(const ConvArgs& a, int groups);
 int launch_conv_igemm_sk(const ConvArgs& a, const SkPlan& pl, const SkWs& sk, const LaunchCtx& ctx, const ConvArgs* b = nullptr);
+// the wave-split unit of the same tree (conv_wsplit.hip): a 32x32 tile per workgroup, the leaves of a group on its four waves;
+// pl.unit = pl.leaves (no slabs) or pl.G (one group per workgroup, a 4 KB slab per group)
+bool conv_wsplit_supported(const ConvArgs& a, const SkPlan& pl);
+int conv_wsplit_tiles(const ConvArgs& a, int groups);
+size_t conv_wsplit_ws_floats(const ConvArgs& a, int slabs, int groups);
+int launch_conv_wsplit(const ConvArgs& a, const SkPlan& pl, const SkWs& sk, const LaunchCtx& ctx, const ConvArgs* b = nullptr);
 // pick the tile the launcher would use (for tests / labels)
 const char* conv_igemm_variant(const ConvArgs& a);
 
