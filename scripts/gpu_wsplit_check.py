@@ -61,27 +61,30 @@ def main():
         for b in [int(v) for v in args.batches.split(',')]:
             xb = x[:b].contiguous()
             res = {}
-            for ws in (0, 1, 2, 3):
-                opt('wsplit', ws)
+            CFG = {'k64': (0, -1), 'auto': (1, -1), 'group': (2, 0), 'all': (3, 0), 'group_ldsA': (2, 1), 'all_ldsA': (3, 1)}
+            for tag, (ws, alds) in CFG.items():
+                opt('wsplit', ws); opt('wsplit_alds', alds)
                 fa, fb = ce.trunk_pair(he, xb, xb)
                 f1 = ce.trunk(xb)
                 out = SpecPipeline(cc, hm, grouped=True)(xb, sc[:b].contiguous(), cen[:b].contiguous(), iw[:b].contiguous(), ih[:b].contiguous())
                 torch.cuda.synchronize()
-                res[ws] = (fa.clone(), fb.clone(), f1.clone(), out['smpl_vertices'].clone(), out['smpl_joints2d'].clone())
+                res[tag] = (fa.clone(), fb.clone(), f1.clone(), out['smpl_vertices'].clone(), out['smpl_joints2d'].clone())
             names = ('pair_cam', 'pair_spec', 'single_cam', 'vertices', 'joints2d')
             row = {'test': 'bit_equal', 'plan': plan, 'batch': b}
             good = True
-            for ws in (1, 2, 3):
-                eq = {n: bool(torch.equal(a, c)) for n, a, c in zip(names, res[0], res[ws])}
-                md = max(float((a - c).abs().max()) for a, c in zip(res[0], res[ws]))
-                row[f'wsplit{ws}'] = {'equal': all(eq.values()), 'maxdiff': md, 'which': [n for n, e in eq.items() if not e]}
+            for tag in CFG:
+                if tag == 'k64':
+                    continue
+                eq = {n: bool(torch.equal(a, c)) for n, a, c in zip(names, res['k64'], res[tag])}
+                md = max(float((a - c).abs().max()) for a, c in zip(res['k64'], res[tag]))
+                row[tag] = {'equal': all(eq.values()), 'maxdiff': md, 'which': [n for n, e in eq.items() if not e]}
                 good &= all(eq.values())
-            good &= bool(all(torch.isfinite(v).all() for v in res[1]))
+            good &= bool(all(torch.isfinite(v).all() for v in res['auto']))
             row['ok'] = good
             ok_all &= good
             emit(**row)
     emit(test='summary_correctness', ok=bool(ok_all))
-    opt('wsplit', 1)
+    opt('wsplit', 1); opt('wsplit_alds', -1)
 
     def time_step(pp, b, iters=200):
         g = GraphedPipeline(pp, x[:b].contiguous(), sc[:b].contiguous(), cen[:b].contiguous(), iw[:b].contiguous(), ih[:b].contiguous())
@@ -105,16 +108,17 @@ def main():
         row = {'test': 'timing', 'batch': b}
         for plan in (('single', 'latency') if b <= 4 else ('latency',)):
             cc.set_plan(plan); hm.set_plan(plan)
-            for ws in (0, 1, 2, 3):
-                opt('wsplit', ws)
-                row[f'{plan}_ws{ws}_grouped'] = time_step(SpecPipeline(cc, hm, grouped=True), b)
-                row[f'{plan}_ws{ws}_2streams'] = time_step(SpecPipeline(cc, hm, overlap=True, grouped=False), b)
-        opt('wsplit', 1)
+            for tag, (ws, alds) in {'k64': (0, -1), 'auto': (1, -1), 'group': (2, 0), 'all': (3, 0), 'group_ldsA': (2, 1), 'all_ldsA': (3, 1)}.items():
+                opt('wsplit', ws); opt('wsplit_alds', alds)
+                row[f'{plan}_{tag}_grouped'] = time_step(SpecPipeline(cc, hm, grouped=True), b)
+                row[f'{plan}_{tag}_2streams'] = time_step(SpecPipeline(cc, hm, overlap=True, grouped=False), b)
+        opt('wsplit', 1); opt('wsplit_alds', -1)
         emit(**row)
 
     if not args.skip_layers:
         pipe = SpecPipeline(cc, hm, overlap=False, grouped=True)
-        CONFIGS = [('k64', {'wsplit': 0}), ('ws_group', {'wsplit': 2}), ('ws_all', {'wsplit': 3}), ('ws_auto', {'wsplit': 1})]
+        CONFIGS = [('k64', {'wsplit': 0}), ('ws_group', {'wsplit': 2, 'wsplit_alds': 0}), ('ws_all', {'wsplit': 3, 'wsplit_alds': 0}),
+                   ('wsA_group', {'wsplit': 2, 'wsplit_alds': 1}), ('wsA_all', {'wsplit': 3, 'wsplit_alds': 1}), ('ws_auto', {'wsplit': 1, 'wsplit_alds': -1})]
         with open(os.path.join(outdir, 'wsplit_layers.txt'), 'a') as fl:
             for plan in ('single', 'latency'):
                 cc.set_plan(plan); hm.set_plan(plan)
@@ -153,7 +157,7 @@ def main():
                         lines.append(f'{lab:28s}' + ''.join(f'{r.get(k, float("nan")):10.1f}' for k, _ in CONFIGS) + f'   {best[1]}')
                     print('\n'.join(lines), flush=True)
                     fl.write('\n'.join(lines) + '\n'); fl.flush()
-        opt('wsplit', 1)
+        opt('wsplit', 1); opt('wsplit_alds', -1)
     cc.set_plan('auto'); hm.set_plan('auto')
     emit(test='done')
 

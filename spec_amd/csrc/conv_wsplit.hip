@@ -28,10 +28,17 @@
 
 namespace specmi {
 
-template <bool IS1X1, bool DUAL>
-__global__ void __launch_bounds__(256, 4) conv_wsplit_f32_kernel(const KArgs p) {
+// ALDS = false: A fragments straight from L2 (lane (row, h) reads its own 16 bytes: 32 rows x 32 bytes per instruction - 32 cache
+//   lines touched for 1 KB; fine while a CU holds one workgroup, the batch 1-2 regime);
+// ALDS = true:  A as whole 128-byte row segments (8 lanes per row, 8 rows per instruction - 8 full lines) into registers two chunks
+//   ahead, transposed through a PRIVATE per-wave LDS stage (2 x 32 x 36 floats, the 64x64 kernel's layout) - still no workgroup
+//   barrier in the K loop (a wave's LDS operations execute in order); what 3-4 co-resident workgroups per CU need (batch >= 4:
+//   the scattered form saturates the vector L1's tag rate, measured at half the matrix pipe).
+template <bool IS1X1, bool DUAL, bool ALDS>
+__global__ void __launch_bounds__(256, ALDS ? 3 : 4) conv_wsplit_f32_kernel(const KArgs p) {
     static_assert(!DUAL || IS1X1, "the second A source exists for 1x1 layers only");
     __shared__ __attribute__((aligned(16))) float lds[4 * 1024];   // one 32x32 leaf tile per wave, [reg][lane]
+    __shared__ __attribute__((aligned(16))) float lds_a[ALDS ? 4 * 2 * 32 * 36 : 4];   // ALDS: [wave][stage][row][32 k + 4 pad]
     __shared__ int flag;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -57,26 +64,31 @@ __global__ void __launch_bounds__(256, 4) conv_wsplit_f32_kernel(const KArgs p) 
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pw), 0, p.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t x2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DUAL ? px2 : px), 0, DUAL ? p.x2_bytes : p.x_bytes, 0x00020000);
 
-    // ---- this lane's A row: byte offset of (tap (0,0) pixel, channel 4 * hh) -----------------------------------------------
-    unsigned a_voff, a_voff2 = 0, a_mask = 0;
-    {
-        const int m = m0 + l31;
+    // ---- this lane's A rows: byte offset of (tap (0,0) pixel, this lane's 16-byte quad).  Direct form: ONE row (l31), quad = the
+    // lane half's 4 k's of sub-chunk 0; ALDS: FOUR rows (lane / 8 + 8 i), quad lane % 8 of the chunk's 32 k's ----------------------
+    constexpr int NA = ALDS ? 4 : 1;
+    unsigned a_voff[NA], a_voff2[NA], a_mask[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int m = m0 + (ALDS ? (lane >> 3) + 8 * i : l31);
+        const int qb = (ALDS ? (lane & 7) : hh) * 16;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
+        a_voff2[i] = 0; a_mask[i] = 0;
         if (DUAL) {
             if (p.stride2 == 1) {
-                a_voff2 = ok ? (unsigned)(mm * p.ldx2 * 4 + hh * 16) : kOutOfRange;
+                a_voff2[i] = ok ? (unsigned)(mm * p.ldx2 * 4 + qb) : kOutOfRange;
             } else {
                 const int b2 = p.OHW == 1 ? mm : (int)(__umulhi((unsigned)mm, p.mg_ohw) >> p.sh_ohw);
                 const int rem2 = mm - b2 * p.OHW;
                 const int oy2 = p.OW == 1 ? rem2 : (int)(__umulhi((unsigned)rem2, p.mg_ow) >> p.sh_ow);
                 const int ox2 = rem2 - oy2 * p.OW;
                 const int pix2 = (b2 * p.H2 + oy2 * p.stride2) * p.W2 + ox2 * p.stride2;
-                a_voff2 = ok ? (unsigned)(pix2 * p.ldx2 * 4 + hh * 16) : kOutOfRange;
+                a_voff2[i] = ok ? (unsigned)(pix2 * p.ldx2 * 4 + qb) : kOutOfRange;
             }
         }
         if (IS1X1 && p.stride == 1) {
-            a_voff = ok ? (unsigned)(mm * p.ldx * 4 + hh * 16) : kOutOfRange;
+            a_voff[i] = ok ? (unsigned)(mm * p.ldx * 4 + qb) : kOutOfRange;
         } else {
             const int b = p.OHW == 1 ? mm : (int)(__umulhi((unsigned)mm, p.mg_ohw) >> p.sh_ohw);
             const int rem = mm - b * p.OHW;
@@ -84,16 +96,16 @@ __global__ void __launch_bounds__(256, 4) conv_wsplit_f32_kernel(const KArgs p) 
             const int ox = rem - oy * p.OW;
             const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
             const int pix0 = (b * p.H + iy0) * p.W + ix0;
-            const unsigned off = (unsigned)(pix0 * p.ldx * 4 + hh * 16);   // wraps for padded rows; only used on valid taps
+            const unsigned off = (unsigned)(pix0 * p.ldx * 4 + qb);   // wraps for padded rows; only used on valid taps
             if (IS1X1) {
-                a_voff = ok ? off : kOutOfRange;
+                a_voff[i] = ok ? off : kOutOfRange;
             } else {
-                a_voff = off;
+                a_voff[i] = off;
                 unsigned colbits = 0, mk = 0;
                 for (int kx = 0; kx < p.KW; ++kx) colbits |= ((unsigned)(ix0 + kx) < (unsigned)p.W ? 1u : 0u) << kx;
                 for (int ky = 0; ky < p.KH; ++ky)
                     if ((unsigned)(iy0 + ky) < (unsigned)p.H) mk |= colbits << (ky * p.KW);
-                a_mask = ok ? mk : 0u;
+                a_mask[i] = ok ? mk : 0u;
             }
         }
     }
@@ -107,29 +119,62 @@ __global__ void __launch_bounds__(256, 4) conv_wsplit_f32_kernel(const KArgs p) 
     const int g0 = (int)blockIdx.y * ngroups_wg;
     const int total = ngroups_wg * L;
     const bool active = wave < G;                  // (a group of 2 or 3 leaves leaves waves idle)
-    f32x4 fa[2][4], fb[2][4];
-    auto load_chunk_q = [&](int v, int q, auto slot) {
-        constexpr int SL = decltype(slot)::value;
-        const bool oob = v >= total;
+    f32x4 fa[2][4], fb[2][4];   // fa: direct form: A fragments [set][q]; ALDS: the raw row quads [set][row i] on their way to LDS
+    struct ChunkAddr { bool oob, second; unsigned s_a, tap_bytes, s_b; int tap; };
+    auto chunk_addr = [&](int v) {
+        ChunkAddr a;
+        a.oob = v >= total;
         const int gi = v / L;                      // (scalar)
         const int c = ((g0 + gi) * G + wave) * L + (v - gi * L);
-        const int tap = IS1X1 ? 0 : c / p.cpc;
-        const int c0 = IS1X1 ? c : c - tap * p.cpc;
-        unsigned tap_bytes = 0;
+        a.tap = IS1X1 ? 0 : c / p.cpc;
+        const int c0 = IS1X1 ? c : c - a.tap * p.cpc;
+        a.tap_bytes = 0;
         if (!IS1X1) {
-            const int ky = tap / p.KW, kx = tap - ky * p.KW;
-            tap_bytes = (unsigned)((ky * p.W + kx) * p.ldx * 4);
+            const int ky = a.tap / p.KW, kx = a.tap - ky * p.KW;
+            a.tap_bytes = (unsigned)((ky * p.W + kx) * p.ldx * 4);
         }
-        const bool second = DUAL && c >= p.cpc1;
-        const unsigned s_a = oob ? 0u : (unsigned)((second ? c0 - p.cpc1 : c0) * 128 + q * 32);
-        unsigned voff = a_voff;
-        if (!IS1X1) voff = ((a_mask >> (tap & 31)) & 1u) ? voff + tap_bytes : kOutOfRange;
-        if (DUAL) voff = second ? a_voff2 : voff;
-        if (oob) voff = kOutOfRange;
-        if (DUAL) fa[SL][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(second ? x2rs : xrs, voff, s_a, 0));
-        else      fa[SL][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, s_a, 0));
-        fb[SL][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-            wrs, oob ? kOutOfRange : b_voff, oob ? 0u : (unsigned)((c * 8 + 2 * q) * p.Npad * 16), 0));
+        a.second = DUAL && c >= p.cpc1;
+        a.s_a = a.oob ? 0u : (unsigned)((a.second ? c0 - p.cpc1 : c0) * 128);
+        a.s_b = a.oob ? 0u : (unsigned)(c * 8 * p.Npad * 16);
+        return a;
+    };
+    auto load_a_one = [&](const ChunkAddr& ca, int i, unsigned extra) {
+        unsigned voff = a_voff[i];
+        if (!IS1X1) voff = ((a_mask[i] >> (ca.tap & 31)) & 1u) ? voff + ca.tap_bytes : kOutOfRange;
+        if (DUAL) voff = ca.second ? a_voff2[i] : voff;
+        if (ca.oob) voff = kOutOfRange;
+        if (DUAL) return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ca.second ? x2rs : xrs, voff, ca.s_a + extra, 0));
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, ca.s_a + extra, 0));
+    };
+    auto load_b_one = [&](const ChunkAddr& ca, int q) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            wrs, ca.oob ? kOutOfRange : b_voff, ca.oob ? 0u : ca.s_b + (unsigned)(2 * q * p.Npad * 16), 0));
+    };
+    // direct form: A and B fragments of sub-chunk q of virtual chunk v into set SL
+    auto load_chunk_q = [&](int v, int q, auto slot) {
+        constexpr int SL = decltype(slot)::value;
+        const ChunkAddr ca = chunk_addr(v);
+        if (!ALDS) fa[SL][q] = load_a_one(ca, 0, (unsigned)(q * 32));
+        fb[SL][q] = load_b_one(ca, q);
+    };
+    // ALDS: the four row quads of virtual chunk v into set SL
+    auto load_rows = [&](int v, auto slot) {
+        constexpr int SL = decltype(slot)::value;
+        const ChunkAddr ca = chunk_addr(v);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) fa[SL][i] = load_a_one(ca, i, 0u);
+    };
+    float* const stage = lds_a + (ALDS ? wave * (2 * 32 * 36) : 0);
+    auto stage_rows = [&](auto slot, int which) {   // set SL -> LDS stage `which` (row-major, 36-float rows)
+        constexpr int SL = decltype(slot)::value;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            *reinterpret_cast<f32x4*>(&stage[which * (32 * 36) + ((lane >> 3) + 8 * i) * 36 + (lane & 7) * 4]) = fa[SL][i];
+    };
+    auto wave_lds_fence = [&]() {   // a wave's LDS operations execute in order: only the COMPILER must not reorder across this point
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
 
     f32x16 acc;
@@ -137,14 +182,37 @@ __global__ void __launch_bounds__(256, 4) conv_wsplit_f32_kernel(const KArgs p) 
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     auto chunk = [&](int v, auto par) {
         constexpr int P = decltype(par)::value;
+        if constexpr (!ALDS) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < 4; ++q) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[P][q][s], fb[P][q][s], acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            load_chunk_q(v + 2, q, par);   // this set's next use is two chunks from now
-            __builtin_amdgcn_sched_barrier(0);
+                for (int s = 0; s < 4; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[P][q][s], fb[P][q][s], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                load_chunk_q(v + 2, q, par);   // this set's next use is two chunks from now
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            // stage P holds chunk v (written during chunk v - 1 / the prologue); set P^1 holds chunk v + 1's rows
+            const float* const st = stage + P * (32 * 36) + l31 * 36 + hh * 4;
+            f32x4 fq[2];
+            fq[0] = *reinterpret_cast<const f32x4*>(st);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fq[q & 1][s], fb[P][q][s], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                fb[P][q] = load_b_one(chunk_addr(v + 2), q);
+                if (q == 0) load_rows(v + 2, par);      // (set P's rows went to LDS during chunk v - 1)
+                if (q < 3) fq[(q + 1) & 1] = *reinterpret_cast<const f32x4*>(st + (q + 1) * 8);
+                if (q == 3) {
+                    std::integral_constant<int, P ^ 1> other;
+                    stage_rows(other, P ^ 1);           // chunk v + 1 -> the other stage
+                    wave_lds_fence();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
     const std::integral_constant<int, 0> even{};
@@ -187,10 +255,16 @@ __global__ void __launch_bounds__(256, 4) conv_wsplit_f32_kernel(const KArgs p) 
     // (conv_igemm_body.inc).
     int v = 0;
     if (active) {
+        if (ALDS) load_rows(0, even);
 #pragma unroll
         for (int q = 0; q < 4; ++q) load_chunk_q(0, q, even);
+        if (ALDS) load_rows(1, odd);
 #pragma unroll
         for (int q = 0; q < 4; ++q) load_chunk_q(1, q, odd);
+        if (ALDS) {
+            stage_rows(even, 0);
+            wave_lds_fence();
+        }
         for (; v + 2 <= total; v += 2) {
             chunk(v, even);
             leaf_end();
@@ -282,7 +356,7 @@ bool conv_wsplit_supported(const ConvArgs& a, const SkPlan& pl) {
     return pl.leaves >= 2 && pl.G >= 2 && pl.G <= 4 && pl.leaves % pl.G == 0 && (pl.unit == pl.leaves || pl.unit == pl.G) && !a.force_variant;
 }
 
-int launch_conv_wsplit(const ConvArgs& a, const SkPlan& pl, const SkWs& sk, const LaunchCtx& ctx, const ConvArgs* b) {
+int launch_conv_wsplit(const ConvArgs& a, const SkPlan& pl, const SkWs& sk, const LaunchCtx& ctx, const ConvArgs* b, bool alds) {
     if (!conv_wsplit_supported(a, pl)) return (int)hipErrorInvalidValue;
     if (int rc = conv_igemm_sk_check(a, pl, b)) return rc;
     const int groups = b ? 2 : 1;
@@ -299,12 +373,19 @@ int launch_conv_wsplit(const ConvArgs& a, const SkPlan& pl, const SkWs& sk, cons
     const double flops = 2.0 * (double)M * a.Cout * Kd;
     const double bytes = 4.0 * ((double)a.B * a.H * a.W * a.Cin + (a.x2 ? (double)M * a.Cin2 : 0.0) + (double)M * a.Cout * (a.res ? 2.0 : 1.0) + Kd * a.Cout);
     const bool is1x1 = (a.KH == 1 && a.KW == 1 && a.pad == 0);
-    const char* name = a.x2 ? "conv_wsplit_f32<32x32,4 leaves,2src>" : "conv_wsplit_f32<32x32,4 leaves>";
+    const char* name = alds ? (a.x2 ? "conv_wsplit_f32<32x32,4 leaves,ldsA,2src>" : "conv_wsplit_f32<32x32,4 leaves,ldsA>")
+                            : (a.x2 ? "conv_wsplit_f32<32x32,4 leaves,2src>" : "conv_wsplit_f32<32x32,4 leaves>");
     ProfScope ps(ctx, name, flops * groups, bytes * groups);
     const dim3 g(grid, S, groups), blk(256);
-    if (a.x2) hipLaunchKernelGGL((conv_wsplit_f32_kernel<true, true>), g, blk, 0, ctx.stream, k);
-    else if (is1x1) hipLaunchKernelGGL((conv_wsplit_f32_kernel<true, false>), g, blk, 0, ctx.stream, k);
-    else hipLaunchKernelGGL((conv_wsplit_f32_kernel<false, false>), g, blk, 0, ctx.stream, k);
+    if (alds) {
+        if (a.x2) hipLaunchKernelGGL((conv_wsplit_f32_kernel<true, true, true>), g, blk, 0, ctx.stream, k);
+        else if (is1x1) hipLaunchKernelGGL((conv_wsplit_f32_kernel<true, false, true>), g, blk, 0, ctx.stream, k);
+        else hipLaunchKernelGGL((conv_wsplit_f32_kernel<false, false, true>), g, blk, 0, ctx.stream, k);
+    } else {
+        if (a.x2) hipLaunchKernelGGL((conv_wsplit_f32_kernel<true, true, false>), g, blk, 0, ctx.stream, k);
+        else if (is1x1) hipLaunchKernelGGL((conv_wsplit_f32_kernel<true, false, false>), g, blk, 0, ctx.stream, k);
+        else hipLaunchKernelGGL((conv_wsplit_f32_kernel<false, false, false>), g, blk, 0, ctx.stream, k);
+    }
     return (int)hipGetLastError();
 }
 
