@@ -61,7 +61,7 @@ def main():
         for b in [int(v) for v in args.batches.split(',')]:
             xb = x[:b].contiguous()
             res = {}
-            CFG = {'k64': (0, -1), 'auto': (1, -1), 'group': (2, 0), 'all': (3, 0), 'group_ldsA': (2, 1), 'all_ldsA': (3, 1)}
+            CFG = {'k64': (0, -1), 'auto': (1, -1), 'group': (2, 0), 'all': (3, 0)}
             for tag, (ws, alds) in CFG.items():
                 opt('wsplit', ws); opt('wsplit_alds', alds)
                 fa, fb = ce.trunk_pair(he, xb, xb)
@@ -108,7 +108,7 @@ def main():
         row = {'test': 'timing', 'batch': b}
         for plan in (('single', 'latency') if b <= 4 else ('latency',)):
             cc.set_plan(plan); hm.set_plan(plan)
-            for tag, (ws, alds) in {'k64': (0, -1), 'auto': (1, -1), 'group': (2, 0), 'all': (3, 0), 'group_ldsA': (2, 1), 'all_ldsA': (3, 1)}.items():
+            for tag, (ws, alds) in {'k64': (0, -1), 'auto': (1, -1), 'group': (2, 0), 'all': (3, 0)}.items():
                 opt('wsplit', ws); opt('wsplit_alds', alds)
                 row[f'{plan}_{tag}_grouped'] = time_step(SpecPipeline(cc, hm, grouped=True), b)
                 row[f'{plan}_{tag}_2streams'] = time_step(SpecPipeline(cc, hm, overlap=True, grouped=False), b)
@@ -117,8 +117,7 @@ def main():
 
     if not args.skip_layers:
         pipe = SpecPipeline(cc, hm, overlap=False, grouped=True)
-        CONFIGS = [('k64', {'wsplit': 0}), ('ws_group', {'wsplit': 2, 'wsplit_alds': 0}), ('ws_all', {'wsplit': 3, 'wsplit_alds': 0}),
-                   ('wsA_group', {'wsplit': 2, 'wsplit_alds': 1}), ('wsA_all', {'wsplit': 3, 'wsplit_alds': 1}), ('ws_auto', {'wsplit': 1, 'wsplit_alds': -1})]
+        CONFIGS = [('k64', {'wsplit': 0}), ('ws_group', {'wsplit': 2}), ('ws_all', {'wsplit': 3}), ('ws_auto', {'wsplit': 1})]
         with open(os.path.join(outdir, 'wsplit_layers.txt'), 'a') as fl:
             for plan in ('single', 'latency'):
                 cc.set_plan(plan); hm.set_plan(plan)

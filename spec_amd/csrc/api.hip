@@ -748,10 +748,7 @@ static int launch_op(specmi_handle* h, const TrunkOp& op, const OpLaunch& L, con
             const long rows = (long)L.a.B * L.a.OH * L.a.OW;
             if (conv_wsplit_supported(L.a, pw) && (wsplit > 1 || rows <= (long)opt_i(h, "wsplit_max_rows", 4096))) {
                 if ((rc = ensure_sk(h, conv_wsplit_ws_floats(L.a, pw.leaves / pw.unit, groups), conv_wsplit_tiles(L.a, groups)))) return rc;
-                // A through the private LDS stage once several workgroups share a CU ("wsplit_alds": -1 by tile count, 0 / 1 never / always)
-                const int alds_opt = opt_i(h, "wsplit_alds", -1);
-                const bool alds = alds_opt < 0 ? (long)t32 * (pw.leaves / pw.unit) > (long)opt_i(h, "wsplit_alds_min_wgs", 320) : alds_opt != 0;
-                LAUNCHCHK(h, launch_conv_wsplit(L.a, pw, h->sk, ctx, partner ? &partner->a : nullptr, alds), op.label.c_str());
+                LAUNCHCHK(h, launch_conv_wsplit(L.a, pw, h->sk, ctx, partner ? &partner->a : nullptr), op.label.c_str());
                 return SPECMI_OK;
             }
         }

@@ -22,23 +22,22 @@
 //   * BatchNorm scale / shift, residual and ReLU in the epilogue with 16-byte row-contiguous stores; im2col padding and the
 //     M tail through the buffer range check; second A source (folded downsample branch) and grouped launches (blockIdx.z =
 //     network) as in the 64x64 kernel.
-// Operand traffic per MFMA is twice the 64x64 kernel's (no sharing between waves): fine while M is small (L2-resident
-// activations, every weight byte still leaves HBM once per tile row); the throughput plan never uses this kernel.
+// Operand traffic per MFMA is 8 KB per wave-chunk against the 64x64 kernel's 6 (no sharing between waves), and an A fragment
+// load touches 32 cache lines: fine while a CU holds one or two workgroups (batch 1-3; layer4 up to batch 4), slower than the
+// 64x64 kernel beyond (measured per layer and batch: profiles/r05_c_wsplit_layers.txt; a variant that stages A as whole rows
+// through a private per-wave LDS buffer was built and measured too - never ahead of the 64x64 kernel at batch >= 4, dropped).
+// The K loop is ISSUE-sensitive (four waves per SIMD interleave their MFMA chains): the chunk addressing is incremental
+// scalar state advanced once per chunk (no division in the steady state), every address is formed once per chunk, and the
+// last two chunks are peeled so that no "past the end" select remains in the loop - 100 scalar instructions more per chunk
+// pair cost 8-17 % (same profile).
 #include "conv_igemm_tile.h"
 
 namespace specmi {
 
-// ALDS = false: A fragments straight from L2 (lane (row, h) reads its own 16 bytes: 32 rows x 32 bytes per instruction - 32 cache
-//   lines touched for 1 KB; fine while a CU holds one workgroup, the batch 1-2 regime);
-// ALDS = true:  A as whole 128-byte row segments (8 lanes per row, 8 rows per instruction - 8 full lines) into registers two chunks
-//   ahead, transposed through a PRIVATE per-wave LDS stage (2 x 32 x 36 floats, the 64x64 kernel's layout) - still no workgroup
-//   barrier in the K loop (a wave's LDS operations execute in order); what 3-4 co-resident workgroups per CU need (batch >= 4:
-//   the scattered form saturates the vector L1's tag rate, measured at half the matrix pipe).
-template <bool IS1X1, bool DUAL, bool ALDS>
-__global__ void __launch_bounds__(256, ALDS ? 3 : 4) conv_wsplit_f32_kernel(const KArgs p) {
+template <bool IS1X1, bool DUAL>
+__global__ void __launch_bounds__(256, 4) conv_wsplit_f32_kernel(const KArgs p) {
     static_assert(!DUAL || IS1X1, "the second A source exists for 1x1 layers only");
     __shared__ __attribute__((aligned(16))) float lds[4 * 1024];   // one 32x32 leaf tile per wave, [reg][lane]
-    __shared__ __attribute__((aligned(16))) float lds_a[ALDS ? 4 * 2 * 32 * 36 : 4];   // ALDS: [wave][stage][row][32 k + 4 pad]
     __shared__ int flag;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -64,31 +63,26 @@ __global__ void __launch_bounds__(256, ALDS ? 3 : 4) conv_wsplit_f32_kernel(cons
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pw), 0, p.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t x2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DUAL ? px2 : px), 0, DUAL ? p.x2_bytes : p.x_bytes, 0x00020000);
 
-    // ---- this lane's A rows: byte offset of (tap (0,0) pixel, this lane's 16-byte quad).  Direct form: ONE row (l31), quad = the
-    // lane half's 4 k's of sub-chunk 0; ALDS: FOUR rows (lane / 8 + 8 i), quad lane % 8 of the chunk's 32 k's ----------------------
-    constexpr int NA = ALDS ? 4 : 1;
-    unsigned a_voff[NA], a_voff2[NA], a_mask[NA];
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int m = m0 + (ALDS ? (lane >> 3) + 8 * i : l31);
-        const int qb = (ALDS ? (lane & 7) : hh) * 16;
+    // ---- this lane's A row: byte offset of (tap (0,0) pixel, channel 4 * hh) -----------------------------------------------
+    unsigned a_voff, a_voff2 = 0, a_mask = 0;
+    {
+        const int m = m0 + l31;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
-        a_voff2[i] = 0; a_mask[i] = 0;
         if (DUAL) {
             if (p.stride2 == 1) {
-                a_voff2[i] = ok ? (unsigned)(mm * p.ldx2 * 4 + qb) : kOutOfRange;
+                a_voff2 = ok ? (unsigned)(mm * p.ldx2 * 4 + hh * 16) : kOutOfRange;
             } else {
                 const int b2 = p.OHW == 1 ? mm : (int)(__umulhi((unsigned)mm, p.mg_ohw) >> p.sh_ohw);
                 const int rem2 = mm - b2 * p.OHW;
                 const int oy2 = p.OW == 1 ? rem2 : (int)(__umulhi((unsigned)rem2, p.mg_ow) >> p.sh_ow);
                 const int ox2 = rem2 - oy2 * p.OW;
                 const int pix2 = (b2 * p.H2 + oy2 * p.stride2) * p.W2 + ox2 * p.stride2;
-                a_voff2[i] = ok ? (unsigned)(pix2 * p.ldx2 * 4 + qb) : kOutOfRange;
+                a_voff2 = ok ? (unsigned)(pix2 * p.ldx2 * 4 + hh * 16) : kOutOfRange;
             }
         }
         if (IS1X1 && p.stride == 1) {
-            a_voff[i] = ok ? (unsigned)(mm * p.ldx * 4 + qb) : kOutOfRange;
+            a_voff = ok ? (unsigned)(mm * p.ldx * 4 + hh * 16) : kOutOfRange;
         } else {
             const int b = p.OHW == 1 ? mm : (int)(__umulhi((unsigned)mm, p.mg_ohw) >> p.sh_ohw);
             const int rem = mm - b * p.OHW;
@@ -96,16 +90,16 @@ __global__ void __launch_bounds__(256, ALDS ? 3 : 4) conv_wsplit_f32_kernel(cons
             const int ox = rem - oy * p.OW;
             const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
             const int pix0 = (b * p.H + iy0) * p.W + ix0;
-            const unsigned off = (unsigned)(pix0 * p.ldx * 4 + qb);   // wraps for padded rows; only used on valid taps
+            const unsigned off = (unsigned)(pix0 * p.ldx * 4 + hh * 16);   // wraps for padded rows; only used on valid taps
             if (IS1X1) {
-                a_voff[i] = ok ? off : kOutOfRange;
+                a_voff = ok ? off : kOutOfRange;
             } else {
-                a_voff[i] = off;
+                a_voff = off;
                 unsigned colbits = 0, mk = 0;
                 for (int kx = 0; kx < p.KW; ++kx) colbits |= ((unsigned)(ix0 + kx) < (unsigned)p.W ? 1u : 0u) << kx;
                 for (int ky = 0; ky < p.KH; ++ky)
                     if ((unsigned)(iy0 + ky) < (unsigned)p.H) mk |= colbits << (ky * p.KW);
-                a_mask[i] = ok ? mk : 0u;
+                a_mask = ok ? mk : 0u;
             }
         }
     }
@@ -119,101 +113,75 @@ __global__ void __launch_bounds__(256, ALDS ? 3 : 4) conv_wsplit_f32_kernel(cons
     const int g0 = (int)blockIdx.y * ngroups_wg;
     const int total = ngroups_wg * L;
     const bool active = wave < G;                  // (a group of 2 or 3 leaves leaves waves idle)
-    f32x4 fa[2][4], fb[2][4];   // fa: direct form: A fragments [set][q]; ALDS: the raw row quads [set][row i] on their way to LDS
-    struct ChunkAddr { bool oob, second; unsigned s_a, tap_bytes, s_b; int tap; };
-    auto chunk_addr = [&](int v) {
-        ChunkAddr a;
-        a.oob = v >= total;
-        const int gi = v / L;                      // (scalar)
-        const int c = ((g0 + gi) * G + wave) * L + (v - gi * L);
-        a.tap = IS1X1 ? 0 : c / p.cpc;
-        const int c0 = IS1X1 ? c : c - a.tap * p.cpc;
-        a.tap_bytes = 0;
+    f32x4 fa[2][4], fb[2][4];
+    // ---- prefetch cursor: the chunk two ahead of the one being consumed, as scalar state advanced once per chunk ----------------
+    const unsigned npad32 = (unsigned)p.Npad * 32u;   // bytes between the quad pairs of consecutive sub-chunks of B
+    int pcl = 0, pgi = 0;         // chunk within the leaf, group within this workgroup's groups
+    int pc = 0, pc0 = 0;          // absolute chunk; chunk within its filter tap (KxK)
+    int pky = 0, pkx = 0;         // filter tap of pc (KxK)
+    auto cursor_leaf = [&]() {    // first chunk of leaf (g0 + pgi) * G + wave: the only place that divides (once per leaf)
+        pc = ((g0 + pgi) * G + wave) * L;
         if (!IS1X1) {
-            const int ky = a.tap / p.KW, kx = a.tap - ky * p.KW;
-            a.tap_bytes = (unsigned)((ky * p.W + kx) * p.ldx * 4);
+            const int tap = pc / p.cpc;
+            pc0 = pc - tap * p.cpc;
+            pky = tap / p.KW;
+            pkx = tap - pky * p.KW;
         }
-        a.second = DUAL && c >= p.cpc1;
-        a.s_a = a.oob ? 0u : (unsigned)((a.second ? c0 - p.cpc1 : c0) * 128);
-        a.s_b = a.oob ? 0u : (unsigned)(c * 8 * p.Npad * 16);
-        return a;
     };
-    auto load_a_one = [&](const ChunkAddr& ca, int i, unsigned extra) {
-        unsigned voff = a_voff[i];
-        if (!IS1X1) voff = ((a_mask[i] >> (ca.tap & 31)) & 1u) ? voff + ca.tap_bytes : kOutOfRange;
-        if (DUAL) voff = ca.second ? a_voff2[i] : voff;
-        if (ca.oob) voff = kOutOfRange;
-        if (DUAL) return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ca.second ? x2rs : xrs, voff, ca.s_a + extra, 0));
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, ca.s_a + extra, 0));
+    auto cursor_next = [&]() {
+        if (++pcl == L) {
+            pcl = 0; ++pgi;
+            cursor_leaf();
+            return;
+        }
+        ++pc;
+        if (!IS1X1) {
+            if (++pc0 == p.cpc) {
+                pc0 = 0;
+                if (++pkx == p.KW) { pkx = 0; ++pky; }
+            }
+        }
     };
-    auto load_b_one = [&](const ChunkAddr& ca, int q) {
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-            wrs, ca.oob ? kOutOfRange : b_voff, ca.oob ? 0u : ca.s_b + (unsigned)(2 * q * p.Npad * 16), 0));
+    // addresses of the cursor's chunk, formed once per chunk: scalar byte offsets of A / B and this lane's A row offset
+    unsigned cs_a = 0, cs_b = 0, cv_a = 0;
+    bool c_second = false;
+    auto cursor_addr = [&]() {
+        c_second = DUAL && pc >= p.cpc1;
+        cs_a = (unsigned)((IS1X1 ? (c_second ? pc - p.cpc1 : pc) : pc0) * 128);
+        cs_b = (unsigned)pc * 8u * (unsigned)p.Npad * 16u;
+        if (IS1X1) {
+            cv_a = DUAL ? (c_second ? a_voff2 : a_voff) : a_voff;
+        } else {
+            const int tap = pky * p.KW + pkx;
+            const unsigned tap_bytes = (unsigned)((pky * p.W + pkx) * p.ldx * 4);
+            cv_a = ((a_mask >> tap) & 1u) ? a_voff + tap_bytes : kOutOfRange;
+        }
     };
-    // direct form: A and B fragments of sub-chunk q of virtual chunk v into set SL
-    auto load_chunk_q = [&](int v, int q, auto slot) {
+    auto load_q = [&](int q, auto slot) {   // sub-chunk q of the cursor's chunk into set SL
         constexpr int SL = decltype(slot)::value;
-        const ChunkAddr ca = chunk_addr(v);
-        if (!ALDS) fa[SL][q] = load_a_one(ca, 0, (unsigned)(q * 32));
-        fb[SL][q] = load_b_one(ca, q);
-    };
-    // ALDS: the four row quads of virtual chunk v into set SL
-    auto load_rows = [&](int v, auto slot) {
-        constexpr int SL = decltype(slot)::value;
-        const ChunkAddr ca = chunk_addr(v);
-#pragma unroll
-        for (int i = 0; i < NA; ++i) fa[SL][i] = load_a_one(ca, i, 0u);
-    };
-    float* const stage = lds_a + (ALDS ? wave * (2 * 32 * 36) : 0);
-    auto stage_rows = [&](auto slot, int which) {   // set SL -> LDS stage `which` (row-major, 36-float rows)
-        constexpr int SL = decltype(slot)::value;
-#pragma unroll
-        for (int i = 0; i < NA; ++i)
-            *reinterpret_cast<f32x4*>(&stage[which * (32 * 36) + ((lane >> 3) + 8 * i) * 36 + (lane & 7) * 4]) = fa[SL][i];
-    };
-    auto wave_lds_fence = [&]() {   // a wave's LDS operations execute in order: only the COMPILER must not reorder across this point
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (DUAL) fa[SL][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(c_second ? x2rs : xrs, cv_a, cs_a + (unsigned)(q * 32), 0));
+        else      fa[SL][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, cv_a, cs_a + (unsigned)(q * 32), 0));
+        fb[SL][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, b_voff, cs_b + (unsigned)q * npad32, 0));
     };
 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    auto chunk = [&](int v, auto par) {
+    // one chunk out of set P; PF: the chunk two ahead is fetched into the same set, sub-chunk by sub-chunk as the set is consumed
+    auto chunk = [&](auto par, auto prefetch) {
         constexpr int P = decltype(par)::value;
-        if constexpr (!ALDS) {
+        constexpr bool PF = decltype(prefetch)::value;
+        if (PF) cursor_addr();
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 4; ++q) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[P][q][s], fb[P][q][s], acc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                load_chunk_q(v + 2, q, par);   // this set's next use is two chunks from now
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-            // stage P holds chunk v (written during chunk v - 1 / the prologue); set P^1 holds chunk v + 1's rows
-            const float* const st = stage + P * (32 * 36) + l31 * 36 + hh * 4;
-            f32x4 fq[2];
-            fq[0] = *reinterpret_cast<const f32x4*>(st);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fq[q & 1][s], fb[P][q][s], acc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                fb[P][q] = load_b_one(chunk_addr(v + 2), q);
-                if (q == 0) load_rows(v + 2, par);      // (set P's rows went to LDS during chunk v - 1)
-                if (q < 3) fq[(q + 1) & 1] = *reinterpret_cast<const f32x4*>(st + (q + 1) * 8);
-                if (q == 3) {
-                    std::integral_constant<int, P ^ 1> other;
-                    stage_rows(other, P ^ 1);           // chunk v + 1 -> the other stage
-                    wave_lds_fence();
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int s = 0; s < 4; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[P][q][s], fb[P][q][s], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (PF) load_q(q, par);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (PF) cursor_next();
     };
     const std::integral_constant<int, 0> even{};
     const std::integral_constant<int, 1> odd{};
@@ -251,32 +219,42 @@ __global__ void __launch_bounds__(256, ALDS ? 3 : 4) conv_wsplit_f32_kernel(cons
     // Waves without a leaf (groups of 2 or 3) only keep the barriers company.  Two separate loops, not `if (active)` around the
     // chunks: hipcc's wait-count pass is path-insensitive - with the chunk under an `if` it assumes the other register set's
     // eight loads are not in flight and waits for vmcnt(6) instead of vmcnt(14) at the top of every chunk (the two-chunk
-    // distance collapses to one; seen in the disassembly).  Whole (even, odd) pairs plus a peeled tail for the same reason
-    // (conv_igemm_body.inc).
-    int v = 0;
+    // distance collapses to one; seen in the disassembly).  Whole (even, odd) pairs for the same reason (conv_igemm_body.inc);
+    // the last two or three chunks are peeled: they fetch nothing (or one chunk), so the loop body has no "past the end" test.
+    const std::true_type pf{};
+    const std::false_type nopf{};
     if (active) {
-        if (ALDS) load_rows(0, even);
+        cursor_leaf();
+        cursor_addr();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) load_chunk_q(0, q, even);
-        if (ALDS) load_rows(1, odd);
+        for (int q = 0; q < 4; ++q) load_q(q, even);
+        cursor_next();
+        cursor_addr();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) load_chunk_q(1, q, odd);
-        if (ALDS) {
-            stage_rows(even, 0);
-            wave_lds_fence();
-        }
-        for (; v + 2 <= total; v += 2) {
-            chunk(v, even);
+        for (int q = 0; q < 4; ++q) load_q(q, odd);
+        cursor_next();
+        int v = 0;
+        for (; v + 4 <= total; v += 2) {     // chunks v, v + 1: their prefetches v + 2, v + 3 exist
+            chunk(even, pf);
             leaf_end();
-            chunk(v + 1, odd);
+            chunk(odd, pf);
             leaf_end();
         }
-        if (v < total) {
-            chunk(v, even);
+        if (total - v == 3) {
+            chunk(even, pf);
+            leaf_end();
+            chunk(odd, nopf);
+            leaf_end();
+            chunk(even, nopf);
+            leaf_end();
+        } else {                              // 2 left (total >= 4: a leaf has at least four chunks)
+            chunk(even, nopf);
+            leaf_end();
+            chunk(odd, nopf);
             leaf_end();
         }
     } else {
-        for (; v < total; ++v) leaf_end();
+        for (int v = 0; v < total; ++v) leaf_end();
     }
 
     if (S > 1) {
@@ -353,10 +331,12 @@ size_t conv_wsplit_ws_floats(const ConvArgs& a, int S, int groups) { return S > 
 
 // the canonical tree must have 2..4 leaves per group (one per wave); unit = leaves (no slabs) or G (one group per workgroup)
 bool conv_wsplit_supported(const ConvArgs& a, const SkPlan& pl) {
-    return pl.leaves >= 2 && pl.G >= 2 && pl.G <= 4 && pl.leaves % pl.G == 0 && (pl.unit == pl.leaves || pl.unit == pl.G) && !a.force_variant;
+    const int nch = a.KH * a.KW * (a.Cin / 32) + (a.x2 ? a.Cin2 / 32 : 0);
+    return pl.leaves >= 2 && pl.G >= 2 && pl.G <= 4 && pl.leaves % pl.G == 0 && (pl.unit == pl.leaves || pl.unit == pl.G) && !a.force_variant &&
+           nch % pl.leaves == 0 && nch / pl.leaves >= 2;   // (the K loop keeps two chunks in flight)
 }
 
-int launch_conv_wsplit(const ConvArgs& a, const SkPlan& pl, const SkWs& sk, const LaunchCtx& ctx, const ConvArgs* b, bool alds) {
+int launch_conv_wsplit(const ConvArgs& a, const SkPlan& pl, const SkWs& sk, const LaunchCtx& ctx, const ConvArgs* b) {
     if (!conv_wsplit_supported(a, pl)) return (int)hipErrorInvalidValue;
     if (int rc = conv_igemm_sk_check(a, pl, b)) return rc;
     const int groups = b ? 2 : 1;
@@ -373,19 +353,12 @@ int launch_conv_wsplit(const ConvArgs& a, const SkPlan& pl, const SkWs& sk, cons
     const double flops = 2.0 * (double)M * a.Cout * Kd;
     const double bytes = 4.0 * ((double)a.B * a.H * a.W * a.Cin + (a.x2 ? (double)M * a.Cin2 : 0.0) + (double)M * a.Cout * (a.res ? 2.0 : 1.0) + Kd * a.Cout);
     const bool is1x1 = (a.KH == 1 && a.KW == 1 && a.pad == 0);
-    const char* name = alds ? (a.x2 ? "conv_wsplit_f32<32x32,4 leaves,ldsA,2src>" : "conv_wsplit_f32<32x32,4 leaves,ldsA>")
-                            : (a.x2 ? "conv_wsplit_f32<32x32,4 leaves,2src>" : "conv_wsplit_f32<32x32,4 leaves>");
+    const char* name = a.x2 ? "conv_wsplit_f32<32x32,4 leaves,2src>" : "conv_wsplit_f32<32x32,4 leaves>";
     ProfScope ps(ctx, name, flops * groups, bytes * groups);
     const dim3 g(grid, S, groups), blk(256);
-    if (alds) {
-        if (a.x2) hipLaunchKernelGGL((conv_wsplit_f32_kernel<true, true, true>), g, blk, 0, ctx.stream, k);
-        else if (is1x1) hipLaunchKernelGGL((conv_wsplit_f32_kernel<true, false, true>), g, blk, 0, ctx.stream, k);
-        else hipLaunchKernelGGL((conv_wsplit_f32_kernel<false, false, true>), g, blk, 0, ctx.stream, k);
-    } else {
-        if (a.x2) hipLaunchKernelGGL((conv_wsplit_f32_kernel<true, true, false>), g, blk, 0, ctx.stream, k);
-        else if (is1x1) hipLaunchKernelGGL((conv_wsplit_f32_kernel<true, false, false>), g, blk, 0, ctx.stream, k);
-        else hipLaunchKernelGGL((conv_wsplit_f32_kernel<false, false, false>), g, blk, 0, ctx.stream, k);
-    }
+    if (a.x2) hipLaunchKernelGGL((conv_wsplit_f32_kernel<true, true>), g, blk, 0, ctx.stream, k);
+    else if (is1x1) hipLaunchKernelGGL((conv_wsplit_f32_kernel<true, false>), g, blk, 0, ctx.stream, k);
+    else hipLaunchKernelGGL((conv_wsplit_f32_kernel<false, false>), g, blk, 0, ctx.stream, k);
     return (int)hipGetLastError();
 }
 

@@ -126,8 +126,7 @@ int launch_conv_igemm_sk(const ConvArgs& a, const SkPlan& pl, const SkWs& sk, co
 bool conv_wsplit_supported(const ConvArgs& a, const SkPlan& pl);
 int conv_wsplit_tiles(const ConvArgs& a, int groups);
 size_t conv_wsplit_ws_floats(const ConvArgs& a, int slabs, int groups);
-// alds: A operand as full rows through a private per-wave LDS stage (conv_wsplit.hip) instead of scattered fragment loads
-int launch_conv_wsplit(const ConvArgs& a, const SkPlan& pl, const SkWs& sk, const LaunchCtx& ctx, const ConvArgs* b = nullptr, bool alds = false);
+int launch_conv_wsplit(const ConvArgs& a, const SkPlan& pl, const SkWs& sk, const LaunchCtx& ctx, const ConvArgs* b = nullptr);
 // pick the tile the launcher would use (for tests / labels)
 const char* conv_igemm_variant(const ConvArgs& a);
 
