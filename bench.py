@@ -444,6 +444,11 @@ def main():
             m._engine.set_option('force_conv_variant', args.force_variant)
     B = args.batch
     x, scale, center, img_w, img_h = make_inputs(B, device, 20210001 + rank)
+    if use_dist:
+        # config 4: every rank runs its shard of the global batch and the gathered records must equal the unsharded forward bit
+        # for bit - an image's bits are batch-invariant WITHIN a plan, so the sharded path pins it (auto would pick by shard size)
+        for m in (cc, hm):
+            m.set_plan('throughput')
 
     # N > 1: one all-gather of the packed records per step, started asynchronously so that RCCL moves step s over xGMI
     # while the kernels of step s+1 run (at most 2 in flight; everything is drained inside the timed region).  The

@@ -737,16 +737,29 @@ static int launch_op(specmi_handle* h, const TrunkOp& op, const OpLaunch& L, con
         const int fu = opt_i(h, "latency_force_unit", 0);   // tests: 1 leaf / 2 group / 3 whole K per workgroup, whatever the batch
         if (fu) pl.unit = fu == 1 ? 1 : (fu == 2 ? pl.G : pl.leaves);
         // The wave-split unit (conv_wsplit.hip, round 5): a 32x32 tile per workgroup, the G leaves of a group on its waves side by
-        // side - four times the tiles, slabs of 4 KB per GROUP or none.  Same canonical tree, same bits.  "wsplit": 0 never,
-        // 1 (default) by the rule below, 2 / 3 always with one group / all groups per workgroup (tests, per-layer tables).
+        // side - four times the tiles, slabs of 4 KB per GROUP or none.  Same canonical tree, same bits: a pure speed choice, made
+        // from the per-layer tables of profiles/r05_c_wsplit_layers.txt:
+        //   * taken when the 64x64 kernel would have to slice K across workgroups (its unit is not the whole K), the layer has one A
+        //     source (the strided second source of a folded downsample branch measured slower at every batch) and the launch stays
+        //     under "wsplit_max_units" (1000) leaf-units = 32x32 tiles x groups: beyond, several workgroups share a CU and the
+        //     8 KB of operands per wave-chunk (6 in the 64x64 kernel) cost more than the slabs (batch 8: layer3 1568 units, slower);
+        //   * one group per workgroup (slab per group) or all groups (no slab): whichever needs fewer rounds of workgroups per CU,
+        //     a round costing one leaf (L chunks of ~0.45 us) and the slab hand-off ~1 us - the rule that reproduces every row of
+        //     the tables (batch 1-4, layer2-4).
+        // "wsplit": 0 never, 1 (default) by this rule, 2 / 3 always with one group / all groups per workgroup (tests, tables).
         const int wsplit = opt_i(h, "wsplit", 1);
         if (wsplit && !fu) {
             SkPlan pw = pl;
-            const int t32 = conv_wsplit_tiles(L.a, groups);
-            // all groups in one workgroup (no slab) as soon as the 32x32 tiles alone fill the chip
-            pw.unit = (wsplit == 3 || (wsplit == 1 && t32 >= opt_i(h, "wsplit_fill_wgs", 200))) ? pl.leaves : pl.G;
-            const long rows = (long)L.a.B * L.a.OH * L.a.OW;
-            if (conv_wsplit_supported(L.a, pw) && (wsplit > 1 || rows <= (long)opt_i(h, "wsplit_max_rows", 4096))) {
+            const long t32 = conv_wsplit_tiles(L.a, groups);
+            const long ng = pl.leaves / (pl.G > 0 ? pl.G : 1);
+            const int nch = L.a.KH * L.a.KW * (L.a.Cin / 32) + (L.a.x2 ? L.a.Cin2 / 32 : 0);
+            const double t_leaf = 0.45 * (double)(nch / pl.leaves);
+            const long slots = opt_i(h, "wsplit_slots", 256);
+            const double cost_all = (double)((t32 + slots - 1) / slots) * (double)ng * t_leaf;
+            const double cost_group = (double)((t32 * ng + slots - 1) / slots) * t_leaf + 1.0;
+            pw.unit = (wsplit == 3 || (wsplit == 1 && cost_all <= cost_group)) ? pl.leaves : pl.G;
+            const bool take = wsplit > 1 || (pl.unit != pl.leaves && !L.a.x2 && t32 * ng <= (long)opt_i(h, "wsplit_max_units", 1000));
+            if (take && conv_wsplit_supported(L.a, pw)) {
                 if ((rc = ensure_sk(h, conv_wsplit_ws_floats(L.a, pw.leaves / pw.unit, groups), conv_wsplit_tiles(L.a, groups)))) return rc;
                 LAUNCHCHK(h, launch_conv_wsplit(L.a, pw, h->sk, ctx, partner ? &partner->a : nullptr), op.label.c_str());
                 return SPECMI_OK;
@@ -1570,8 +1583,17 @@ int specmi_conv2d(specmi_handle* h, const float* x, int B, int H, int W, int Cin
             }
             const int fu = opt_i(h, "latency_force_unit", 0);
             if (fu) pl.unit = fu == 1 ? 1 : (fu == 2 ? pl.G : pl.leaves);
-            if ((rc = ensure_sk(h, conv_igemm_sk_ws_floats(a, pl.leaves / pl.unit, 1), conv_igemm_sk_tiles(a, 1)))) { free_pool(tmp); return rc; }
-            lrc = pl.leaves > 1 ? launch_conv_igemm_sk(a, pl, h->sk, ctx) : launch_conv_igemm(a, ctx);
+            // "conv2d_wsplit" (tests): 2 / 3 = the wave-split unit of the same tree, one group / all groups per workgroup
+            const int ws = opt_i(h, "conv2d_wsplit", 0);
+            SkPlan pw = pl;
+            pw.unit = ws == 3 ? pl.leaves : pl.G;
+            if (ws >= 2 && conv_wsplit_supported(a, pw)) {
+                if ((rc = ensure_sk(h, conv_wsplit_ws_floats(a, pw.leaves / pw.unit, 1), conv_wsplit_tiles(a, 1)))) { free_pool(tmp); return rc; }
+                lrc = launch_conv_wsplit(a, pw, h->sk, ctx);
+            } else {
+                if ((rc = ensure_sk(h, conv_igemm_sk_ws_floats(a, pl.leaves / pl.unit, 1), conv_igemm_sk_tiles(a, 1)))) { free_pool(tmp); return rc; }
+                lrc = pl.leaves > 1 ? launch_conv_igemm_sk(a, pl, h->sk, ctx) : launch_conv_igemm(a, ctx);
+            }
         } else lrc = wino ? launch_conv_wino(a, ctx) : launch_conv_igemm(a, ctx);
     }
     hipError_t se = hipStreamSynchronize(s);

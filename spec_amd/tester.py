@@ -135,8 +135,10 @@ class SPECTester:
         plan (``args.plan``: 'throughput' | 'latency' | 'auto', see ``spec_amd.modules._EngineModule.set_plan``) an image's
         outputs do not depend on the batch it travels in (every kernel of the path has a fixed summation order), so with the
         plan pinned the per-frame ``spec_results/<stem>.pkl`` files are bit-identical to ``frame_batch=1``, the reference's
-        own structure.  Default: 'throughput' when frames are batched, 'auto' (the latency plan for up to 10 detections) for
-        one forward per frame - last bits then differ between the two settings (contract: 1e-4).
+        own structure (one deterministic result per image, ``spec/tester.py:143-163``).  Default (round 5): ONE plan for the
+        whole run whatever ``frame_batch`` is - 'throughput' - so the files do not depend on how the frames were batched; the
+        choice is logged.  ``--plan auto`` buys the lowest per-frame latency (single / latency plan by detection count) at the
+        price of last bits that depend on the batch (contract: 1e-4).
         Decode-ahead is bounded: at most 2 x ``args.decode_threads`` decoded frames wait in host memory (the reference holds
         one frame at a time; an unbounded queue would keep a whole video folder in RAM when decoding outruns the GPU)."""
         from collections import deque
@@ -145,7 +147,14 @@ class SPECTester:
         res = self.model_cfg.DATASET.IMG_RES
         cap = max(1, int(getattr(self.args, 'frame_batch', 256) or 1))
         per_frame = cap <= 1                                             # the reference's structure: one forward per frame
-        self.model.set_plan(getattr(self.args, 'plan', None) or ('auto' if per_frame else 'throughput'))
+        plan = getattr(self.args, 'plan', None)
+        if not plan:
+            plan = 'throughput'
+            _log("execution plan: 'throughput' for the whole run (results bit-identical for any --frame_batch; "
+                 "--plan auto = lowest latency per forward, last bits then depend on the batch size)")
+        else:
+            _log(f"execution plan: '{plan}' (pinned by --plan)")
+        self.model.set_plan(plan)
         dev = self.device
         todo = [(i, f) for i, f in enumerate(image_file_names) if len(detections[i]) >= 1]
         if not todo:

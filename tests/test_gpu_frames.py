@@ -146,7 +146,7 @@ def test_tester_batched_equals_per_frame(tmp_path):
     try:
         results = {}
         for tag, fb, plan in (('per_frame', 1, 'throughput'), ('batched', 256, 'throughput'), ('small_cap', 5, 'throughput'),
-                              ('per_frame_default_plan', 1, None)):
+                              ('per_frame_default_plan', 1, None), ('batched_default_plan', 256, None), ('per_frame_auto', 1, 'auto')):
             out = os.path.join(d, 'out_' + tag)
             args = SimpleNamespace(cfg=None, ckpt=hs, no_save=False, no_render=True, synthetic_assets=True, frame_batch=fb, plan=plan,
                                    decode_threads=2, camcalib_model=gpu_models(True, True, DEV)[0], detections=dets)
@@ -163,10 +163,16 @@ def test_tester_batched_equals_per_frame(tmp_path):
         for f, ref in results['per_frame'].items():
             for key, v in ref.items():
                 assert results[tag][f][key].shape == v.shape and np.array_equal(results[tag][f][key], v), (tag, f, key)
-    # the default of one-forward-per-frame is the latency plan for up to 10 detections: same results to fp32 rounding
+    # DEFAULT arguments (no --plan): one plan for the whole run whatever --frame_batch, so frame_batch = 1 (the reference's
+    # structure, spec/tester.py:143-163: one deterministic result per image) and 256 write identical files
+    for tag in ('per_frame_default_plan', 'batched_default_plan'):
+        for f, ref in results['per_frame'].items():
+            for key, v in ref.items():
+                assert np.array_equal(results[tag][f][key], v), (tag, f, key)
+    # --plan auto: the single / latency plan by detection count - same results to fp32 rounding
     for f, ref in results['per_frame'].items():
         for key in ('smpl_vertices', 'smpl_joints2d', 'pred_cam_t'):
-            a, b = results['per_frame_default_plan'][f][key].astype(np.float64), ref[key].astype(np.float64)
+            a, b = results['per_frame_auto'][f][key].astype(np.float64), ref[key].astype(np.float64)
             assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max(), (f, key)
     assert results['per_frame']['f4.pkl']['smpl_vertices'].shape == (4, 6890, 3)
     assert results['per_frame']['f5.pkl']['smpl_vertices'].shape == (70, 6890, 3)

@@ -125,23 +125,31 @@ def models():
 
 
 def test_plan_selection_and_launch_count(models):
-    """auto: a single trunk takes the latency plan up to 16 images, throughput beyond; one launch per layer either way."""
+    """auto: a single trunk takes the single plan up to 2 images (no Winograd anywhere), the latency plan up to 16, throughput
+    beyond; one launch per layer in all three.  Sliced layers run on the 64x64 sliced kernel or on the wave-split unit of the same
+    tree (round 5) - the small batches on the latter."""
     _, hm = models
     e = hm.engine(torch.device(DEV))
-    for B, want in ((1, True), (16, True), (17, False)):
+    for B, want in ((1, 'single'), (2, 'single'), (3, 'latency'), (16, 'latency'), (17, 'throughput')):
         x = t(synth.images(5, B)).to(DEV)
         e.profile(True)
         e.trunk(x)
         prof = e.profile_read()
         e.profile(False)
         assert sum(p['launches'] for p in prof) == 2 + 16 * 3
-        sliced = [p['label'] for p in prof if 'splitK' in p['kernel']]
-        assert (len(sliced) > 25) == want, (B, sliced)
-        if want:   # layer3 / layer4 3x3 convolutions leave Winograd for the sliced direct kernel; layer1 / layer2 keep it
-            kern = {p['label']: p['kernel'] for p in prof}
-            assert 'splitK' in kern['backbone.layer4.1.conv2'] and 'splitK' in kern['backbone.layer3.2.conv2']
+        kern = {p['label']: p['kernel'] for p in prof}
+        sliced = [l for l, k in kern.items() if 'splitK' in k or 'wsplit' in k]
+        assert (len(sliced) > 25) == (want != 'throughput'), (B, sliced)
+        wino = [l for l, k in kern.items() if 'wino' in k]
+        if want == 'single':
+            assert not wino, (B, wino)
+            assert 'wsplit' in kern['backbone.layer4.1.conv2'] and 'wsplit' in kern['backbone.layer3.2.conv1']
+        if want == 'latency':   # layer3 / layer4 3x3 convolutions leave Winograd for the sliced direct kernels; layer1 / layer2 keep it
+            assert all(s in kern['backbone.layer4.1.conv2'] or 'wsplit' in kern['backbone.layer4.1.conv2'] for s in ('splitK',))
             assert 'wino' in kern['backbone.layer1.1.conv2'] and 'wino' in kern['backbone.layer2.1.conv2']
             assert '2src' in kern['backbone.layer3.0.conv3+downsample'] and 'splitK' in kern['backbone.layer3.0.conv3+downsample']
+        if B == 16:             # past the wave-split unit's range: the 64x64 sliced kernel
+            assert 'splitK' in kern['backbone.layer4.1.conv2'] and 'splitK' in kern['backbone.layer3.2.conv2']
 
 
 def test_latency_plan_is_batch_invariant_and_deterministic(models):
