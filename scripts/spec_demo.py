@@ -108,6 +108,9 @@ if __name__ == '__main__':
     parser.add_argument('--batch_size', type=int, default=16, help='batch size of SPEC')
     parser.add_argument('--frame_batch', type=int, default=256, help='crops per SPEC forward, collected across frames (1 = one forward per frame, the reference structure; results are bit-identical)')
     parser.add_argument('--decode_threads', type=int, default=4, help='host threads decoding frames ahead of the GPU')
+    parser.add_argument('--plan', type=str, default=None, choices=['throughput', 'latency', 'single', 'auto'],
+                        help="execution plan of the trunk; default: 'throughput' for the whole run whatever --frame_batch (results are then "
+                             "bit-identical for any batching); 'auto' = lowest latency per forward, last bits depend on the batch")
     parser.add_argument('--display', action='store_true')
     parser.add_argument('--smooth', action='store_true')
     parser.add_argument('--no_render', action='store_true', help='(rendering is never done by this build)')
