@@ -253,9 +253,16 @@ def test_batch1_latency_path(models):
     x = t(synth.images(35, 4)).to(DEV)
     sc, ce, iw, ih = [t(a).to(DEV) for a in synth.bbox_inputs(35, 4, 640., 480.)]
     pipe = SpecPipeline(cc, hm, overlap=False)
+    from tests.util import pinned_plan
+    for plan in ('latency', 'single', 'throughput'):      # bit-identity holds WITHIN a plan ('auto' switches at 2 and at 10 images)
+        with pinned_plan(plan, cc, hm):
+            full = pipe(x, sc, ce, iw, ih)['record'].clone()
+            one = pipe(x[2:3], sc[2:3], ce[2:3], iw[2:3], ih[2:3])['record']
+            assert torch.equal(one[0], full[2]), plan
+    # default plan: rows of different batch sizes may come from different plans - equal to fp32 rounding
     full = pipe(x, sc, ce, iw, ih)['record'].clone()
     one = pipe(x[2:3], sc[2:3], ce[2:3], iw[2:3], ih[2:3])['record']
-    assert torch.equal(one[0], full[2])
+    assert float((one[0] - full[2]).abs().max()) <= 2e-5 * float(full[2].abs().max())
 
 
 # ---- second device in one process (per-device kernel attributes) + real RCCL path -------------------------
