@@ -325,6 +325,11 @@ int specmi_regress_joints(specmi_handle* h, const float* vertices, int B, int V,
  * -> out (B,N,3), out[b,n] = R[b] points[b,n]. */
 int specmi_rotate_points(specmi_handle* h, const float* R, const float* points, int B, int N, float* out, void* stream);
 
+/* Which execution plan a trunk forward of (B, 3, H, W) takes under the handle's current options ("plan" and its thresholds):
+ * *mode = 0 throughput, 1 latency, 2 single; pair != 0: as specmi_trunk_forward_pair decides (the FIRST handle's options).  Callers
+ * that describe or log what ran ask here instead of re-deriving the rule (bench.py, SpecPipeline). */
+int specmi_trunk_plan(specmi_handle* h, int B, int H, int W, int pair, int32_t* mode);
+
 /* ---- in-launch hand-off state (round 5) ---------------------------------------------------
  * The latency / single plans hand data between workgroups INSIDE a launch (split-K tile tickets, the completion counters of the
  * persistent multi-layer walker: spec_amd/csrc/conv_persist.hip).  Those protocols keep a few device counters that every launch

@@ -12,6 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=1)
 ap.add_argument('--reps', type=int, default=20)
 ap.add_argument('--plan', default='auto')
+ap.add_argument('--grouped', default='auto', help="'auto' (what a caller gets), 1 or 0")
 args = ap.parse_args()
 torch.set_grad_enabled(False)
 dev = torch.device('cuda:0')
@@ -19,7 +20,8 @@ cc, hm, _, _ = bench.build_models(dev)
 for m in (cc, hm):
     m.set_plan(args.plan)
 x, sc, ce, iw, ih = bench.make_inputs(args.batch, dev, 7)
-g = GraphedPipeline(SpecPipeline(cc, hm, grouped=True), x, sc, ce, iw, ih)
+grouped = 'auto' if args.grouped == 'auto' else bool(int(args.grouped))
+g = GraphedPipeline(SpecPipeline(cc, hm, grouped=grouped), x, sc, ce, iw, ih)
 for _ in range(args.reps):
     g(*g.static_in)
 torch.cuda.synchronize()

@@ -116,6 +116,7 @@ PROTOTYPES = {
     'specmi_regress_joints': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                         C.c_void_p]),
     'specmi_rotate_points': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'specmi_trunk_plan': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
     'specmi_sync_status': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     'specmi_sync_reset': (C.c_int, [C.c_void_p, C.c_void_p]),
     'specmi_debug_poison_sync': (C.c_int, [C.c_void_p, C.c_uint32]),

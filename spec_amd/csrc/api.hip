@@ -766,8 +766,14 @@ static int launch_op(specmi_handle* h, const TrunkOp& op, const OpLaunch& L, con
             }
         }
         if ((rc = ensure_sk(h, conv_igemm_sk_ws_floats(L.a, pl.leaves / pl.unit, groups), conv_igemm_sk_tiles(L.a, groups)))) return rc;
-        LAUNCHCHK(h, launch_conv_igemm_sk(L.a, pl, h->sk, ctx, partner ? &partner->a : nullptr), op.label.c_str());
-        return SPECMI_OK;
+        rc = launch_conv_igemm_sk(L.a, pl, h->sk, ctx, partner ? &partner->a : nullptr);
+        if (rc != (int)hipErrorInvalidValue) {
+            LAUNCHCHK(h, rc, op.label.c_str());
+            return SPECMI_OK;
+        }
+        // the sliced launcher does not split the batch (activations past 32-bit addressing, plan = 'latency' pinned at a large
+        // batch or resolution): the throughput launcher below does - other bits (the plans differ anyway), never an error
+        (void)hipGetLastError();
     }
     int rc = L.family == 1 ? launch_conv_wino(L.a, ctx, partner ? &partner->a : nullptr)
                            : launch_conv_igemm(L.a, ctx, partner ? &partner->a : nullptr);
@@ -1719,6 +1725,13 @@ int specmi_rotate_points(specmi_handle* h, const float* R, const float* points, 
     if (!R || !points || !out || B <= 0 || N <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
     LaunchCtx ctx{(hipStream_t)stream, &h->prof, "eval.rotate_points"};
     LAUNCHCHK(h, launch_rotate_points(R, points, B, N, out, ctx), "rotate_points");
+    return SPECMI_OK;
+}
+
+int specmi_trunk_plan(specmi_handle* h, int B, int H, int W, int pair, int32_t* mode) {
+    if (!h) return SPECMI_ERR_ARG;
+    if (!mode || B <= 0 || H <= 0 || W <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
+    *mode = h->hrnet ? 0 : trunk_mode(h, B, H, W, pair != 0);
     return SPECMI_OK;
 }
 

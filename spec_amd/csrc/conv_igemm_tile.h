@@ -11,6 +11,15 @@
 #pragma once
 #include <type_traits>
 
+// The split-K / walker hand-offs (sc1 write-through stores, vmcnt(0), relaxed agent-scope ticket, sc1 loads: no release / acquire
+// fence) are the form MI355X_MICROARCH.md documents for gfx950 and are stress-tested there (tests/test_gpu_latency.py::
+// test_in_kernel_reduction_is_race_free, tests/test_gpu_round5.py); they are NOT the portable HIP memory-model form (release on the
+// ticket + acquire in the last arriver = buffer_wbl2 + buffer_inv per workgroup, measured 35 us per launch here).  Refuse to build
+// for anything else rather than run a protocol nobody validated there.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libspecmi's in-launch hand-offs are validated on gfx950 (MI355X) only: build with --offload-arch=gfx950"
+#endif
+
 #include "specmi_internal.h"
 
 namespace specmi {

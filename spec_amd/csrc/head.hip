@@ -151,14 +151,16 @@ __global__ void __launch_bounds__(256) fc_gemv_kernel(const GemvArgs a) {
         }
 #pragma unroll
         for (int u = 0; u < GKU; ++u) {
+            // a step past the row re-read the last real quad: BOTH operands are zeroed there, so that it adds exactly +0 even when
+            // that x quad holds Inf / NaN (0 * Inf = NaN would reach outputs the matrix-core path leaves finite)
             const bool in = k0 + u * 256 < a.Kp;
             const float wx = in ? wv[u].x : 0.f, wy = in ? wv[u].y : 0.f, wz = in ? wv[u].z : 0.f, ww = in ? wv[u].w : 0.f;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                acc[b] = fmaf(wx, xv[u][b].x, acc[b]);
-                acc[b] = fmaf(wy, xv[u][b].y, acc[b]);
-                acc[b] = fmaf(wz, xv[u][b].z, acc[b]);
-                acc[b] = fmaf(ww, xv[u][b].w, acc[b]);
+                acc[b] = fmaf(wx, in ? xv[u][b].x : 0.f, acc[b]);
+                acc[b] = fmaf(wy, in ? xv[u][b].y : 0.f, acc[b]);
+                acc[b] = fmaf(wz, in ? xv[u][b].z : 0.f, acc[b]);
+                acc[b] = fmaf(ww, in ? xv[u][b].w : 0.f, acc[b]);
             }
         }
         // all loads of the body first, then the arithmetic (the scheduler otherwise puts each load next to its use: serial round trips)

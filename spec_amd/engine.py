@@ -64,6 +64,14 @@ class Engine:
         else:
             _lib.check(self.h, self.lib.specmi_set_option_i32(self.h, name.encode(), int(value)))
 
+    PLAN_NAMES = ('throughput', 'latency', 'single')
+
+    def trunk_plan(self, B: int, H: int = 224, W: int = 224, pair: bool = False) -> str:
+        """The execution plan a trunk forward of (B, 3, H, W) takes under the current options ('throughput' | 'latency' | 'single')."""
+        mode = C.c_int32(0)
+        _lib.check(self.h, self.lib.specmi_trunk_plan(self.h, int(B), int(H), int(W), int(bool(pair)), C.byref(mode)))
+        return self.PLAN_NAMES[int(mode.value)]
+
     def sync_status(self) -> int:
         """Synchronises; 0 = every in-launch hand-off of this handle's persistent launches completed (include/specmi.h)."""
         err = C.c_int32(0)

@@ -36,11 +36,12 @@ class SpecPipeline:
         (the benchmark configuration), every trunk layer of BOTH networks is one grouped launch on one stream
         (``specmi_trunk_forward_pair``) instead of two trunks on two streams: half the launches, no stream join - what small
         batches want; results are bit-identical either way.  Falls back to ``overlap`` when the shapes differ.
-        ``'auto'`` (default) groups where it measured faster on MI355X (scripts/grouped_sweep.py, round 4,
-        profiles/r04_e_grouped_sweep.jsonl, r04_z_fill_sweep.txt): batch 1-2 (0.65 vs 0.74 ms at batch 1) and 11-16 (throughput
-        plan: 2.45 vs 2.59 ms at batch 16); at batch 3-10 the latency plan's sliced kernels run better as two trunks on two streams
-        (1.44 vs 1.54 ms at batch 8, 1.55 vs 1.59 at 10: one trunk's launch gaps and reduction tails hide under the other's
-        kernels), beyond 16 two streams are ahead as before.
+        ``'auto'`` (default) groups where it measured faster on MI355X (round 5, with the wave-split unit:
+        profiles/r05_c_wsplit_check.jsonl): batch 1-3 (0.50 vs 0.61 ms at batch 1, 0.69 vs 0.72 at 2, 0.88 vs 0.94 at 3) and
+        11-16 (throughput plan: 2.45 vs 2.59 ms at batch 16, profiles/r04_e_grouped_sweep.jsonl); at batch 4-10 the latency plan's
+        sliced kernels run better as two trunks on two streams (0.97 vs 1.01 ms at batch 4, 1.44 vs 1.54 at 8: one trunk's launch
+        gaps and reduction tails hide under the other's kernels), beyond 16 two streams are ahead as before.
+        ``auto_groups(nb)`` is that rule - the ONE place that holds it (bench.py asks ``launch_structure``).
         ``packed=True``: the kernels write every per-image output straight into ONE (B, 21294)-float record (the
         all-gather payload of config 4); the returned tensors are views of it and ``out['record']`` is the record
         itself, so collecting results over RCCL needs no packing copy."""
@@ -50,6 +51,36 @@ class SpecPipeline:
         self.packed = packed
         self.grouped = grouped
         self._side = {}
+
+    @staticmethod
+    def auto_groups(nb: int) -> bool:
+        """grouped='auto': both trunks per layer as one grouped launch at this batch size?"""
+        return nb <= 3 or 11 <= nb <= 16
+
+    def _can_group(self, images_shape, cam_shape) -> bool:
+        want_group = self.auto_groups(images_shape[0]) if self.grouped == 'auto' else bool(self.grouped)
+        return bool(want_group and self.hmr.use_cam and cam_shape == images_shape and
+                    getattr(self.hmr, '_backbone_id', 50) == getattr(self.camcalib, '_backbone_depth', 50) and
+                    getattr(self.hmr, 'conv_precision', 0) == 0 and getattr(self.camcalib, 'conv_precision', 0) == 0)
+
+    def launch_structure(self, images_shape, camcalib_shape=None) -> Dict[str, object]:
+        """What ``__call__`` does for inputs of these shapes: {'grouped': bool, 'structure': str, 'plan': str} - the launch
+        structure (the rule of ``__call__`` itself) and the trunk plan the library reports for it (``specmi_trunk_plan``)."""
+        images_shape = tuple(images_shape)
+        cam_shape = images_shape if camcalib_shape is None else tuple(camcalib_shape)
+        nb = images_shape[0]
+        can_group = self._can_group(images_shape, cam_shape)
+        if can_group:
+            structure = 'both trunks per layer as one grouped launch, one stream'
+        elif self.overlap and self.hmr.use_cam:
+            structure = 'two trunks on two streams'
+        else:
+            structure = 'one trunk after the other, one stream'
+        plan = None
+        eng = getattr(self.camcalib if can_group else self.hmr, '_engine', None)
+        if eng is not None:
+            plan = eng.trunk_plan(nb, images_shape[2], images_shape[3], pair=can_group)
+        return {'grouped': bool(can_group), 'structure': structure, 'plan': plan}
 
     def _side_stream(self, device, busy=None):
         """The stream CamCalib runs on.  Chosen by measurement when ``busy`` (a callable that enqueues the SPEC trunk on the
@@ -78,11 +109,7 @@ class SpecPipeline:
         if record is not None:
             v = eng.record_views(record)
             angles = (v['cam_vfov'], v['cam_pitch'], v['cam_roll'])
-        nb = images.shape[0]
-        want_group = (nb <= 2 or 11 <= nb <= 16) if self.grouped == 'auto' else bool(self.grouped)
-        can_group = (want_group and self.hmr.use_cam and cam_in.shape == images.shape and
-                     getattr(self.hmr, '_backbone_id', 50) == getattr(self.camcalib, '_backbone_depth', 50) and
-                     getattr(self.hmr, 'conv_precision', 0) == 0 and getattr(self.camcalib, 'conv_precision', 0) == 0)
+        can_group = self._can_group(tuple(images.shape), tuple(cam_in.shape))
         if can_group:
             ceng = self.camcalib.engine(device)
             cfeat, feat = ceng.trunk_pair(eng, cam_in, images)
