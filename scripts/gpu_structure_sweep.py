@@ -1,0 +1,48 @@
+"""Whole-step time (hipGraph replay) per batch: launch structure (grouped / two streams) x wave-split rule on / off x max-units
+threshold.  Output: gpurun_out/structure_sweep.jsonl"""
+import json, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from spec_amd import synth, assets
+from spec_amd.modules import HMR, CameraRegressorNetwork
+from spec_amd.pipeline import SpecPipeline, GraphedPipeline
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+torch.set_grad_enabled(False)
+dev = 'cuda:0'
+cs, hs = synth.camcalib_state(1001), synth.hmr_state(1002, True)
+assets.use_synthetic_assets(1003)
+cc = CameraRegressorNetwork(); cc.load_state_dict({k: t(v) for k, v in cs.items()})
+hm = HMR(use_cam=True, use_cam_feats=True); hm.load_state_dict({k: t(v) for k, v in hs.items()}, strict=False)
+cc = cc.to(dev).eval(); hm = hm.to(dev).eval()
+cc.commit(dev, freeze=True); hm.commit(dev, freeze=True)
+ce, he = cc.engine(dev), hm.engine(dev)
+x = t(synth.images(9, 16)).to(dev)
+sc, cen, iw, ih = [t(a).to(dev) for a in synth.bbox_inputs(9, 16, 640., 480.)]
+def opt(n, v):
+    ce.set_option(n, v); he.set_option(n, v)
+def step_ms(pp, b, iters=150):
+    g = GraphedPipeline(pp, x[:b].contiguous(), sc[:b].contiguous(), cen[:b].contiguous(), iw[:b].contiguous(), ih[:b].contiguous())
+    ins = g.static_in
+    for _ in range(10): g(*ins)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters): g(*ins)
+        e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / iters)
+    del g
+    return round(best, 4)
+out = open(os.path.join(ROOT, 'gpurun_out', 'structure_sweep.jsonl'), 'a')
+batches = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else '1,2,3,4,5,6,8,10,12,16').split(',')]
+for b in batches:
+    row = {'batch': b, 'plan': ce.trunk_plan(b, pair=True)}
+    for tag, kw in (('grouped', dict(grouped=True)), ('two_streams', dict(overlap=True, grouped=False))):
+        for ws, mu in ((0, 1000), (1, 500), (1, 1000), (1, 2000)):
+            opt('wsplit', ws); opt('wsplit_max_units', mu)
+            row[f'{tag}_ws{ws}_u{mu}'] = step_ms(SpecPipeline(cc, hm, **kw), b)
+    opt('wsplit', 1); opt('wsplit_max_units', 1000)
+    row['auto'] = step_ms(SpecPipeline(cc, hm), b)
+    line = json.dumps(row); print(line, flush=True); out.write(line + '\n'); out.flush()
