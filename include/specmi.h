@@ -29,7 +29,8 @@
  *   - every call runs on the device the handle was created for and restores the caller's current HIP device before
  *     it returns (a second device in the same process is fine; kernel attributes are set per device).
  *   - one handle per model instance; a handle is not thread-safe (the reference is
- *     single-threaded), distinct handles are independent.
+ *     single-threaded) and is driven from ONE stream at a time (its workspaces, split-K slabs and hand-off counters are per
+ *     handle: two streams in the same handle at once would share them); distinct handles are independent.
  *   - all arithmetic is IEEE fp32 (reference inference never enables AMP:
  *     spec/config.py:138, spec/tester.py:109-110); index tables are int32.
  */
@@ -118,15 +119,31 @@ const char* specmi_version(void);
  *         frame, scripts/camcalib_demo.py:95-102 at batch 1 - every convolution with K >= 512 is cut into K slices that run as ONE
  *         launch (the last slice of a tile to arrive folds the partial tiles and applies BN / residual / ReLU), layer3 / layer4
  *         3x3 convolutions leave Winograd for the sliced direct kernel;
- *     0 = auto (default): latency while the call carries no more pixels than N images of 224 x 224 - N = "latency_max_batch"
- *         (default 10) for specmi_trunk_forward_pair and the FC heads, "latency_max_batch_single" (default 16) for a single trunk
- *         (measured crossovers; one CamCalib frame at 600 x 1066 counts as 12.7 images) - throughput beyond.
+ *     3 = single (round 5): the latency plan with EVERY 3x3 convolution on the sliced direct kernels (no Winograd) - what batch
+ *         1-2 wants (scripts/camcalib_demo.py:95-102 never runs anything else): layer1 / layer2 conv2 measured 21 / 12 us faster
+ *         there at batch 1 / 2, slower from batch 4;
+ *     0 = auto (default): single while the call carries no more pixels than "single_max_batch" (default 2) images of 224 x 224,
+ *         latency up to N images - N = "latency_max_batch" (default 10) for specmi_trunk_forward_pair and the FC heads,
+ *         "latency_max_batch_single" (default 16) for a single trunk (measured crossovers; one CamCalib frame at 600 x 1066 counts
+ *         as 12.7 images) - throughput beyond.  specmi_trunk_plan reports the choice for a shape.
  *   WITHIN a plan an image's result is bit-identical whatever the batch size, the grouping (specmi_trunk_forward_pair) or the
  *   replay (every k sum has one association fixed by the layer's shape: the latency plan's is a canonical tree - leaves of L chunks,
  *   groups of G leaves - of which a workgroup computes a leaf, a group or the whole by batch size; 8 x 256 rank shards == 2048
  *   unsharded).  BETWEEN plans the last bits differ (other association of the same products, other algorithm on layer3 / layer4
- *   conv2); both meet the 1e-4 contract on every reference fixture (tests/test_gpu_e2e.py).  Callers that need bit-reproducibility
- *   across batch sizes on both sides of the switch pin a plan.
+ *   conv2); all meet the 1e-4 contract on every reference fixture (tests/test_gpu_e2e.py).  Callers that need bit-reproducibility
+ *   across batch sizes on both sides of a switch pin a plan - the library's own batch-splitting callers do (spec_amd.tester runs a
+ *   whole folder under ONE plan whatever --frame_batch; bench.py pins 'throughput' for rank-sharded runs).
+ *   Round 5, same bits as before (speed choices inside the latency / single plans):
+ *     "wsplit" (default 1): sliced layers whose 64x64 launch would need slabs run on the wave-split unit of the SAME canonical tree
+ *       (spec_amd/csrc/conv_wsplit.hip: a 32x32 tile per workgroup, a group's leaves on its four waves, 4 KB group slabs or none) while
+ *       the launch has at most "wsplit_max_units" (2000, trunk pair) / "wsplit_max_units_single" (500) leaf-units; 0 = never; 2 / 3 =
+ *       always with one group / all groups per workgroup (tests).  "conv2d_wsplit" (specmi_conv2d only: 0 | 2 | 3).
+ *     "persist" (default 0, opt-in): every run of implicit-GEMM layers of the latency / single plan as ONE persistent launch
+ *       (spec_amd/csrc/conv_persist.hip: resident workgroups walk the layers, completion counters instead of kernel boundaries,
+ *       write-through hand-offs).  Bit-identical to the per-layer launches and measured SLOWER on MI355X (0.68 vs 0.55 ms for the trunk
+ *       pair at batch 1, profiles/r05_a_persist_ab.jsonl) - kept for the record and for other parts; at most two such forwards may be
+ *       in flight per device (the grid must be co-resident).  "persist_wgs" (512 pair / 256 single), "persist_l2_prefetch",
+ *       "persist_spin_limit", "persist_min_run"; specmi_sync_status reports a spin that gave up.
  *   Tuning / tests: "latency_target_wgs" (256), "latency_min_chunks" (4), "latency_wino_min_tiles" (128), "latency_fill_wgs" (240),
  *   "latency_force_unit" (0 = by batch, 1 / 2 / 3 = a leaf / a group / the whole K per workgroup: same bits),
  *   "conv2d_sk" (specmi_conv2d only: 0 = throughput kernel, -1 = the latency plan's rule, n > 1 = n leaves),
