@@ -149,7 +149,11 @@ const char* specmi_version(void);
  *   "conv2d_sk" (specmi_conv2d only: 0 = throughput kernel, -1 = the latency plan's rule, n > 1 = n leaves),
  *   "smpl_skin_split" (-1 = by batch: three waves per 32-vertex group up to 64 images, one beyond; 0 / 1 = never / always: same bits),
  *   "head_fuse" (default 3; bit 0: the regressor's state init rides in the pooling launch, bit 1: head_final's work is done by the
- *   SMPL pose kernel of specmi_hmr_forward / specmi_hmr_regress - two graph nodes less per step, same bits). */
+ *   SMPL pose kernel of specmi_hmr_forward / specmi_hmr_regress - two graph nodes less per step, same bits);
+ *   "tail_fuse" (default 1, round 5): at small batches each network's tail is ONE launch - HMR: avg-pool + state init -> composed
+ *   regressor map -> pose chains; CamCalib (specmi_camcalib_head_decode): avg-pool -> three heads -> decode - instead of three: the
+ *   first workgroups pool, every workgroup waits on one counter, the last arriver per image pair runs the epilogue (same code, same
+ *   bits; spec_amd/csrc/head.hip). */
 int specmi_set_option_i32(specmi_handle* h, const char* name, int value);
 int specmi_set_option_f32(specmi_handle* h, const char* name, float value);
 
@@ -181,6 +185,15 @@ int specmi_trunk_forward_pair(specmi_handle* ha, specmi_handle* hb, const float*
  * Linear chains) from a trunk feature map (B,fh,fw,C) NHWC -> vfov / pitch / roll logits (B,nbins) each. */
 int specmi_camcalib_head_forward(specmi_handle* h, const float* feat_nhwc, int B, int fh, int fw, float* logits_vfov,
                                  float* logits_pitch, float* logits_roll, void* stream);
+
+/* specmi_camcalib_head_forward + specmi_camcalib_decode in one call (round 5): at small batches (the GEMV path of the latency /
+ * single plans, one Linear layer per head, option "tail_fuse" default 1) the avg-pool, the three heads and the decode run as ONE
+ * launch (spec_amd/csrc/head.hip: tail_gemv_kernel - the code of the three kernels, same bits); otherwise the separate kernels.
+ * Replaces camcalib/model.py:74-80 + camcalib/cam_utils.py:110-133 + scripts/camcalib_demo.py:129 + spec/utils/cam_params.py:37-46.
+ * Outputs as in the two calls (any of vfov .. K may be NULL); "angle_ld" applies to vfov / pitch / roll. */
+int specmi_camcalib_head_decode(specmi_handle* h, const float* feat_nhwc, int B, int fh, int fw, float* logits_vfov,
+                                float* logits_pitch, float* logits_roll, const float* img_h, const float* img_w, float* vfov,
+                                float* pitch, float* roll, float* f_pix, float* cam_rotmat, float* cam_intrinsics, void* stream);
 
 /* CameraRegressorNetwork.forward (camcalib/model.py:72-81): images (B,3,H,W) NCHW fp32 ->
  * three (B,256) logit tensors [vfov, pitch, roll]. */

@@ -472,6 +472,7 @@ static int sync_for_growth(specmi_handle* h, const char* what) {
 static void reset_sync_state(specmi_handle* h, hipStream_t s) {
     if (h->sk.cnt) (void)hipMemsetAsync(h->sk.cnt, 0, (size_t)h->sk.ncnt * 4, s);
     if (h->pctl) (void)hipMemsetAsync(h->pctl, 0, sizeof(PersistCtl), s);
+    if (h->tail_ctl) (void)hipMemsetAsync(h->tail_ctl, 0, (size_t)specmi_handle::kTailCtlWords * 4, s);
     (void)hipGetLastError();
 }
 
@@ -521,6 +522,10 @@ static int ensure_ws(specmi_handle* h, int B, int H, int W) {
     if ((rc = dev_alloc(h, (size_t)Bp32 * SMPL_KQ * 8 * 4, (void**)&h->pf_ws, h->ws_allocs))) return rc;
     if ((rc = dev_alloc(h, (size_t)Bp32 * 288 * 4, (void**)&h->A_ws, h->ws_allocs))) return rc;
     if ((rc = dev_alloc(h, (size_t)Bp * 72 * 4, (void**)&h->pj_ws, h->ws_allocs))) return rc;
+    if (!h->tail_ctl) {   // (once: captured graphs keep naming it)
+        HIPCHK(h, hipMalloc((void**)&h->tail_ctl, (size_t)specmi_handle::kTailCtlWords * 4));
+        HIPCHK(h, hipMemset(h->tail_ctl, 0, (size_t)specmi_handle::kTailCtlWords * 4));
+    }
     HIPCHK(h, hipMemset(h->pf_ws, 0, (size_t)Bp32 * SMPL_KQ * 8 * 4));   // rows 218..223 of the feature operand stay zero
     HIPCHK(h, hipMemset(h->A_ws, 0, (size_t)Bp32 * 288 * 4));
     h->ws_B = Bw;
@@ -1056,12 +1061,31 @@ static OutLd out_ld(specmi_handle* h) {
 // defer != nullptr: head_final is not launched; *defer describes it for the SMPL pose kernel, which does its work (run_smpl)
 static int run_head(specmi_handle* h, const float* feat, int B, int fh, int fw, const float* R, const float* K,
                     const float* img_h, float* pred_pose, float* pred_shape, float* pred_cam, float* pred_pose_6d,
-                    const OutLd& old, hipStream_t s, HeadFinal* defer = nullptr) {
+                    const OutLd& old, hipStream_t s, HeadFinal* defer = nullptr, bool* pose_done = nullptr) {
     int rc;
     const int ucf = opt_i(h, "use_cam_feats", 0);
     const int F = h->feat_ch, LD = h->xc_ld;
     if (ucf && (!R || !K || !img_h))
         return fail(h, SPECMI_ERR_ARG, "use_cam_feats needs cam_rotmat, cam_intrinsics and img_h");
+    if (pose_done) *pose_done = false;
+    // Small batches (round 5, option "tail_fuse", default 1): avg-pool + state init -> composed regressor map -> pose chains as ONE
+    // launch (head.hip: tail_gemv_kernel; the code of the three kernels, same bits).  Needs the collapsed head, the GEMV path,
+    // head_final deferred into the pose chain and a map that pools in one part.
+    if (defer && pose_done && opt_i(h, "tail_fuse", 1) && use_latency_heads(h, B) && h->has_head_c && opt_i(h, "head_collapse", 1) &&
+        h->head_c.w_rm && fh * fw < 64 && (B + 1) / 2 + 2 <= specmi_handle::kTailCtlWords && h->tail_ctl && !h->prof.on) {
+        const HeadInit hi{h->xc, h->init_pose, h->init_shape, h->init_cam, R, K, img_h, ucf, F, LD};
+        defer->state = h->h1; defer->ld_state = 1024;
+        defer->pred_pose = pred_pose; defer->pred_shape = pred_shape; defer->pred_cam = pred_cam; defer->pred_pose_6d = pred_pose_6d;
+        defer->ld_pose = old.pose; defer->ld_shape = old.shape; defer->ld_cam = old.cam; defer->ld_p6d = old.p6d;
+        defer->rot_ws = h->rot_ws; defer->betas_ws = h->betas_ws; defer->cam_ws = h->cam_ws;
+        const FcGemv hd{h->xc, h->head_c.w_rm, h->head_c.shift, nullptr, h->h1};
+        LaunchCtx ctx{s, &h->prof, "head.tail"};
+        const int lrc = launch_tail_hmr(hd, h->head_c.nout, h->head_c.Kp, LD, 1024, B, feat, h->xc, fh * fw, F, hi, h->tail_ctl,
+                                        specmi_handle::kTailCtlWords, h->smpl, h->pf_ws, h->A_ws, h->pj_ws, *defer, ctx);
+        if (lrc == 0) { *pose_done = true; return SPECMI_OK; }
+        if (lrc != (int)hipErrorInvalidValue) LAUNCHCHK(h, lrc, "hmr tail");
+        (void)hipGetLastError();
+    }
     {
         // the IEF state columns are written by extra workgroups of the pooling launch (option "head_fuse" bit 0, default on; large
         // maps pool in parts and keep head_init as its own launch)
@@ -1120,7 +1144,7 @@ static int run_head(specmi_handle* h, const float* feat, int B, int fh, int fw, 
 static int run_smpl(specmi_handle* h, const float* rotmat, const float* betas, const float* cam, int B, const float* R,
                     const float* K, const float* bbox_scale, const float* bbox_center, const float* img_w,
                     const float* img_h, float* vertices, float* joints3d, float* joints2d, float* cam_t,
-                    const OutLd& old, hipStream_t s, const HeadFinal* final_ = nullptr) {
+                    const OutLd& old, hipStream_t s, const HeadFinal* final_ = nullptr, bool pose_done = false) {
     const int use_cam = opt_i(h, "use_cam", 0);
     if (use_cam && (!R || !K || !bbox_scale || !bbox_center || !img_w || !img_h))
         return fail(h, SPECMI_ERR_ARG, "use_cam needs cam_rotmat, cam_intrinsics, bbox_scale, bbox_center, img_w, img_h");
@@ -1139,6 +1163,7 @@ static int run_smpl(specmi_handle* h, const float* rotmat, const float* betas, c
     a.normalize_joints2d = use_cam ? 0 : 1;  // spec/models/hmr.py:111 vs :119
     a.skin_split = opt_i(h, "smpl_skin_split", -1);
     a.final_ = final_;
+    a.pose_done = pose_done;
     LaunchCtx ctx{s, &h->prof, "smpl"};
     LAUNCHCHK(h, launch_smpl(h->smpl, a, ctx), "smpl");
     return SPECMI_OK;
@@ -1182,6 +1207,7 @@ int specmi_destroy(specmi_handle* h) {
     free_pool(h->ws_retired);
     for (auto& t : h->persist_tables) if (t.dev) (void)hipFree(t.dev);
     if (h->pctl) (void)hipFree(h->pctl);
+    if (h->tail_ctl) (void)hipFree(h->tail_ctl);
     if (h->resize_tab) (void)hipFree(h->resize_tab);
     hrnet_free(h->hrnet);
     delete h;
@@ -1408,6 +1434,37 @@ static int run_camcalib_head(specmi_handle* h, const float* f, int B, int fh, in
     return SPECMI_OK;
 }
 
+int specmi_camcalib_head_decode(specmi_handle* h, const float* feat, int B, int fh, int fw, float* lv, float* lp, float* lr,
+                                const float* img_h, const float* img_w, float* vfov, float* pitch, float* roll, float* f_pix,
+                                float* R, float* K, void* stream) {
+    ENTER(h); NEED_COMMIT(h);
+    if (h->kind != SPECMI_MODEL_CAMCALIB) return fail(h, SPECMI_ERR_STATE, "handle is not a CamCalib model");
+    if (!feat || !lv || !lp || !lr || B <= 0 || fh <= 0 || fw <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = ensure_ws(h, B, 32, 32))) return rc;
+    const long ld_ang = opt_i(h, "angle_ld", 0) > 0 ? opt_i(h, "angle_ld", 0) : 1;
+    const FcW& f0 = h->fc_cam[0][0];
+    // small batches (round 5, option "tail_fuse"): avg-pool -> the three heads -> decode as ONE launch (head.hip: tail_gemv_kernel)
+    if (opt_i(h, "tail_fuse", 1) && use_latency_heads(h, B) && h->fc_layers == 1 && f0.w_rm && fh * fw < 64 && f0.Kp == h->feat_ch &&
+        h->fc_cam[1][0].nout == f0.nout && h->fc_cam[2][0].nout == f0.nout && h->fc_cam[1][0].Kp == f0.Kp && h->fc_cam[2][0].Kp == f0.Kp &&
+        (B + 1) / 2 + 2 <= specmi_handle::kTailCtlWords && h->tail_ctl && !h->prof.on) {
+        float* outs[3] = {lv, lp, lr};
+        FcGemv hd[3];
+        for (int i = 0; i < 3; ++i) hd[i] = FcGemv{h->xf, h->fc_cam[i][0].w_rm, h->fc_cam[i][0].shift, nullptr, outs[i]};
+        LaunchCtx ctx{s, &h->prof, "camcalib.tail"};
+        const int lrc = launch_tail_camcalib(hd, f0.nout, f0.Kp, B, feat, h->xf, fh * fw, h->feat_ch, h->tail_ctl, specmi_handle::kTailCtlWords,
+                                             img_h, img_w, vfov, pitch, roll, f_pix, R, K, ld_ang, ctx);
+        if (lrc == 0) return SPECMI_OK;
+        if (lrc != (int)hipErrorInvalidValue) LAUNCHCHK(h, lrc, "camcalib tail");
+        (void)hipGetLastError();
+    }
+    if ((rc = run_camcalib_head(h, feat, B, fh, fw, lv, lp, lr, s))) return rc;
+    LaunchCtx ctx{s, &h->prof, "camcalib.decode"};
+    LAUNCHCHK(h, launch_camcalib_decode(lv, lp, lr, B, f0.nout, img_h, img_w, vfov, pitch, roll, f_pix, R, K, ld_ang, ctx), "camcalib_decode");
+    return SPECMI_OK;
+}
+
 int specmi_camcalib_decode(specmi_handle* h, const float* lv, const float* lp, const float* lr, int B, int nbins,
                            const float* img_h, const float* img_w, float* vfov, float* pitch, float* roll, float* f_pix,
                            float* R, float* K, void* stream) {
@@ -1502,11 +1559,12 @@ int specmi_hmr_forward(specmi_handle* h, const float* images, int B, int H, int 
     const OutLd old = out_ld(h);
     HeadFinal fin;
     const bool fuse = (opt_i(h, "head_fuse", 3) & 2) != 0;     // head_final's work inside the SMPL pose kernel (same bits, one node less)
+    bool pose_done = false;
     if ((rc = run_head(h, f, B, fh, fw, R, K, img_h, out->pred_pose, out->pred_shape, out->pred_cam, out->pred_pose_6d, old, s,
-                       fuse ? &fin : nullptr)))
+                       fuse ? &fin : nullptr, fuse ? &pose_done : nullptr)))
         return rc;
     return run_smpl(h, h->rot_ws, h->betas_ws, h->cam_ws, B, R, K, bbox_scale, bbox_center, img_w, img_h,
-                    out->smpl_vertices, out->smpl_joints3d, out->smpl_joints2d, out->pred_cam_t, old, s, fuse ? &fin : nullptr);
+                    out->smpl_vertices, out->smpl_joints3d, out->smpl_joints2d, out->pred_cam_t, old, s, fuse ? &fin : nullptr, pose_done);
 }
 
 int specmi_hmr_regress(specmi_handle* h, const float* feat, int B, int fh, int fw, const float* R, const float* K,
@@ -1521,11 +1579,12 @@ int specmi_hmr_regress(specmi_handle* h, const float* feat, int B, int fh, int f
     const OutLd old = out_ld(h);
     HeadFinal fin;
     const bool fuse = (opt_i(h, "head_fuse", 3) & 2) != 0;     // head_final's work inside the SMPL pose kernel (same bits, one node less)
+    bool pose_done = false;
     if ((rc = run_head(h, feat, B, fh, fw, R, K, img_h, out->pred_pose, out->pred_shape, out->pred_cam, out->pred_pose_6d, old, s,
-                       fuse ? &fin : nullptr)))
+                       fuse ? &fin : nullptr, fuse ? &pose_done : nullptr)))
         return rc;
     return run_smpl(h, h->rot_ws, h->betas_ws, h->cam_ws, B, R, K, bbox_scale, bbox_center, img_w, img_h,
-                    out->smpl_vertices, out->smpl_joints3d, out->smpl_joints2d, out->pred_cam_t, old, s, fuse ? &fin : nullptr);
+                    out->smpl_vertices, out->smpl_joints3d, out->smpl_joints2d, out->pred_cam_t, old, s, fuse ? &fin : nullptr, pose_done);
 }
 
 int specmi_conv2d(specmi_handle* h, const float* x, int B, int H, int W, int Cin, const float* w_host,
@@ -1770,6 +1829,10 @@ int specmi_debug_poison_sync(specmi_handle* h, uint32_t value) {
     if (h->sk.cnt) {
         std::vector<unsigned> v((size_t)h->sk.ncnt, value);
         HIPCHK(h, hipMemcpy(h->sk.cnt, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (h->tail_ctl) {
+        std::vector<unsigned> v((size_t)specmi_handle::kTailCtlWords, value);
+        HIPCHK(h, hipMemcpy(h->tail_ctl, v.data(), v.size() * 4, hipMemcpyHostToDevice));
     }
     if (h->pctl) {
         PersistCtl c;

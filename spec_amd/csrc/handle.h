@@ -97,6 +97,8 @@ struct specmi_handle {
     struct PersistTable { std::vector<unsigned char> img; void* dev = nullptr; int nl = 0; };
     std::vector<PersistTable> persist_tables;
     PersistCtl* pctl = nullptr;         // device control block of this handle's persistent launches (one launch at a time per handle)
+    unsigned* tail_ctl = nullptr;       // device: counters of the fused tails (head.hip: tail_gemv_kernel), kTailCtlWords zeroed words
+    static constexpr int kTailCtlWords = 64;
 
     Profiler prof;
 };

@@ -12,9 +12,12 @@
 //     f = h/2/tan(vfov/2) (scripts/camcalib_demo.py:129), R = euler2matrix([pitch,0,roll])
 //     via the quaternion route and K with K[2,2] = 0 (spec/utils/cam_params.py:37-46).
 //     One wave per (image, head): 64-lane shuffle reductions, no LDS traffic for the softmax.
-#include "specmi_internal.h"
+#include "smpl_pose_body.h"
 
 namespace specmi {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(256) head_init_kernel(const HeadInit a) { head_init_row(a, blockIdx.x, threadIdx.x, blockDim.x); }
 
@@ -203,58 +206,284 @@ int launch_fc_gemv(const FcGemv* heads, int nheads, int N, int Kp, int ldx, int 
     return (int)hipGetLastError();
 }
 
-__global__ void __launch_bounds__(192) camcalib_decode_kernel(const float* __restrict__ lv, const float* __restrict__ lp,
-                                                               const float* __restrict__ lr, int nbins,
-                                                               const float* __restrict__ img_h,
-                                                               const float* __restrict__ img_w, float* __restrict__ vfov,
-                                                               float* __restrict__ pitch, float* __restrict__ roll,
-                                                               float* __restrict__ f_pix, float* __restrict__ R,
-                                                               float* __restrict__ K, long ld_ang) {
-    __shared__ float ang[3];
-    const int b = blockIdx.x;
+// soft-argmax decode of image b: waves 0..2 = vfov / pitch / roll (a fourth wave idles), `ang` = 3 floats of LDS.  COHERENT: the
+// logits were written earlier in the SAME launch by other workgroups (fused tail: write-through stores) -> agent-scope loads.
+struct DecodeArgs {
+    const float *lv, *lp, *lr; int nbins; const float *img_h, *img_w;
+    float *vfov, *pitch, *roll, *f_pix, *R, *K; long ld_ang;
+};
+template <bool COHERENT>
+__device__ __forceinline__ void camcalib_decode_image(const DecodeArgs& a, int b, float* ang) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const float* row = (wave == 0 ? lv : wave == 1 ? lp : lr) + (size_t)b * nbins;
-    float mx = -INFINITY;
-    for (int i = lane; i < nbins; i += 64) mx = fmaxf(mx, row[i]);
-    mx = wave_max(mx);
-    float se = 0.f, sp = 0.f;
-    for (int i = lane; i < nbins; i += 64) {
-        const float e = expf(row[i] - mx);
-        se += e;
-    }
-    se = wave_sum(se);
-    for (int i = lane; i < nbins; i += 64) {
-        const float pr = expf(row[i] - mx) / se;  // softmax, then expectation of the index
-        sp += pr * (float)i;
-    }
-    sp = wave_sum(sp);
-    if (lane == 0) {
-        const float s = sp / (float)(nbins - 1) * 2.0f - 1.0f;                  // softargmax1d normalisation
-        // soft_idx_to_angle: (max - min) is a python double rounded to fp32 when it meets the tensor
-        const float span = wave == 0 ? (float)(2.1 - 0.2617) : (float)(0.6 - (-0.6));
-        const float lo = wave == 0 ? (float)0.2617 : (float)-0.6;
-        ang[wave] = span * ((s + 1.0f) / 2.0f) + lo;
+    if (wave < 3) {
+        const float* row = (wave == 0 ? a.lv : wave == 1 ? a.lp : a.lr) + (size_t)b * a.nbins;
+        auto X = [&](int i) { return COHERENT ? __hip_atomic_load(row + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : row[i]; };
+        float mx = -INFINITY;
+        for (int i = lane; i < a.nbins; i += 64) mx = fmaxf(mx, X(i));
+        mx = wave_max(mx);
+        float se = 0.f, sp = 0.f;
+        for (int i = lane; i < a.nbins; i += 64) {
+            const float e = expf(X(i) - mx);
+            se += e;
+        }
+        se = wave_sum(se);
+        for (int i = lane; i < a.nbins; i += 64) {
+            const float pr = expf(X(i) - mx) / se;  // softmax, then expectation of the index
+            sp += pr * (float)i;
+        }
+        sp = wave_sum(sp);
+        if (lane == 0) {
+            const float s = sp / (float)(a.nbins - 1) * 2.0f - 1.0f;                  // softargmax1d normalisation
+            // soft_idx_to_angle: (max - min) is a python double rounded to fp32 when it meets the tensor
+            const float span = wave == 0 ? (float)(2.1 - 0.2617) : (float)(0.6 - (-0.6));
+            const float lo = wave == 0 ? (float)0.2617 : (float)-0.6;
+            ang[wave] = span * ((s + 1.0f) / 2.0f) + lo;
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         const float vf = ang[0], pt = ang[1], rl = ang[2];
-        if (vfov) vfov[(size_t)b * ld_ang] = vf;
-        if (pitch) pitch[(size_t)b * ld_ang] = pt;
-        if (roll) roll[(size_t)b * ld_ang] = rl;
-        const float h = img_h ? img_h[b] : 0.f, w = img_w ? img_w[b] : 0.f;
+        if (a.vfov) a.vfov[(size_t)b * a.ld_ang] = vf;
+        if (a.pitch) a.pitch[(size_t)b * a.ld_ang] = pt;
+        if (a.roll) a.roll[(size_t)b * a.ld_ang] = rl;
+        const float h = a.img_h ? a.img_h[b] : 0.f, w = a.img_w ? a.img_w[b] : 0.f;
         const float f = h / 2.0f / tanf(vf / 2.0f);
-        if (f_pix) f_pix[b] = f;
-        build_cam_RK(pt, rl, f, w, h, R ? R + (size_t)b * 9 : nullptr, K ? K + (size_t)b * 9 : nullptr);
+        if (a.f_pix) a.f_pix[b] = f;
+        build_cam_RK(pt, rl, f, w, h, a.R ? a.R + (size_t)b * 9 : nullptr, a.K ? a.K + (size_t)b * 9 : nullptr);
     }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(192) camcalib_decode_kernel(const DecodeArgs a) {
+    __shared__ float ang[3];
+    camcalib_decode_image<false>(a, blockIdx.x, ang);
 }
 
 int launch_camcalib_decode(const float* lv, const float* lp, const float* lr, int B, int nbins, const float* img_h,
                            const float* img_w, float* vfov, float* pitch, float* roll, float* f_pix, float* R,
                            float* K, long ld_ang, const LaunchCtx& ctx) {
     ProfScope ps(ctx, "camcalib_decode", 0.0, 4.0 * B * (3.0 * nbins + 24));
-    hipLaunchKernelGGL(camcalib_decode_kernel, dim3(B), dim3(192), 0, ctx.stream, lv, lp, lr, nbins, img_h, img_w, vfov,
-                       pitch, roll, f_pix, R, K, ld_ang);
+    const DecodeArgs a{lv, lp, lr, nbins, img_h, img_w, vfov, pitch, roll, f_pix, R, K, ld_ang};
+    hipLaunchKernelGGL(camcalib_decode_kernel, dim3(B), dim3(192), 0, ctx.stream, a);
     return (int)hipGetLastError();
+}
+
+// ---- fused tails (round 5) ---------------------------------------------------------------------------------------------------
+// Behind each trunk the small-batch step ran 3 (CamCalib: avg-pool -> three heads -> decode) and 3 (HMR: avg-pool + state init ->
+// composed regressor map -> pose chain) graph nodes of 4.5-7 us each whose work is a few hundred KB.  Here each tail is ONE launch
+// of the GEMV grid:
+//   phase A  the first workgroups pool the trunk's feature map (one (image, channel quad) per thread, the order of avgpool_kernel)
+//            and write the IEF state columns (head_init_row) with write-through stores, drain them and bump ONE counter;
+//   phase B  every workgroup requests its weight rows FIRST (they depend on nothing), waits for the counter (bounded spin), reads
+//            the pooled rows with agent-scope loads and runs the GEMV exactly as fc_gemv_kernel does (same lane-local k order, same
+//            shuffle tree: same bits); outputs leave with write-through stores, one ticket per image slab (blockIdx.z);
+//   epilogue the last workgroup of a slab to arrive decodes its images (CamCalib: camcalib_decode_image) or runs their pose chains
+//            (HMR: smpl_pose_body, one wave per image) - the code of the stand-alone kernels on agent-scope loads.
+// The hand-offs are the write-through form of conv_igemm_tile.h (gfx950: MI355X_MICROARCH.md, inter-workgroup visibility).  The
+// producers are the lowest-numbered workgroups of the grid and wait for nobody; every spin is bounded.
+struct PoseTail {
+    const float *Jt, *Jd; const int* parents; float *feat, *Afrag, *posed_j; HeadFinal fin;
+};
+struct TailArgs {
+    GemvArgs g;
+    const float* map; float* pool_out; int HW, C4, pool_ld, pool_total, npool, ninit;
+    HeadInit init;
+    unsigned* ctl;        // [0] phase-A arrivals, [1] slabs finished, [2 + z] arrivals of slab z; all zero between launches
+    unsigned spin_limit;
+    DecodeArgs dec;
+    PoseTail pose;
+};
+
+template <int NB, int EPI>   // EPI: 1 = CamCalib decode, 2 = HMR pose chain
+__global__ void __launch_bounds__(256) tail_gemv_kernel(const TailArgs a) {
+    __shared__ float ang[3];
+    __shared__ int flag;
+    const GemvHead& hd = a.g.hd[blockIdx.y];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    // ---- phase A ---------------------------------------------------------------------------------------------------------------
+    if (w < a.npool + a.ninit) {
+        if (w < a.npool) {
+            const int i = w * 256 + threadIdx.x;
+            if (i < a.pool_total) {
+                const int c4 = i % a.C4, b = i / a.C4;
+                const f32x4* src = reinterpret_cast<const f32x4*>(a.map) + (size_t)b * a.HW * a.C4 + c4;
+                f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 7
+                for (int p = 0; p < a.HW; ++p) {
+                    const f32x4 v = src[(size_t)p * a.C4];
+                    s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+                }
+                f32x4 q;    // PyTorch's mean is sum / count
+#pragma unroll
+                for (int e = 0; e < 4; ++e) q[e] = s[e] / (float)a.HW;
+                const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(a.pool_out, 0, (unsigned)a.g.B * (unsigned)a.pool_ld * 4u, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q), prs, (unsigned)((b * a.pool_ld + c4 * 4) * 4), 0, /*sc1*/ 16);
+            }
+        } else {
+            head_init_row<true>(a.init, w - a.npool, threadIdx.x, 256);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(a.ctl + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- phase B: fc_gemv_kernel with the weights requested before the wait ------------------------------------------------------
+    const int n = blockIdx.x * 4 + wave;
+    const int b0 = blockIdx.z * NB;
+    const int nb = min(NB, a.g.B - b0);
+    const bool col = n < a.g.N;
+    const float* wrow = hd.w + (size_t)(col ? n : 0) * a.g.Kp;
+    float acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = 0.f;
+    int xr[NB];    // rows past the batch re-read the last image (results discarded)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) xr[b] = b0 + (b < nb ? b : nb - 1);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hd.x), 0, (unsigned)a.g.B * (unsigned)a.g.ldx * 4u, 0x00020000);
+    bool waited = false;
+    for (int k0 = lane * 4; k0 < a.g.Kp; k0 += 256 * GKU) {
+        float4 wv[GKU], xv[GKU][NB];
+#pragma unroll
+        for (int u = 0; u < GKU; ++u) {
+            const int k = min(k0 + u * 256, a.g.Kp - 4);
+            wv[u] = *reinterpret_cast<const float4*>(wrow + k);
+        }
+        if (!waited) {
+            if (threadIdx.x == 0) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(a.ctl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(a.npool + a.ninit)) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > a.spin_limit) break;
+                }
+            }
+            __syncthreads();
+            waited = true;
+        }
+#pragma unroll
+        for (int u = 0; u < GKU; ++u) {
+            const int k = min(k0 + u * 256, a.g.Kp - 4);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (unsigned)((xr[b] * a.g.ldx + k) * 4), 0, /*sc1*/ 16));
+                xv[u][b].x = q[0]; xv[u][b].y = q[1]; xv[u][b].z = q[2]; xv[u][b].w = q[3];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GKU; ++u) {
+            const bool in = k0 + u * 256 < a.g.Kp;
+            const float wx = in ? wv[u].x : 0.f, wy = in ? wv[u].y : 0.f, wz = in ? wv[u].z : 0.f, ww = in ? wv[u].w : 0.f;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                acc[b] = fmaf(wx, in ? xv[u][b].x : 0.f, acc[b]);
+                acc[b] = fmaf(wy, in ? xv[u][b].y : 0.f, acc[b]);
+                acc[b] = fmaf(wz, in ? xv[u][b].z : 0.f, acc[b]);
+                acc[b] = fmaf(ww, in ? xv[u][b].w : 0.f, acc[b]);
+            }
+        }
+        // all x loads of the body first, then the arithmetic (as in fc_gemv_kernel: the scheduler otherwise pairs each load with its use)
+        __builtin_amdgcn_sched_group_barrier(0x020, GKU * NB, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, GKU * NB * 8, 0);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        float v = acc[b];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        acc[b] = v;
+    }
+    if (col && lane < nb) {
+        float v = 0.f;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            if (lane == b) v = acc[b];
+        const size_t o = (size_t)(b0 + lane) * a.g.ldo + n;
+        v += hd.bias[n];
+        if (hd.res) v += hd.res[o];
+        __hip_atomic_store(hd.out + o, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- epilogue by the slab's last arriver ----------------------------------------------------------------------------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned per_slab = gridDim.x * gridDim.y;
+        const unsigned ticket = __hip_atomic_fetch_add(a.ctl + 2 + blockIdx.z, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = ticket == per_slab - 1;
+        if (last) {
+            __hip_atomic_store(a.ctl + 2 + blockIdx.z, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the last slab to finish frees the phase-A counter: every workgroup has passed its wait by then
+            const unsigned done = __hip_atomic_fetch_add(a.ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (done == gridDim.z - 1) {
+                __hip_atomic_store(a.ctl + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.ctl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        flag = last;
+    }
+    __syncthreads();
+    if (!flag) return;
+    if (EPI == 1) {
+        for (int b = 0; b < nb; ++b) camcalib_decode_image<true>(a.dec, b0 + b, ang);
+    } else {
+        if (wave < nb)
+            smpl_pose_body<true, true>(b0 + wave, lane, nullptr, nullptr, a.pose.Jt, a.pose.Jd, a.pose.parents, a.pose.feat, a.pose.Afrag,
+                                       a.pose.posed_j, a.pose.fin);
+    }
+}
+
+// One launch for: avg-pool of `map` (B, HW, C) into pool_out rows (stride pool_ld) [+ IEF state columns `init`] -> up to three GEMV
+// heads over those rows -> epilogue (dec != nullptr: CamCalib decode; pose != nullptr: HMR pose chain).  ctl: >= 2 + ceil(B / 2) zeroed
+// words.  Returns hipErrorInvalidValue for shapes the fused form does not take (the caller launches the separate kernels).
+int launch_tail_gemv(const FcGemv* heads, int nheads, int N, int Kp, int ldx, int ldo, int B, const float* map, float* pool_out, int HW,
+                     int C, int pool_ld, const HeadInit* init, unsigned* ctl, int ctl_words, const DecodeArgs* dec, const PoseTail* pose,
+                     const LaunchCtx& ctx) {
+    if (nheads < 1 || nheads > 3 || N < 1 || B < 1 || Kp % 4 != 0 || ldx % 4 != 0 || C % 4 != 0 || pool_ld % 4 != 0 || HW >= 64 ||
+        (dec != nullptr) == (pose != nullptr) || !ctl)
+        return (int)hipErrorInvalidValue;
+    const int NBv = B == 1 ? 1 : 2;
+    const int nz = (B + NBv - 1) / NBv;
+    if (ctl_words < 2 + nz) return (int)hipErrorInvalidValue;
+    TailArgs a;
+    a.g.nheads = nheads; a.g.N = N; a.g.Kp = Kp; a.g.ldx = ldx; a.g.ldo = ldo; a.g.B = B;
+    for (int i = 0; i < 3; ++i) {
+        const FcGemv& f = heads[i < nheads ? i : 0];
+        if ((reinterpret_cast<uintptr_t>(f.x) | reinterpret_cast<uintptr_t>(f.w)) & 15) return (int)hipErrorInvalidValue;
+        a.g.hd[i] = GemvHead{f.x, f.w, f.bias, f.res, f.out};
+    }
+    a.map = map; a.pool_out = pool_out; a.HW = HW; a.C4 = C / 4; a.pool_ld = pool_ld;
+    a.pool_total = B * (C / 4);
+    a.npool = (a.pool_total + 255) / 256;
+    a.ninit = init ? B : 0;
+    a.init = init ? *init : HeadInit{};
+    a.ctl = ctl;
+    a.spin_limit = 2000000u;
+    a.dec = dec ? *dec : DecodeArgs{};
+    a.pose = pose ? *pose : PoseTail{};
+    const dim3 grid((N + 3) / 4, nheads, nz), blk(256);
+    if ((int)(grid.x * grid.y * grid.z) < a.npool + a.ninit) return (int)hipErrorInvalidValue;   // (every phase-A item needs a workgroup)
+    ProfScope ps(ctx, dec ? "tail_pool_gemv_decode" : "tail_pool_gemv_pose", 2.0 * nheads * (double)B * N * Kp,
+                 4.0 * (nheads * ((double)N * Kp + (double)B * (Kp + N)) + (double)B * HW * C));
+    if (dec) {
+        if (NBv == 1) hipLaunchKernelGGL((tail_gemv_kernel<1, 1>), grid, blk, 0, ctx.stream, a);
+        else hipLaunchKernelGGL((tail_gemv_kernel<2, 1>), grid, blk, 0, ctx.stream, a);
+    } else {
+        if (NBv == 1) hipLaunchKernelGGL((tail_gemv_kernel<1, 2>), grid, blk, 0, ctx.stream, a);
+        else hipLaunchKernelGGL((tail_gemv_kernel<2, 2>), grid, blk, 0, ctx.stream, a);
+    }
+    return (int)hipGetLastError();
+}
+
+int launch_tail_camcalib(const FcGemv* heads, int N, int Kp, int B, const float* map, float* pooled, int HW, int C, unsigned* ctl, int ctl_words,
+                         const float* img_h, const float* img_w, float* vfov, float* pitch, float* roll, float* f_pix, float* R, float* K,
+                         long ld_ang, const LaunchCtx& ctx) {
+    const DecodeArgs d{heads[0].out, heads[1].out, heads[2].out, N, img_h, img_w, vfov, pitch, roll, f_pix, R, K, ld_ang};
+    return launch_tail_gemv(heads, 3, N, Kp, Kp, N, B, map, pooled, HW, C, Kp, nullptr, ctl, ctl_words, &d, nullptr, ctx);
+}
+
+int launch_tail_hmr(const FcGemv& head, int N, int Kp, int ldx, int ldo, int B, const float* map, float* xc, int HW, int C, const HeadInit& init,
+                    unsigned* ctl, int ctl_words, const SmplDev& m, float* feat, float* Afrag, float* posed_j, const HeadFinal& fin,
+                    const LaunchCtx& ctx) {
+    const PoseTail pt{m.J_template, m.J_shapedirs, m.parents, feat, Afrag, posed_j, fin};
+    return launch_tail_gemv(&head, 1, N, Kp, ldx, ldo, B, map, xc, HW, C, ldx, &init, ctl, ctl_words, nullptr, &pt, ctx);
 }
 
 // The two per-row reductions camcalib/cam_utils.py applies to a (rows, nbins) logit tensor, one wave per row:

@@ -187,7 +187,9 @@ struct HeadInit {
     float* xc; const float *init_pose, *init_shape, *init_cam, *R, *K, *img_h;
     int use_cam_feats, state_off, ld;
 };
-// columns state_off .. ld of row b, by `nthreads` threads
+// columns state_off .. ld of row b, by `nthreads` threads.  WT: write-through (agent-scope) stores - the row is read later in the
+// SAME launch by other workgroups (fused tail, head.hip)
+template <bool WT = false>
 __device__ __forceinline__ void head_init_row(const HeadInit& a, int b, int tid, int nthreads) {
     float* row = a.xc + (size_t)b * a.ld + a.state_off;
     for (int i = tid; i < a.ld - a.state_off; i += nthreads) {
@@ -201,7 +203,8 @@ __device__ __forceinline__ void head_init_row(const HeadInit& a, int b, int tid,
         } else if (a.use_cam_feats && i == 163) {
             v = 2.0f * atanf(a.img_h[b] / (2.0f * a.K[(size_t)b * 9]));
         }
-        row[i] = v;
+        if (WT) __hip_atomic_store(row + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else row[i] = v;
     }
 }
 // x (B,HW,C) -> out[b*ldo + c] = mean_hw.  init != nullptr: the same launch also writes the IEF state columns of every row
@@ -253,6 +256,17 @@ int launch_bins_reduce(const float* x, int rows, int nbins, int* idx, float* sof
 // zero padded to Kp; x rows ldx floats apart with Kp floats readable; out[b * ldo + n] = w[n] . x[b] + bias[n] (+ res[b * ldo + n])
 struct FcGemv { const float* x; const float* w; const float* bias; const float* res; float* out; };
 int launch_fc_gemv(const FcGemv* heads, int nheads, int N, int Kp, int ldx, int ldo, int B, const LaunchCtx& ctx);
+
+// fused tails of the small-batch step (head.hip: tail_gemv_kernel): pool [+ state init] -> GEMV heads -> CamCalib decode | HMR pose chain
+struct DecodeArgs;
+struct PoseTail;
+int launch_tail_camcalib(const FcGemv* heads, int N, int Kp, int B, const float* map, float* pooled, int HW, int C, unsigned* ctl, int ctl_words,
+                         const float* img_h, const float* img_w, float* vfov, float* pitch, float* roll, float* f_pix, float* R, float* K,
+                         long ld_ang, const LaunchCtx& ctx);
+struct SmplDev;
+int launch_tail_hmr(const FcGemv& head, int N, int Kp, int ldx, int ldo, int B, const float* map, float* xc, int HW, int C, const HeadInit& init,
+                    unsigned* ctl, int ctl_words, const SmplDev& m, float* feat, float* Afrag, float* posed_j, const HeadFinal& fin,
+                    const LaunchCtx& ctx);
 
 int launch_cam_params(const float* pitch, const float* roll, const float* f_pix, const float* img_w, const float* img_h,
                       int B, float* R, float* K, const LaunchCtx& ctx);
@@ -309,6 +323,7 @@ struct SmplArgs {
     // non-null: the pose kernel first does head_final's work for its image (rot6d -> rotmat, output gather) and takes rotmat /
     // betas from there instead of a.rotmat / a.betas (one graph node less; same bits)
     const HeadFinal* final_ = nullptr;
+    bool pose_done = false;   // the pose chains of this batch already ran (fused HMR tail, head.hip): launch_smpl starts at the skinning
 };
 int launch_smpl(const SmplDev& m, const SmplArgs& a, const LaunchCtx& ctx);
 // vertices (optional) + the 24 posed kinematic joints (optional; a.posed_j receives them otherwise)

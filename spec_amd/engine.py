@@ -219,6 +219,33 @@ class Engine:
             self.h, _ptr(x), B, H, W, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), self._stream()))
         return [out[0], out[1], out[2]]
 
+    def camcalib_head_decode(self, feat_nhwc, img_h=None, img_w=None, angles_out=None):
+        """``camcalib_head`` + ``camcalib_decode`` as one call (one launch at small batches: ``specmi_camcalib_head_decode``) ->
+        ([logits_vfov, logits_pitch, logits_roll], dict(vfov, pitch, roll, f_pix, cam_rotmat, cam_intrinsics))."""
+        f = _dev_f32(feat_nhwc, self.device)
+        B, fh, fw, _ = f.shape
+        out = torch.empty(3, B, self.nbins, device=self.device, dtype=torch.float32)
+        img_h = _dev_f32(img_h, self.device, (B,))
+        img_w = _dev_f32(img_w, self.device, (B,))
+        mk = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)
+        if angles_out is not None:
+            vf, pt, rl = angles_out
+            ld = vf.stride(0) if B > 1 else 1
+            if any(t.shape != (B,) or t.dtype != torch.float32 or (B > 1 and t.stride(0) != ld) for t in (vf, pt, rl)):
+                raise ValueError('angles_out: three (B,) fp32 tensors with one common stride')
+            self._set_ld('angle_ld', ld if ld != 1 else 0)
+        else:
+            vf, pt, rl = mk(B), mk(B), mk(B)
+            self._set_ld('angle_ld', 0)
+        fp = mk(B) if img_h is not None else None
+        R = mk(B, 3, 3)
+        K = mk(B, 3, 3) if (img_h is not None and img_w is not None) else None
+        if B > 0:
+            _lib.check(self.h, self.lib.specmi_camcalib_head_decode(
+                self.h, _ptr(f), B, fh, fw, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(img_h), _ptr(img_w), _ptr(vf), _ptr(pt),
+                _ptr(rl), _ptr(fp), _ptr(R), _ptr(K), self._stream()))
+        return [out[0], out[1], out[2]], {'vfov': vf, 'pitch': pt, 'roll': rl, 'f_pix': fp, 'cam_rotmat': R, 'cam_intrinsics': K}
+
     def camcalib_decode(self, lv, lp, lr, img_h=None, img_w=None, angles_out=None):
         """``angles_out``: optional (vfov, pitch, roll) tensors of shape (B,) with a common element stride
         (e.g. three columns of the packed record) that the kernel writes directly."""

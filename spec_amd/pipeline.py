@@ -113,8 +113,7 @@ class SpecPipeline:
         if can_group:
             ceng = self.camcalib.engine(device)
             cfeat, feat = ceng.trunk_pair(eng, cam_in, images)
-            logits = ceng.camcalib_head(cfeat)
-            cam = cam_utils.decode_camera(logits[0], logits[1], logits[2], img_h=img_h, img_w=img_w, angles_out=angles)
+            logits, cam = ceng.camcalib_head_decode(cfeat, img_h=img_h, img_w=img_w, angles_out=angles)   # one launch at small batches
             out = eng.hmr_regress(feat, cam['cam_rotmat'], cam['cam_intrinsics'], bbox_scale, bbox_center, img_w, img_h,
                                   record=record)
         elif not (self.overlap and self.hmr.use_cam):
@@ -131,9 +130,8 @@ class SpecPipeline:
             side = self._side_stream(device, lambda: eng.trunk(images))
             side.wait_stream(main)                      # inputs were produced on the main stream
             with torch.cuda.stream(side):
-                logits = self.camcalib(cam_in)
-                cam = cam_utils.decode_camera(logits[0], logits[1], logits[2], img_h=img_h, img_w=img_w,
-                                              angles_out=angles)
+                ceng = self.camcalib.engine(device)
+                logits, cam = ceng.camcalib_head_decode(ceng.trunk(cam_in), img_h=img_h, img_w=img_w, angles_out=angles)
             feat = eng.trunk(images)                    # SPEC trunk on the main stream, concurrently
             main.wait_stream(side)                      # the head needs (R, K)
             for v in cam.values():

@@ -220,3 +220,36 @@ def test_poisoned_hand_off_counters_are_reset(models):
         out = SpecPipeline(cc, hm, grouped=True)(*ins)
         for k in KEYS:
             assert torch.equal(out[k], ref[k]), ('commit', k)
+
+
+@pytest.mark.parametrize('B', [1, 2, 3, 7, 10])
+def test_fused_tails_are_bit_identical(models, B):
+    """Option tail_fuse (default 1): at small batches each network's tail is ONE launch - CamCalib avg-pool -> three heads -> decode,
+    HMR avg-pool + state init -> regressor map -> pose chains - with an in-launch completion counter and a last-arriver epilogue
+    (head.hip: tail_gemv_kernel).  Same code as the separate kernels: every output bit, eager and replayed, grouped and two streams."""
+    from spec_amd.pipeline import SpecPipeline, GraphedPipeline
+    cc, hm = models
+    ce, he = cc.engine(torch.device(DEV)), hm.engine(torch.device(DEV))
+    ins = _inputs(71 + B, B)
+    keys = KEYS + ('pred_pose', 'pred_shape', 'pred_cam', 'cam_roll', 'cam_f_pix', 'cam_rotmat', 'cam_intrinsics')
+    try:
+        res = {}
+        for fuse in (0, 1):
+            for e in (ce, he):
+                e.set_option('tail_fuse', fuse)
+            res[fuse] = {}
+            for tag, pp in (('grouped', SpecPipeline(cc, hm, grouped=True)), ('two_streams', SpecPipeline(cc, hm, overlap=True, grouped=False))):
+                out = pp(*ins)
+                torch.cuda.synchronize()
+                res[fuse][tag] = {k: out[k].clone() for k in keys}
+        for tag in ('grouped', 'two_streams'):
+            for k in keys:
+                assert torch.equal(res[0][tag][k], res[1][tag][k]), (tag, k)
+        gp = GraphedPipeline(SpecPipeline(cc, hm), *ins)
+        for _ in range(20):
+            out = gp(*ins)
+            for k in keys:
+                assert torch.equal(out[k], res[0]['grouped'][k]), k
+    finally:
+        for e in (ce, he):
+            e.set_option('tail_fuse', 1)
