@@ -150,10 +150,11 @@ const char* specmi_version(void);
  *   "smpl_skin_split" (-1 = by batch: three waves per 32-vertex group up to 64 images, one beyond; 0 / 1 = never / always: same bits),
  *   "head_fuse" (default 3; bit 0: the regressor's state init rides in the pooling launch, bit 1: head_final's work is done by the
  *   SMPL pose kernel of specmi_hmr_forward / specmi_hmr_regress - two graph nodes less per step, same bits);
- *   "tail_fuse" (default 1, round 5): at small batches each network's tail is ONE launch - HMR: avg-pool + state init -> composed
- *   regressor map -> pose chains; CamCalib (specmi_camcalib_head_decode): avg-pool -> three heads -> decode - instead of three: the
- *   first workgroups pool, every workgroup waits on one counter, the last arriver per image pair runs the epilogue (same code, same
- *   bits; spec_amd/csrc/head.hip). */
+ *   "tail_fuse" (default 0, round 5, opt-in): at small batches each network's tail as ONE launch - HMR: avg-pool + state init ->
+ *   composed regressor map -> pose chains; CamCalib (specmi_camcalib_head_decode): avg-pool -> three heads -> decode - instead of
+ *   three: the first workgroups pool, every workgroup waits on one counter, the last arriver per image pair runs the epilogue (same
+ *   code, same bits; spec_amd/csrc/head.hip).  Four graph nodes less per step and NOT faster on MI355X (15.2 vs 16.3 us per tail, the
+ *   whole step 0-1 % slower: profiles/r05_f_tail_check.jsonl) - an in-launch hand-off costs what a kernel boundary costs. */
 int specmi_set_option_i32(specmi_handle* h, const char* name, int value);
 int specmi_set_option_f32(specmi_handle* h, const char* name, float value);
 
@@ -186,8 +187,8 @@ int specmi_trunk_forward_pair(specmi_handle* ha, specmi_handle* hb, const float*
 int specmi_camcalib_head_forward(specmi_handle* h, const float* feat_nhwc, int B, int fh, int fw, float* logits_vfov,
                                  float* logits_pitch, float* logits_roll, void* stream);
 
-/* specmi_camcalib_head_forward + specmi_camcalib_decode in one call (round 5): at small batches (the GEMV path of the latency /
- * single plans, one Linear layer per head, option "tail_fuse" default 1) the avg-pool, the three heads and the decode run as ONE
+/* specmi_camcalib_head_forward + specmi_camcalib_decode in one call (round 5); with option "tail_fuse" = 1 and at small batches
+ * (the GEMV path of the latency / single plans, one Linear layer per head) the avg-pool, the three heads and the decode run as ONE
  * launch (spec_amd/csrc/head.hip: tail_gemv_kernel - the code of the three kernels, same bits); otherwise the separate kernels.
  * Replaces camcalib/model.py:74-80 + camcalib/cam_utils.py:110-133 + scripts/camcalib_demo.py:129 + spec/utils/cam_params.py:37-46.
  * Outputs as in the two calls (any of vfov .. K may be NULL); "angle_ld" applies to vfov / pitch / roll. */

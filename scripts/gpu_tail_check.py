@@ -49,5 +49,5 @@ for b in (1, 2, 3, 5, 8, 10):
     for fuse in (0, 1):
         opt('tail_fuse', fuse)
         row[f'fuse{fuse}_ms'] = step_ms(SpecPipeline(cc, hm), b)
-    opt('tail_fuse', 1)
+    opt('tail_fuse', 0)
     line = json.dumps(row); print(line, flush=True); out.write(line + '\n'); out.flush()

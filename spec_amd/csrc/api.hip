@@ -1068,10 +1068,12 @@ static int run_head(specmi_handle* h, const float* feat, int B, int fh, int fw, 
     if (ucf && (!R || !K || !img_h))
         return fail(h, SPECMI_ERR_ARG, "use_cam_feats needs cam_rotmat, cam_intrinsics and img_h");
     if (pose_done) *pose_done = false;
-    // Small batches (round 5, option "tail_fuse", default 1): avg-pool + state init -> composed regressor map -> pose chains as ONE
+    // Small batches (round 5, option "tail_fuse", default 0): avg-pool + state init -> composed regressor map -> pose chains as ONE
     // launch (head.hip: tail_gemv_kernel; the code of the three kernels, same bits).  Needs the collapsed head, the GEMV path,
-    // head_final deferred into the pose chain and a map that pools in one part.
-    if (defer && pose_done && opt_i(h, "tail_fuse", 1) && use_latency_heads(h, B) && h->has_head_c && opt_i(h, "head_collapse", 1) &&
+    // head_final deferred into the pose chain and a map that pools in one part.  Opt-in: measured 15.2 us against 16.3 us for the
+    // three kernels at batch 1 and the whole step 0-1 % SLOWER at batch 1-10 (profiles/r05_f_tail_check.jsonl) - an in-launch hop
+    // costs what a kernel boundary costs on this part.
+    if (defer && pose_done && opt_i(h, "tail_fuse", 0) && use_latency_heads(h, B) && h->has_head_c && opt_i(h, "head_collapse", 1) &&
         h->head_c.w_rm && fh * fw < 64 && (B + 1) / 2 + 2 <= specmi_handle::kTailCtlWords && h->tail_ctl && !h->prof.on) {
         const HeadInit hi{h->xc, h->init_pose, h->init_shape, h->init_cam, R, K, img_h, ucf, F, LD};
         defer->state = h->h1; defer->ld_state = 1024;
@@ -1445,8 +1447,8 @@ int specmi_camcalib_head_decode(specmi_handle* h, const float* feat, int B, int 
     if ((rc = ensure_ws(h, B, 32, 32))) return rc;
     const long ld_ang = opt_i(h, "angle_ld", 0) > 0 ? opt_i(h, "angle_ld", 0) : 1;
     const FcW& f0 = h->fc_cam[0][0];
-    // small batches (round 5, option "tail_fuse"): avg-pool -> the three heads -> decode as ONE launch (head.hip: tail_gemv_kernel)
-    if (opt_i(h, "tail_fuse", 1) && use_latency_heads(h, B) && h->fc_layers == 1 && f0.w_rm && fh * fw < 64 && f0.Kp == h->feat_ch &&
+    // small batches (round 5, option "tail_fuse", opt-in): avg-pool -> the three heads -> decode as ONE launch (head.hip: tail_gemv_kernel)
+    if (opt_i(h, "tail_fuse", 0) && use_latency_heads(h, B) && h->fc_layers == 1 && f0.w_rm && fh * fw < 64 && f0.Kp == h->feat_ch &&
         h->fc_cam[1][0].nout == f0.nout && h->fc_cam[2][0].nout == f0.nout && h->fc_cam[1][0].Kp == f0.Kp && h->fc_cam[2][0].Kp == f0.Kp &&
         (B + 1) / 2 + 2 <= specmi_handle::kTailCtlWords && h->tail_ctl && !h->prof.on) {
         float* outs[3] = {lv, lp, lr};

@@ -224,7 +224,7 @@ def test_poisoned_hand_off_counters_are_reset(models):
 
 @pytest.mark.parametrize('B', [1, 2, 3, 7, 10])
 def test_fused_tails_are_bit_identical(models, B):
-    """Option tail_fuse (default 1): at small batches each network's tail is ONE launch - CamCalib avg-pool -> three heads -> decode,
+    """Option tail_fuse (opt-in): at small batches each network's tail is ONE launch - CamCalib avg-pool -> three heads -> decode,
     HMR avg-pool + state init -> regressor map -> pose chains - with an in-launch completion counter and a last-arriver epilogue
     (head.hip: tail_gemv_kernel).  Same code as the separate kernels: every output bit, eager and replayed, grouped and two streams."""
     from spec_amd.pipeline import SpecPipeline, GraphedPipeline
@@ -252,4 +252,4 @@ def test_fused_tails_are_bit_identical(models, B):
                 assert torch.equal(out[k], res[0]['grouped'][k]), k
     finally:
         for e in (ce, he):
-            e.set_option('tail_fuse', 1)
+            e.set_option('tail_fuse', 0)
