@@ -18,7 +18,8 @@ def build():
     cc = cc.to(dev).eval(); hm = hm.to(dev).eval()
     cc.commit(dev, freeze=True); hm.commit(dev, freeze=True)
     return cc, hm
-R = 4
+R = int(os.environ.get('REPLICAS', '4'))
+ONLY = os.environ.get('ONLY')   # e.g. '8:2:auto'
 reps = [build() for _ in range(R)]
 x = t(synth.images(9, 16)).to(dev)
 sc, cen, iw, ih = [t(a).to(dev) for a in synth.bbox_inputs(9, 16, 640., 480.)]
@@ -59,14 +60,14 @@ def time_fn(g, ins, iters=200):
     return round(best, 4)
 
 out = open(os.path.join(ROOT, 'gpurun_out', 'subbatch_overlap.jsonl'), 'a')
-for b in (4, 6, 8, 10, 12, 16):
+for b in ([int(ONLY.split(':')[0])] if ONLY else (4, 6, 8, 10, 12, 16)):
     ins = tuple(a[:b].contiguous() for a in (x, sc, cen, iw, ih))
     row = {'batch': b}
     ref = None
-    for nrep in (1, 2, 4):
-        if b % nrep:
+    for nrep in ([int(ONLY.split(':')[1])] if ONLY else (1, 2, 4)):
+        if b % nrep or nrep > R:
             continue
-        for grouped in ('auto', True, False):
+        for grouped in ([{'auto': 'auto', '1': True, '0': False}[ONLY.split(':')[2]]] if ONLY else ('auto', True, False)):
             try:
                 g = GraphedStep(make_step(nrep, grouped), *ins)
                 o = g(*ins)
