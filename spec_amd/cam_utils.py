@@ -10,6 +10,8 @@ to the GPU first - there is no CPU arithmetic path.
 """
 from __future__ import annotations
 
+import threading
+
 import numpy as np
 import torch
 
@@ -17,13 +19,18 @@ from . import constants as C
 from .engine import Engine
 
 _engines = {}
+_engines_lock = threading.Lock()
 
 
 def _engine(device) -> Engine:
+    """The parameter-less decode engine of a (device, thread): a handle is not thread-safe (include/specmi.h), so the module-level
+    helpers below keep one per calling thread - a server loop with worker threads may call them concurrently."""
     dev = torch.device('cuda', device.index if device.index is not None else torch.cuda.current_device())
-    if dev not in _engines:
-        _engines[dev] = Engine('camcalib', dev)   # decode needs no parameters
-    return _engines[dev]
+    key = (dev, threading.get_ident())
+    with _engines_lock:
+        if key not in _engines:
+            _engines[key] = Engine('camcalib', dev)   # decode needs no parameters
+        return _engines[key]
 
 
 # ---- bin tables (camcalib/cam_utils.py:23-63) -------------------------------------------------------------
@@ -74,6 +81,17 @@ def _argmax_idx(bins) -> np.ndarray:
             raise NotImplementedError('bins2*: float64 logits that are not exactly representable in fp32')
     idx, _ = _engine(dev).camcalib_bins(bins.to(dev), argmax=True, soft=False)
     return idx.cpu().numpy().astype(np.int64)
+
+
+def bins2centers_device(bins, centers) -> torch.Tensor:
+    """The ``bins2*`` look-up WITHOUT leaving the device: arg-max bin of (..., nbins) device logits -> float64 centres as a device
+    tensor, no host synchronisation (the reference's ``bins2*`` return NumPy arrays - camcalib/cam_utils.py:66-91 - which costs a
+    device-to-host copy per call: fine for the demo script, not for a serving loop; ``centers`` = one of the ``*_bins_centers``)."""
+    if not isinstance(bins, torch.Tensor) or bins.device.type != 'cuda':
+        raise RuntimeError('bins2centers_device needs device logits')
+    idx, _ = _engine(bins.device).camcalib_bins(bins, argmax=True, soft=False)
+    table = torch.from_numpy(np.ascontiguousarray(centers)).to(bins.device)
+    return table[idx.long()]
 
 
 def bins2horizon(bins):

@@ -253,3 +253,16 @@ def test_fused_tails_are_bit_identical(models, B):
     finally:
         for e in (ce, he):
             e.set_option('tail_fuse', 0)
+
+
+def test_bins_lookup_on_the_device_matches_the_numpy_api():
+    """bins2centers_device: the bins2* table look-up without a host synchronisation - same indices, same float64 centres."""
+    from spec_amd import cam_utils
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(37, 256, generator=g).to(DEV)
+    logits[3, 10] = logits[3, 200] = logits[3].max() + 1.0          # a tie: the FIRST maximum wins (np.argmax)
+    for centers, fn in ((cam_utils.vfov_bins_centers, cam_utils.bins2vfov), (cam_utils.pitch_bins_centers, cam_utils.bins2pitch),
+                        (cam_utils.roll_bins_centers, cam_utils.bins2roll)):
+        dev_out = cam_utils.bins2centers_device(logits, centers)
+        assert dev_out.dtype == torch.float64 and dev_out.device.type == 'cuda'
+        assert np.array_equal(dev_out.cpu().numpy(), fn(logits))
