@@ -679,10 +679,7 @@ static OpLaunch prepare_op(specmi_handle* h, const TrunkOp& op, const float* ima
         // walking Cin = 512 for 75 us, the sliced direct kernel takes 45)
         const int min_tiles = opt_i(h, "latency_wino_min_tiles", 128);
         if (wino && ((a.OH + 1) / 2) * ((a.OW + 1) / 2) < (min_tiles > a.Cin || min_tiles == 0 || min_tiles >= 100000 ? min_tiles : a.Cin)) wino = false;
-        if (mode == 2) {
-            wino = false;              // 'single': batch 1-2, the direct kernel wins on layer1 / layer2 too
-            a.sk_rule = opt_i(h, "single_tree", 1);   // ... and small-K / two-source layers get four-leaf trees for the wave-split unit
-        }
+        if (mode == 2) wino = false;   // 'single': batch 1-2, the direct kernel wins on layer1 / layer2 too
         if (!wino) L.sk = conv_igemm_sk_slices(a, opt_i(h, "latency_target_wgs", 256), opt_i(h, "latency_min_chunks", 4));
     }
     if (wino) {
@@ -771,8 +768,7 @@ static int launch_op(specmi_handle* h, const TrunkOp& op, const OpLaunch& L, con
             // 4-10 - want the cap at 500 units, 1.245 vs 1.285 ms at batch 6, 1.441 vs 1.487 at 8; the pair's grouped launches at 2000:
             // 0.884 vs 0.913 ms at batch 3, 1.312 vs 1.421 at 6)
             const long max_units = groups == 2 ? opt_i(h, "wsplit_max_units", 2000) : opt_i(h, "wsplit_max_units_single", 500);
-            // (two-source layers: only with the single plan's four-leaf trees - with the latency plan's two leaves they measured slower)
-            const bool take = wsplit > 1 || (pl.unit != pl.leaves && (!L.a.x2 || (L.a.sk_rule == 1 && pl.G == 4)) && t32 * ng <= max_units);
+            const bool take = wsplit > 1 || (pl.unit != pl.leaves && !L.a.x2 && t32 * ng <= max_units);
             if (take && conv_wsplit_supported(L.a, pw)) {
                 if ((rc = ensure_sk(h, conv_wsplit_ws_floats(L.a, pw.leaves / pw.unit, groups), conv_wsplit_tiles(L.a, groups)))) return rc;
                 LAUNCHCHK(h, launch_conv_wsplit(L.a, pw, h->sk, ctx, partner ? &partner->a : nullptr), op.label.c_str());

@@ -241,19 +241,7 @@ int conv_igemm_sk_slices(const ConvArgs& a, int target_wgs, int min_chunks) {
     const int nch = a.KH * a.KW * (a.Cin / 32) + (a.x2 ? a.Cin2 / 32 : 0);
     // K < 512: the unsplit kernel wins at every batch size (measured per layer, profiles/r04_b_latency_layers.txt: a second
     // slab round trip costs more than walking 8-12 chunks)
-    if (nch < 16) {
-        // The single plan (batch 1-2, round 5) has its own bits and its sliced layers run on the wave-split unit (conv_wsplit.hip),
-        // which folds a group's leaves inside the workgroup - no slab: there a layer of 8 or 12 chunks (K = 256 / 384) is one GROUP of
-        // four leaves, so that four waves share the K walk of a 32x32 tile instead of each wave of a 64x64 tile doing all of it.
-        if (a.sk_rule == 1 && nch % 4 == 0 && nch / 4 >= 2) return 4;
-        return 1;
-    }
-    // single plan: a two-source layer (folded downsample branch) gets four leaves where the latency plan's rule gives two (its
-    // 24 chunks at layer3: two leaves would leave two of the unit's four waves idle)
-    if (a.sk_rule == 1 && a.x2 && nch % 4 == 0 && nch / 4 >= 4) {
-        const int tiles1s = ((a.OH * a.OW + 63) / 64) * (a.Npad / 64);
-        if (2 * tiles1s * 4 >= target_wgs / 2) return 4;
-    }
+    if (nch < 16) return 1;
     const int tiles1 = ((a.OH * a.OW + 63) / 64) * (a.Npad / 64);
     int best = 1;
     for (int s = 1; s <= nch; ++s) {

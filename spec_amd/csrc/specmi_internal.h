@@ -92,7 +92,6 @@ struct ConvArgs {
     const float* x2 = nullptr;
     int H2 = 0, W2 = 0, ldx2 = 0, Cin2 = 0, stride2 = 1;
     // per-handle tuning overrides (tests / tools): 0 = automatic choice
-    int sk_rule = 0;         // which canonical k-sum tree the sliced kernels use: 0 the latency plan's (conv_igemm_sk_slices), 1 the single plan's
     int force_variant = 0;   // conv_igemm tile (1: 128x128/4 waves, 2: 128x64/4, 3: 64x64/4, 4: 128x128/8 waves)
     int wino_variant = 0;    // conv_wino frequencies per wave (16 / 8)
 };
