@@ -23,7 +23,7 @@ def elementwise(name, a, b, unit, floor):
 
 
 
-for PLAN in ('latency', 'throughput'):
+for PLAN in ('single', 'latency', 'throughput'):
     print(f'================ execution plan: {PLAN} (include/specmi.h, option "plan") ================')
     print('--- GPU vs golden fixtures produced by the reference modules (relative max-norm error)')
     for tag, uc, ucf in (('camfeats', True, True), ('cam', True, False), ('nocam', False, False)):

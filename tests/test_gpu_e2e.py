@@ -30,7 +30,7 @@ def test_native_library_is_loaded(models):
     assert 'libspecmi.so' in maps
 
 
-@pytest.mark.parametrize('plan', ['latency', 'throughput'])
+@pytest.mark.parametrize('plan', ['single', 'latency', 'throughput'])
 def test_trunk_vs_oracle(models, plan):
     _, hm = models
     _, ohm = oracle_models(True, True)
@@ -88,7 +88,7 @@ def test_trunk_tile_order_of_wide_layers_keeps_batch_invariance(models):
             assert torch.equal(small, big[lo:lo + 2]), lo
 
 
-@pytest.mark.parametrize('plan', ['latency', 'throughput'])
+@pytest.mark.parametrize('plan', ['single', 'latency', 'throughput'])
 def test_camcalib_vs_reference_fixture(models, plan):
     cc, _ = models
     g = golden('camcalib_e2e.npz')
@@ -105,7 +105,7 @@ def test_camcalib_vs_reference_fixture(models, plan):
         assert np.abs(a.cpu().numpy() - g[k]).max() < 2e-5, k
 
 
-@pytest.mark.parametrize('plan', ['latency', 'throughput'])
+@pytest.mark.parametrize('plan', ['single', 'latency', 'throughput'])
 @pytest.mark.parametrize('tag,use_cam,ucf', [('camfeats', True, True), ('cam', True, False), ('nocam', False, False)])
 def test_hmr_vs_reference_fixture(tag, use_cam, ucf, plan):
     g = golden(f'hmr_e2e_{tag}.npz')
@@ -137,7 +137,7 @@ def _elementwise_ok(out, ref, key):
     return float(excess.max()), float(np.abs(a - b).max())
 
 
-@pytest.mark.parametrize('plan', ['latency', 'throughput'])
+@pytest.mark.parametrize('plan', ['single', 'latency', 'throughput'])
 @pytest.mark.parametrize('tag,use_cam,ucf', [('camfeats', True, True), ('cam', True, False), ('nocam', False, False)])
 def test_hmr_fixture_elementwise_bound(tag, use_cam, ucf, plan):
     """What tests/parity_report.py prints, asserted: every element of the mesh, the joints and the projection, not only the
@@ -383,7 +383,7 @@ def test_camcalib_model_matrix(backbone, num_fc_layers, num_fc_channels, size):
         assert rel_err(o.cpu().numpy(), r.numpy()) < 1e-4, (backbone, num_fc_layers, num_fc_channels, size)
 
 
-@pytest.mark.parametrize('plan', ['latency', 'throughput'])
+@pytest.mark.parametrize('plan', ['single', 'latency', 'throughput'])
 @pytest.mark.parametrize('backbone', ['resnet18', 'resnet101', 'resnet152'])
 def test_other_resnet_depths_vs_oracle(backbone, plan):
     """The rest of the torchvision family that the reference's ``eval(backbone)(pretrained=True)`` resolves (spec/models/hmr.py:53,
