@@ -1405,7 +1405,7 @@ static int run_camcalib_head(specmi_handle* h, const float* f, int B, int fh, in
         for (int l = 0; l < h->fc_layers; ++l) {
             const bool lastl = (l + 1 == h->fc_layers);
             FcGemv hd[3];
-            // hidden rows of head i: h1 / h2 hold two of them, the third borrows the regressor-state buffer xc (unused by CamCalib)
+            // hidden rows of the three heads of layer l: fc_hidden[l & 1] holds them (3 x B x 1024), alternating with the layer that reads them
             const FcW& f0 = h->fc_cam[0][l];
             const int ldy = lastl ? f0.nout : 1024;
             for (int i = 0; i < 3; ++i) {
