@@ -136,7 +136,7 @@ const char* specmi_version(void);
  *   Round 5, same bits as before (speed choices inside the latency / single plans):
  *     "wsplit" (default 1): sliced layers whose 64x64 launch would need slabs run on the wave-split unit of the SAME canonical tree
  *       (spec_amd/csrc/conv_wsplit.hip: a 32x32 tile per workgroup, a group's leaves on its four waves, 4 KB group slabs or none) while
- *       the launch has at most "wsplit_max_units" (2000, trunk pair) / "wsplit_max_units_single" (500) leaf-units; 0 = never; 2 / 3 =
+ *       the launch has at most "wsplit_max_units" (1400, trunk pair) / "wsplit_max_units_single" (500) leaf-units; 0 = never; 2 / 3 =
  *       always with one group / all groups per workgroup (tests).  "conv2d_wsplit" (specmi_conv2d only: 0 | 2 | 3).
  *     "persist" (default 0, opt-in): every run of implicit-GEMM layers of the latency / single plan as ONE persistent launch
  *       (spec_amd/csrc/conv_persist.hip: resident workgroups walk the layers, completion counters instead of kernel boundaries,

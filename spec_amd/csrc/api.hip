@@ -746,7 +746,7 @@ static int launch_op(specmi_handle* h, const TrunkOp& op, const OpLaunch& L, con
         // from the per-layer tables of profiles/r05_c_wsplit_layers.txt:
         //   * taken when the 64x64 kernel would have to slice K across workgroups (its unit is not the whole K), the layer has one A
         //     source (the strided second source of a folded downsample branch measured slower at every batch) and the launch stays
-        //     under "wsplit_max_units" (2000 for the trunk pair, "wsplit_max_units_single" 500 for one trunk) leaf-units = 32x32 tiles x
+        //     under "wsplit_max_units" (1400 for the trunk pair, "wsplit_max_units_single" 500 for one trunk) leaf-units = 32x32 tiles x
         //     groups: beyond, several workgroups share a CU and the
         //     8 KB of operands per wave-chunk (6 in the 64x64 kernel) cost more than the slabs (batch 8: layer3 1568 units, slower);
         //   * one group per workgroup (slab per group) or all groups (no slab): whichever needs fewer rounds of workgroups per CU,
@@ -765,9 +765,10 @@ static int launch_op(specmi_handle* h, const TrunkOp& op, const OpLaunch& L, con
             const double cost_group = (double)((t32 * ng + slots - 1) / slots) * t_leaf + 1.0;
             pw.unit = (wsplit == 3 || (wsplit == 1 && cost_all <= cost_group)) ? pl.leaves : pl.G;
             // (whole-step sweep, profiles/r05_d_structure_sweep.jsonl: a single trunk's launches - two trunks on two streams, batch
-            // 4-10 - want the cap at 500 units, 1.245 vs 1.285 ms at batch 6, 1.441 vs 1.487 at 8; the pair's grouped launches at 2000:
-            // 0.884 vs 0.913 ms at batch 3, 1.312 vs 1.421 at 6)
-            const long max_units = groups == 2 ? opt_i(h, "wsplit_max_units", 2000) : opt_i(h, "wsplit_max_units_single", 500);
+            // 4-10 - want the cap at 500 units, 1.245 vs 1.285 ms at batch 6, 1.441 vs 1.487 at 8; the pair's grouped launches between 1300 and 1500:
+            // 0.884 vs 0.913 ms at batch 3 and 1.312 vs 1.421 at 6 with layer3 / layer4 on the unit (<= 1280 units), 1.546 vs 1.573 at
+            // batch 8 without it (1568 / 1664 units))
+            const long max_units = groups == 2 ? opt_i(h, "wsplit_max_units", 1400) : opt_i(h, "wsplit_max_units_single", 500);
             const bool take = wsplit > 1 || (pl.unit != pl.leaves && !L.a.x2 && t32 * ng <= max_units);
             if (take && conv_wsplit_supported(L.a, pw)) {
                 if ((rc = ensure_sk(h, conv_wsplit_ws_floats(L.a, pw.leaves / pw.unit, groups), conv_wsplit_tiles(L.a, groups)))) return rc;
