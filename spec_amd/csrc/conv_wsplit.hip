@@ -66,7 +66,11 @@ __global__ void __launch_bounds__(256, 4) conv_wsplit_f32_kernel(const KArgs p) 
     // ---- this lane's A row: byte offset of (tap (0,0) pixel, channel 4 * hh) -----------------------------------------------
     unsigned a_voff, a_voff2 = 0, a_mask = 0;
     {
+#ifdef WS_ABLATE_A      // timing experiment (wrong results): every tile reads the SAME 32 activation rows
+        const int m = l31;
+#else
         const int m = m0 + l31;
+#endif
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
         if (DUAL) {
@@ -103,7 +107,11 @@ __global__ void __launch_bounds__(256, 4) conv_wsplit_f32_kernel(const KArgs p) 
             }
         }
     }
+#ifdef WS_ABLATE_B      // timing experiment (wrong results): every tile reads the SAME weight columns -> B traffic becomes L1 / L2 hits
+    const unsigned b_voff = (unsigned)((hh * p.Npad + l31) * 16);
+#else
     const unsigned b_voff = (unsigned)((hh * p.Npad + n0 + l31) * 16);
+#endif
 
     // ---- this wave's K stream: the leaves (g0 + gi) * G + wave, gi = 0 .. ngroups_wg - 1, as ONE sequence of virtual chunks
     // v = gi * L + cl, so that the operands of the next leaf are already in flight when a leaf ends ------------------------------
