@@ -13,12 +13,17 @@ ap.add_argument('--batch', type=int, default=1)
 ap.add_argument('--reps', type=int, default=20)
 ap.add_argument('--plan', default='auto')
 ap.add_argument('--grouped', default='auto', help="'auto' (what a caller gets), 1 or 0")
+ap.add_argument('--opt', action='append', default=[], help='library option name=value for both models (e.g. persist=1, tail_fuse=1)')
 args = ap.parse_args()
 torch.set_grad_enabled(False)
 dev = torch.device('cuda:0')
 cc, hm, _, _ = bench.build_models(dev)
 for m in (cc, hm):
     m.set_plan(args.plan)
+for o in args.opt:
+    k, v = o.split('=')
+    for m in (cc, hm):
+        m.engine(dev).set_option(k, int(v))
 x, sc, ce, iw, ih = bench.make_inputs(args.batch, dev, 7)
 grouped = 'auto' if args.grouped == 'auto' else bool(int(args.grouped))
 g = GraphedPipeline(SpecPipeline(cc, hm, grouped=grouped), x, sc, ce, iw, ih)
