@@ -266,3 +266,53 @@ def test_bins_lookup_on_the_device_matches_the_numpy_api():
         dev_out = cam_utils.bins2centers_device(logits, centers)
         assert dev_out.dtype == torch.float64 and dev_out.device.type == 'cuda'
         assert np.array_equal(dev_out.cpu().numpy(), fn(logits))
+
+
+def test_trunk_plan_reports_what_a_forward_takes(models):
+    """specmi_trunk_plan: the plan of a (B, H, W) call under the handle's options - auto thresholds (2 / 10 pair / 16 single trunk images'
+    worth of pixels), a pinned plan, a full frame counted by its pixels."""
+    cc, hm = models
+    e = cc.engine(torch.device(DEV))
+    with pinned_plan('auto', cc, hm):
+        assert [e.trunk_plan(b) for b in (1, 2, 3, 10, 16, 17)] == ['single', 'single', 'latency', 'latency', 'latency', 'throughput']
+        assert [e.trunk_plan(b, pair=True) for b in (2, 3, 10, 11)] == ['single', 'latency', 'latency', 'throughput']
+        assert e.trunk_plan(1, 600, 1066) == 'latency'           # 12.7 crops' worth of pixels
+        assert e.trunk_plan(2, 600, 1066) == 'throughput'
+    for plan in ('throughput', 'latency', 'single'):
+        with pinned_plan(plan, cc, hm):
+            assert e.trunk_plan(1) == plan and e.trunk_plan(256, pair=True) == plan
+    from spec_amd.pipeline import SpecPipeline
+    with pinned_plan('auto', cc, hm):
+        st = SpecPipeline(cc, hm).launch_structure((8, 3, 224, 224))
+        assert st == {'grouped': False, 'structure': 'two trunks on two streams', 'plan': 'latency'}
+        st = SpecPipeline(cc, hm).launch_structure((1, 3, 224, 224))
+        assert st['grouped'] and st['plan'] == 'single'
+
+
+def test_camcalib_head_decode_equals_the_two_calls(models):
+    """specmi_camcalib_head_decode (separate kernels and the fused tail) == specmi_camcalib_head_forward + specmi_camcalib_decode,
+    dense and with the angles as strided columns of a record, optional outputs absent."""
+    cc, _ = models
+    e = cc.engine(torch.device(DEV))
+    for B in (1, 5):
+        x = t(synth.images(81, B)).to(DEV)
+        ih = torch.full((B,), 480., device=DEV); iw = torch.full((B,), 640., device=DEV)
+        with pinned_plan('latency', cc):
+            feat = e.trunk(x)
+            logits = e.camcalib_head(feat)
+            ref = e.camcalib_decode(logits[0], logits[1], logits[2], ih, iw)
+            for fuse in (0, 1):
+                e.set_option('tail_fuse', fuse)
+                try:
+                    lg, cam = e.camcalib_head_decode(feat, ih, iw)
+                    for a, b in zip(lg, logits):
+                        assert torch.equal(a, b)
+                    for k in ('vfov', 'pitch', 'roll', 'f_pix', 'cam_rotmat', 'cam_intrinsics'):
+                        assert torch.equal(cam[k], ref[k]), (B, fuse, k)
+                    rec = torch.zeros(B, 7, device=DEV)
+                    lg2, cam2 = e.camcalib_head_decode(feat, None, None, angles_out=(rec[:, 1], rec[:, 3], rec[:, 5]))
+                    assert cam2['f_pix'] is None and cam2['cam_intrinsics'] is None
+                    assert torch.equal(rec[:, 1], ref['vfov']) and torch.equal(rec[:, 3], ref['pitch']) and torch.equal(rec[:, 5], ref['roll'])
+                    assert torch.equal(cam2['cam_rotmat'], ref['cam_rotmat']) and float(rec[:, [0, 2, 4, 6]].abs().max()) == 0.0
+                finally:
+                    e.set_option('tail_fuse', 0)
