@@ -1,0 +1,43 @@
+"""Whole-step time (hipGraph replay) around the latency / throughput crossover: batch 8-20, plans latency and throughput, grouped and two streams."""
+import json, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from spec_amd import synth, assets
+from spec_amd.modules import HMR, CameraRegressorNetwork
+from spec_amd.pipeline import SpecPipeline, GraphedPipeline
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+torch.set_grad_enabled(False)
+dev = 'cuda:0'
+cs, hs = synth.camcalib_state(1001), synth.hmr_state(1002, True)
+assets.use_synthetic_assets(1003)
+cc = CameraRegressorNetwork(); cc.load_state_dict({k: t(v) for k, v in cs.items()})
+hm = HMR(use_cam=True, use_cam_feats=True); hm.load_state_dict({k: t(v) for k, v in hs.items()}, strict=False)
+cc = cc.to(dev).eval(); hm = hm.to(dev).eval()
+cc.commit(dev, freeze=True); hm.commit(dev, freeze=True)
+x = t(synth.images(9, 24)).to(dev)
+sc, cen, iw, ih = [t(a).to(dev) for a in synth.bbox_inputs(9, 24, 640., 480.)]
+def step_ms(pp, b, iters=150):
+    g = GraphedPipeline(pp, x[:b].contiguous(), sc[:b].contiguous(), cen[:b].contiguous(), iw[:b].contiguous(), ih[:b].contiguous())
+    ins = g.static_in
+    for _ in range(10): g(*ins)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters): g(*ins)
+        e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / iters)
+    del g
+    return round(best, 4)
+out = open(os.path.join(ROOT, 'gpurun_out', 'plan_crossover.jsonl'), 'a')
+for b in (8, 10, 11, 12, 14, 16, 20, 24):
+    row = {'batch': b}
+    for plan in ('latency', 'throughput'):
+        cc.set_plan(plan); hm.set_plan(plan)
+        row[f'{plan}_grouped'] = step_ms(SpecPipeline(cc, hm, grouped=True), b)
+        row[f'{plan}_two_streams'] = step_ms(SpecPipeline(cc, hm, overlap=True, grouped=False), b)
+    cc.set_plan('auto'); hm.set_plan('auto')
+    row['auto'] = step_ms(SpecPipeline(cc, hm), b)
+    line = json.dumps(row); print(line, flush=True); out.write(line + '\n'); out.flush()
