@@ -15,8 +15,8 @@ cc = CameraRegressorNetwork(); cc.load_state_dict({k: t(v) for k, v in cs.items(
 hm = HMR(use_cam=True, use_cam_feats=True); hm.load_state_dict({k: t(v) for k, v in hs.items()}, strict=False)
 cc = cc.to(dev).eval(); hm = hm.to(dev).eval()
 cc.commit(dev, freeze=True); hm.commit(dev, freeze=True)
-x = t(synth.images(9, 24)).to(dev)
-sc, cen, iw, ih = [t(a).to(dev) for a in synth.bbox_inputs(9, 24, 640., 480.)]
+x = t(synth.images(9, 32)).to(dev)
+sc, cen, iw, ih = [t(a).to(dev) for a in synth.bbox_inputs(9, 32, 640., 480.)]
 def step_ms(pp, b, iters=150):
     g = GraphedPipeline(pp, x[:b].contiguous(), sc[:b].contiguous(), cen[:b].contiguous(), iw[:b].contiguous(), ih[:b].contiguous())
     ins = g.static_in
@@ -32,7 +32,7 @@ def step_ms(pp, b, iters=150):
     del g
     return round(best, 4)
 out = open(os.path.join(ROOT, 'gpurun_out', 'plan_crossover.jsonl'), 'a')
-for b in (8, 10, 11, 12, 14, 16, 20, 24):
+for b in [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else '8,10,11,12,14,16,20,24').split(',')]:
     row = {'batch': b}
     for plan in ('latency', 'throughput'):
         cc.set_plan(plan); hm.set_plan(plan)
