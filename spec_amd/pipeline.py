@@ -37,10 +37,11 @@ class SpecPipeline:
         (``specmi_trunk_forward_pair``) instead of two trunks on two streams: half the launches, no stream join - what small
         batches want; results are bit-identical either way.  Falls back to ``overlap`` when the shapes differ.
         ``'auto'`` (default) groups where it measured faster on MI355X (round 5, with the wave-split unit:
-        profiles/r05_c_wsplit_check.jsonl): batch 1-3 (0.50 vs 0.61 ms at batch 1, 0.69 vs 0.72 at 2, 0.88 vs 0.94 at 3) and
-        11-16 (throughput plan: 2.45 vs 2.59 ms at batch 16, profiles/r04_e_grouped_sweep.jsonl); at batch 4-10 the latency plan's
-        sliced kernels run better as two trunks on two streams (0.97 vs 1.01 ms at batch 4, 1.44 vs 1.54 at 8: one trunk's launch
-        gaps and reduction tails hide under the other's kernels), beyond 16 two streams are ahead as before.
+        profiles/r05_c_wsplit_check.jsonl, r05_d_structure_sweep.jsonl, r05_l_plan_and_structure_crossover.jsonl): batch 1-3 (0.50 vs
+        0.61 ms at batch 1, 0.69 vs 0.72 at 2, 0.88 vs 0.94 at 3) and 17-20 (throughput plan: 2.43 vs 2.60 ms at batch 17, 2.59 vs
+        2.83 at 20).  At batch 4-16 two trunks on two streams are ahead - each is then a SINGLE trunk, which keeps the latency plan up
+        to 16 images (0.97 vs 1.01 ms at batch 4, 1.44 vs 1.54 at 8, 1.96 vs 2.10 at 11, 2.40 vs 2.41 at 16: one trunk's launch gaps
+        and reduction tails hide under the other's kernels) - and again from 21 (3.00 vs 3.22 ms).
         ``auto_groups(nb)`` is that rule - the ONE place that holds it (bench.py asks ``launch_structure``).
         ``packed=True``: the kernels write every per-image output straight into ONE (B, 21294)-float record (the
         all-gather payload of config 4); the returned tensors are views of it and ``out['record']`` is the record
@@ -55,7 +56,7 @@ class SpecPipeline:
     @staticmethod
     def auto_groups(nb: int) -> bool:
         """grouped='auto': both trunks per layer as one grouped launch at this batch size?"""
-        return nb <= 3 or 11 <= nb <= 16
+        return nb <= 3 or 17 <= nb <= 20
 
     def _can_group(self, images_shape, cam_shape) -> bool:
         want_group = self.auto_groups(images_shape[0]) if self.grouped == 'auto' else bool(self.grouped)

@@ -44,8 +44,8 @@ def test_launch_structure_rule_lives_in_one_place():
     class Dummy:
         use_cam = True
     pipe = SpecPipeline(Dummy(), Dummy())
-    assert [n for n in range(1, 20) if SpecPipeline.auto_groups(n)] == [1, 2, 3, 11, 12, 13, 14, 15, 16]
-    for n in (1, 3, 4, 10, 11, 16, 17):
+    assert [n for n in range(1, 30) if SpecPipeline.auto_groups(n)] == [1, 2, 3, 17, 18, 19, 20]
+    for n in (1, 3, 4, 10, 11, 16, 17, 20, 21):
         st = pipe.launch_structure((n, 3, 224, 224))
         assert st['grouped'] == SpecPipeline.auto_groups(n)
         assert ('grouped launch' in st['structure']) == st['grouped']
@@ -54,7 +54,7 @@ def test_launch_structure_rule_lives_in_one_place():
     assert not pipe.launch_structure((1, 3, 224, 224), (1, 3, 600, 1066))['grouped']
     # bench.py must not hold a copy of the rule
     src = open(os.path.join(ROOT, 'bench.py')).read()
-    assert 'launch_structure' in src and not re.search(r'11\s*<=\s*b\s*<=\s*16', src)
+    assert 'launch_structure' in src and not re.search(r'1[17]\s*<=\s*b\s*<=\s*(16|20)', src)
 
 
 def test_round5_entry_points_are_declared_and_bound():
