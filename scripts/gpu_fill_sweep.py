@@ -33,9 +33,9 @@ def step_ms(pp, b, iters=150):
     del g
     return round(best, 4)
 out = open(os.path.join(ROOT, 'gpurun_out', 'fill_sweep.jsonl'), 'a')
-for b in (4, 6, 8, 10, 12, 16):
+for b in [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else '4,6,8,10,12,16').split(',')]:
     row = {'batch': b}
-    for fill in (120, 160, 200, 240, 280, 400):
+    for fill in [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else '120,160,200,240,280,400').split(',')]:
         for e in (ce, he): e.set_option('latency_fill_wgs', fill)
         row[f'fill{fill}'] = step_ms(SpecPipeline(cc, hm), b)
     for e in (ce, he): e.set_option('latency_fill_wgs', 240)
