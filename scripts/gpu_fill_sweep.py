@@ -36,7 +36,12 @@ out = open(os.path.join(ROOT, 'gpurun_out', 'fill_sweep.jsonl'), 'a')
 for b in [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else '4,6,8,10,12,16').split(',')]:
     row = {'batch': b}
     for fill in [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else '120,160,200,240,280,400').split(',')]:
-        for e in (ce, he): e.set_option('latency_fill_wgs', fill)
-        row[f'fill{fill}'] = step_ms(SpecPipeline(cc, hm), b)
-    for e in (ce, he): e.set_option('latency_fill_wgs', 240)
+        # fill > 0: the threshold rule; fill < 0: the round model with -fill slots (option latency_unit_model)
+        for e in (ce, he):
+            e.set_option('latency_unit_model', 1 if fill < 0 else 0)
+            e.set_option('latency_unit_slots', -fill if fill < 0 else 256)
+            e.set_option('latency_fill_wgs', fill if fill > 0 else 240)
+        row[f'fill{fill}' if fill > 0 else f'model{-fill}'] = step_ms(SpecPipeline(cc, hm), b)
+    for e in (ce, he):
+        e.set_option('latency_fill_wgs', 240); e.set_option('latency_unit_model', 0)
     line = json.dumps(row); print(line, flush=True); out.write(line + '\n'); out.flush()

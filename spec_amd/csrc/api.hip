@@ -708,6 +708,12 @@ static int trunk_mode(specmi_handle* h, int B, int H, int W, bool pair = false) 
     return px <= (long)nmax * crop ? 1 : 0;
 }
 // the FC layers behind the trunk see batch rows only: the small-batch GEMV kernel (head.hip) up to "latency_max_batch" rows
+// the unit rule of the sliced 64x64 kernel (conv_igemm_sk_plan): "latency_unit_model" = 1 -> the round model (fill <= 0 = -slots),
+// 0 -> the threshold "latency_fill_wgs"
+static int sk_fill(specmi_handle* h) {
+    return opt_i(h, "latency_unit_model", 0) ? -opt_i(h, "latency_unit_slots", 256) : opt_i(h, "latency_fill_wgs", 240);
+}
+
 static bool use_latency_heads(specmi_handle* h, int B) {
     const int plan = opt_i(h, "plan", 0);
     return opt_i(h, "fc_gemv", 1) && (plan == 2 || plan == 3 || (plan == 0 && B <= opt_i(h, "latency_max_batch", 10)));
@@ -738,7 +744,7 @@ static int launch_op(specmi_handle* h, const TrunkOp& op, const OpLaunch& L, con
         const int groups = partner ? 2 : 1;
         int rc;
         SkPlan pl = conv_igemm_sk_plan(L.a, groups, opt_i(h, "latency_target_wgs", 256), opt_i(h, "latency_min_chunks", 4),
-                                       opt_i(h, "latency_fill_wgs", 240));
+                                       sk_fill(h));
         const int fu = opt_i(h, "latency_force_unit", 0);   // tests: 1 leaf / 2 group / 3 whole K per workgroup, whatever the batch
         if (fu) pl.unit = fu == 1 ? 1 : (fu == 2 ? pl.G : pl.leaves);
         // The wave-split unit (conv_wsplit.hip, round 5): a 32x32 tile per workgroup, the G leaves of a group on its waves side by
@@ -886,7 +892,7 @@ static int persist_run(specmi_handle* h, const std::vector<OpLaunch>& La, const 
     const int groups = Lb ? 2 : 1;
     std::vector<PersistLayerHost> lay((size_t)nl);
     float *out0 = nullptr, *out1 = nullptr;
-    const int fill = opt_i(h, "persist_fill_wgs", opt_i(h, "latency_fill_wgs", 240));
+    const int fill = opt_i(h, "persist_fill_wgs", sk_fill(h));
     const int fu = opt_i(h, "latency_force_unit", 0);
     for (int l = 0; l < nl; ++l) {
         PersistLayerHost& P = lay[(size_t)l];
@@ -1647,7 +1653,7 @@ int specmi_conv2d(specmi_handle* h, const float* x, int B, int H, int W, int Cin
         if (split && conv_bf16s_supported(a)) lrc = launch_conv_bf16s(a, dsplit, terms, ctx);
         else if (S != 0) {
             SkPlan pl = conv_igemm_sk_plan(a, 1, opt_i(h, "latency_target_wgs", 256), opt_i(h, "latency_min_chunks", 4),
-                                           opt_i(h, "latency_fill_wgs", 240));
+                                           sk_fill(h));
             if (S > 0) {
                 pl.leaves = S; pl.G = 1;
                 for (int g = 2; g <= 4; ++g)

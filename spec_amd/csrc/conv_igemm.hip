@@ -261,6 +261,28 @@ SkPlan conv_igemm_sk_plan(const ConvArgs& a, int groups, int target_wgs, int min
     for (int g = 2; g <= 4; ++g)
         if (pl.leaves % g == 0) pl.G = g;
     const long tiles = (long)conv_igemm_sk_tiles(a, groups);
+    if (fill_wgs <= 0) {
+        // fill_wgs <= 0: the round model instead of a threshold (round 5; slots = -fill_wgs, 0 = one per CU): a launch lasts
+        // ceil(workgroups / slots) rounds of one workgroup's chunks (~0.5 us each on the shared matrix pipe) plus, when K is also cut
+        // across workgroups, the slab hop (~3 us) and the last arriver's read of S slabs of 16 KB (~0.25 us each).  The candidates
+        // are the three units; ties go to the larger one (fewer slabs).  It reproduces what the threshold sweeps found batch by
+        // batch - group at 10 images, leaves at 12, where 240 / 400 workgroups were each right once (profiles/r05_n_*).
+        const long slots = fill_wgs < 0 ? -fill_wgs : 256;
+        const int nch = a.KH * a.KW * (a.Cin / 32) + (a.x2 ? a.Cin2 / 32 : 0);
+        const int cand[3] = {pl.leaves, pl.G, 1};
+        double best = 0.0;
+        pl.unit = pl.leaves;
+        for (int i = 0; i < 3; ++i) {
+            const int u = cand[i];
+            if (i && u == cand[i - 1]) continue;
+            const long S = pl.leaves / u;
+            const long wgs = tiles * S;
+            const double chunks = (double)(nch / pl.leaves) * u;
+            const double cost = (double)((wgs + slots - 1) / slots) * chunks * 0.5 + (S > 1 ? 3.0 + 0.25 * (double)S : 0.0);
+            if (i == 0 || cost < best - 1e-9) { best = cost; pl.unit = u; }
+        }
+        return pl;
+    }
     if (tiles >= fill_wgs) pl.unit = pl.leaves;
     else if (tiles * (pl.leaves / pl.G) >= fill_wgs) pl.unit = pl.G;
     else pl.unit = 1;
