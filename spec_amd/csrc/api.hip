@@ -710,8 +710,12 @@ static int trunk_mode(specmi_handle* h, int B, int H, int W, bool pair = false) 
 // the FC layers behind the trunk see batch rows only: the small-batch GEMV kernel (head.hip) up to "latency_max_batch" rows
 // the unit rule of the sliced 64x64 kernel (conv_igemm_sk_plan): "latency_unit_model" = 1 -> the round model (fill <= 0 = -slots),
 // 0 -> the threshold "latency_fill_wgs"
-static int sk_fill(specmi_handle* h) {
-    return opt_i(h, "latency_unit_model", 0) ? -opt_i(h, "latency_unit_slots", 256) : opt_i(h, "latency_fill_wgs", 240);
+// px = pixels of the trunk call (B x H x W): beyond ten 224 x 224 crops' worth - a single trunk keeps the latency plan up to 16 - the
+// threshold is "latency_fill_wgs_large" (400): measured per batch under the auto structure (profiles/r05_n_unit_rule_sweep.jsonl:
+// 1.99 -> 1.80 ms at batch 11, 2.13 -> 1.91 at 12, 2.20 -> 2.10 at 14; at batch <= 10 240 stays ahead: 1.55 vs 2.06 ms at 10)
+static int sk_fill(specmi_handle* h, long px = 0) {
+    if (opt_i(h, "latency_unit_model", 0)) return -opt_i(h, "latency_unit_slots", 256);
+    return px > 10L * 224 * 224 ? opt_i(h, "latency_fill_wgs_large", 400) : opt_i(h, "latency_fill_wgs", 240);
 }
 
 static bool use_latency_heads(specmi_handle* h, int B) {
@@ -744,7 +748,7 @@ static int launch_op(specmi_handle* h, const TrunkOp& op, const OpLaunch& L, con
         const int groups = partner ? 2 : 1;
         int rc;
         SkPlan pl = conv_igemm_sk_plan(L.a, groups, opt_i(h, "latency_target_wgs", 256), opt_i(h, "latency_min_chunks", 4),
-                                       sk_fill(h));
+                                       sk_fill(h, (long)nb * Himg * Wimg));
         const int fu = opt_i(h, "latency_force_unit", 0);   // tests: 1 leaf / 2 group / 3 whole K per workgroup, whatever the batch
         if (fu) pl.unit = fu == 1 ? 1 : (fu == 2 ? pl.G : pl.leaves);
         // The wave-split unit (conv_wsplit.hip, round 5): a 32x32 tile per workgroup, the G leaves of a group on its waves side by
