@@ -144,7 +144,9 @@ const char* specmi_version(void);
  *       pair at batch 1, profiles/r05_a_persist_ab.jsonl) - kept for the record and for other parts; at most two such forwards may be
  *       in flight per device (the grid must be co-resident).  "persist_wgs" (512 pair / 256 single), "persist_l2_prefetch",
  *       "persist_spin_limit", "persist_min_run"; specmi_sync_status reports a spin that gave up.
- *   Tuning / tests: "latency_target_wgs" (256), "latency_min_chunks" (4), "latency_wino_min_tiles" (128), "latency_fill_wgs" (240),
+ *   Tuning / tests: "latency_target_wgs" (256), "latency_min_chunks" (4), "latency_wino_min_tiles" (128), "latency_fill_wgs" (240; beyond ten
+ *   224 x 224 crops' worth of pixels "latency_fill_wgs_large", 400), "latency_unit_model" (0; 1 = pick the unit by a round model with
+ *   "latency_unit_slots" 256 instead of the threshold: measured equal or worse, kept for tuning),
  *   "latency_force_unit" (0 = by batch, 1 / 2 / 3 = a leaf / a group / the whole K per workgroup: same bits),
  *   "conv2d_sk" (specmi_conv2d only: 0 = throughput kernel, -1 = the latency plan's rule, n > 1 = n leaves),
  *   "smpl_skin_split" (-1 = by batch: three waves per 32-vertex group up to 64 images, one beyond; 0 / 1 = never / always: same bits),

@@ -40,7 +40,7 @@ class SpecPipeline:
         profiles/r05_c_wsplit_check.jsonl, r05_d_structure_sweep.jsonl, r05_l_plan_and_structure_crossover.jsonl): batch 1-3 (0.50 vs
         0.61 ms at batch 1, 0.69 vs 0.72 at 2, 0.88 vs 0.94 at 3) and 17-20 (throughput plan: 2.43 vs 2.60 ms at batch 17, 2.59 vs
         2.83 at 20).  At batch 4-16 two trunks on two streams are ahead - each is then a SINGLE trunk, which keeps the latency plan up
-        to 16 images (0.97 vs 1.01 ms at batch 4, 1.44 vs 1.54 at 8, 1.96 vs 2.10 at 11, 2.40 vs 2.41 at 16: one trunk's launch gaps
+        to 16 images (0.97 vs 1.01 ms at batch 4, 1.44 vs 1.54 at 8, 1.81 vs 2.09 at 11, 2.10 vs 2.22 at 14, 2.40 vs 2.41 at 16: one trunk's launch gaps
         and reduction tails hide under the other's kernels) - and again from 21 (3.00 vs 3.22 ms).
         ``auto_groups(nb)`` is that rule - the ONE place that holds it (bench.py asks ``launch_structure``).
         ``packed=True``: the kernels write every per-image output straight into ONE (B, 21294)-float record (the
