@@ -96,8 +96,118 @@ def resnet50_conv_specs(blocks=RESNET50_BLOCKS):
     return specs
 
 
-def resnet50_state(seed: int, prefix: str = '', blocks=RESNET50_BLOCKS) -> 'OrderedDict[str, np.ndarray]':
-    """Random ResNet-50 (101 / 152 by ``blocks``) trunk parameters with activations kept O(1) through the blocks."""
+def student_t3(seed, name, shape) -> np.ndarray:
+    """Heavy-tailed unit-variance draws: Student-t with 3 degrees of freedom, z0 / sqrt((z1^2 + z2^2 + z3^2) / 3) / sqrt(3),
+    from the Irwin-Hall normals above (IEEE sqrt / divide are exactly rounded, so still bit-reproducible across hosts).
+    The tail is clipped at 12 standard deviations (a handful of weights per trunk)."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    z = [normal(seed, f'{name}.t{i}', (n,)).astype(np.float64) for i in range(4)]
+    chi = (z[1] * z[1] + z[2] * z[2] + z[3] * z[3]) / 3.0
+    t = z[0] / np.sqrt(np.maximum(chi, 1e-3)) / 1.7320508075688772
+    return np.clip(t, -12.0, 12.0).astype(np.float32).reshape(shape)
+
+
+def log_uniform_pow2(seed, name, n, lo_exp=-13, hi_exp=6) -> np.ndarray:
+    """n float64 values (1 + u) * 2^k, k uniform integer in [lo_exp, hi_exp]: log-uniform over [1.2e-4, 128) octave by octave,
+    built with ldexp only (no libm pow / exp)."""
+    k = np.floor(uniform01(seed, name + '.exp', n) * (hi_exp - lo_exp + 1)).astype(np.int64) + lo_exp
+    return np.ldexp(1.0 + uniform01(seed, name + '.man', n), k)
+
+
+def _pretrained_like_conv_bn(sd, seed, prefix, name, bn, cin, cout, k):
+    """One convolution + BatchNorm of a 'pretrained_like' trunk before calibration: running_var log-uniform
+    over six decades, gamma ~ N(0.5, 0.4) with ~5 % exact zeros, ~10 % negative and 1 % six times louder, beta ~ N(0, 0.5), Student-t(3) filters,
+    ~0.5 % (at least one) all-zero filters.  ``_calibrate_trunk`` then sizes every filter and sets running_mean."""
+    var = log_uniform_pow2(seed, bn + '.running_var', cout)
+    fscale = np.sqrt(var / (cin * k * k))
+    w = student_t3(seed, name + '.weight', (cout, cin, k, k)).astype(np.float64) * fscale.reshape(cout, 1, 1, 1)
+    dead = uniform01(seed, name + '.dead', cout) < 0.005
+    dead[int(uniform01(seed, name + '.dead1', 1)[0] * cout)] = True
+    w[dead] = 0.0
+    gamma = normal(seed, bn + '.weight', (cout,), std=0.4, mean=0.5).astype(np.float64)
+    gamma[uniform01(seed, bn + '.zero', cout) < 0.05] = 0.0
+    gamma[uniform01(seed, bn + '.outlier', cout) < 0.01] *= 6.0          # the few very loud channels every trained trunk has
+    sd[f'{prefix}{name}.weight'] = w.astype(np.float32)
+    sd[f'{prefix}{bn}.weight'] = gamma.astype(np.float32)
+    sd[f'{prefix}{bn}.bias'] = normal(seed, bn + '.bias', (cout,), std=0.5)
+    sd[f'{prefix}{bn}.running_mean'] = np.zeros(cout, np.float32)
+    sd[f'{prefix}{bn}.running_var'] = var.astype(np.float32)
+    sd[f'{prefix}{bn}.num_batches_tracked'] = np.array(0, dtype=np.int64)
+
+
+def _calibrate_trunk(sd, seed, prefix, specs, basic):
+    """What training does to a released checkpoint, done to the random trunk: one float64 pass over four calibration crops, layer
+    by layer; each filter is scaled by the POWER OF TWO that brings the standard deviation of its pre-BN channel (over batch and
+    pixels) within [0.71, 1.41] of sqrt(running_var), and running_mean is set to the channel's mean plus a N(0, 0.3 sigma) offset,
+    rounded to sigma / 32.  The measured statistics only enter through those two coarse roundings, so hosts whose float64
+    convolutions differ in the last bits still produce bit-identical parameters (a channel would have to sit within ~1e-12 of a
+    rounding boundary), and power-of-two scaling keeps the fp32 filters exact.  Dead filters (pre-BN identically 0) keep a random
+    running_mean.  torch is used for the float64 convolutions only."""
+    import torch
+    import torch.nn.functional as F
+    x = torch.from_numpy(images(seed + 7919, 4, saturate=True)).double()
+
+    def conv_bn(x, spec, relu):
+        name, _cin, cout, _k, stride, pad, bn = spec
+        w = torch.from_numpy(sd[f'{prefix}{name}.weight']).double()
+        y = F.conv2d(x, w, stride=stride, padding=pad)
+        yc = y.transpose(0, 1).reshape(cout, -1)
+        mean, std = yc.mean(dim=1).numpy(), yc.std(dim=1, unbiased=False).numpy()
+        var = sd[f'{prefix}{bn}.running_var'].astype(np.float64)
+        sigma = np.sqrt(var)
+        live = std > 0
+        m, e = np.frexp(np.where(live, sigma / np.where(live, std, 1.0), 1.0))       # ratio = m * 2^e, m in [0.5, 1)
+        q = np.ldexp(1.0, np.where(m >= 0.7071067811865476, e, e - 1))
+        q = np.where(live, q, 1.0)
+        xi = normal(seed, bn + '.running_mean', (cout,)).astype(np.float64)
+        rm = np.where(live, np.round((mean * q / sigma + 0.3 * xi) * 32.0) / 32.0, xi) * sigma
+        sd[f'{prefix}{name}.weight'] = (sd[f'{prefix}{name}.weight'].astype(np.float64) * q.reshape(-1, 1, 1, 1)).astype(np.float32)
+        sd[f'{prefix}{bn}.running_mean'] = rm.astype(np.float32)
+        g = torch.from_numpy(sd[f'{prefix}{bn}.weight'].astype(np.float64))
+        b = torch.from_numpy(sd[f'{prefix}{bn}.bias'].astype(np.float64))
+        rm32 = torch.from_numpy(sd[f'{prefix}{bn}.running_mean'].astype(np.float64))
+        y = (y * torch.from_numpy(q).view(1, -1, 1, 1) - rm32.view(1, -1, 1, 1)) / torch.from_numpy(np.sqrt(var + 1e-5)).view(1, -1, 1, 1) \
+            * g.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+        return y.clamp_(min=0) if relu else y
+
+    x = F.max_pool2d(conv_bn(x, specs[0], True), 3, 2, 1)
+    blocks = OrderedDict()                          # 'layer1.0' -> {member name: spec}
+    for s_ in specs[1:]:
+        blocks.setdefault('.'.join(s_[0].split('.')[:2]), {})[s_[0].split('.', 2)[2]] = s_
+    for members in blocks.values():
+        out = conv_bn(x, members['conv1'], True)
+        if basic:
+            out = conv_bn(out, members['conv2'], False)
+        else:
+            out = conv_bn(conv_bn(out, members['conv2'], True), members['conv3'], False)
+        identity = conv_bn(x, members['downsample.0'], False) if 'downsample.0' in members else x
+        x = (out + identity).clamp_(min=0)
+    return sd
+
+
+def _pretrained_like_trunk(seed, prefix, specs, basic=False):
+    """Bottleneck or BasicBlock trunk with the statistics of a released checkpoint (``_pretrained_like_conv_bn`` then
+    ``_calibrate_trunk``); ~20 s of float64 CPU convolutions per trunk, cached per (seed, architecture) in this process."""
+    key = (seed, prefix, tuple(s[0] for s in specs), basic)
+    if key not in _PL_CACHE:
+        sd = OrderedDict()
+        for (name, cin, cout, k, _s, _p, bn) in specs:
+            _pretrained_like_conv_bn(sd, seed, prefix, name, bn, cin, cout, k)
+        _PL_CACHE[key] = _calibrate_trunk(sd, seed, prefix, specs, basic)
+    return OrderedDict((k, v.copy()) for k, v in _PL_CACHE[key].items())
+
+
+_PL_CACHE = {}
+STATS = ('benign', 'pretrained_like')
+
+
+def resnet50_state(seed: int, prefix: str = '', blocks=RESNET50_BLOCKS, stats: str = 'benign') -> 'OrderedDict[str, np.ndarray]':
+    """Random ResNet-50 (101 / 152 by ``blocks``) trunk parameters.  ``stats='benign'``: activations kept O(1) through the blocks
+    (BN variances in [0.8, 1.2]); ``'pretrained_like'``: the statistics of a released checkpoint (``_pretrained_like_conv_bn``)."""
+    if stats not in STATS:
+        raise ValueError(f'stats must be one of {STATS}')
+    if stats == 'pretrained_like':
+        return _pretrained_like_trunk(seed, prefix, resnet50_conv_specs(blocks))
     sd = OrderedDict()
     for (name, cin, cout, k, _s, _p, bn) in resnet50_conv_specs(blocks):
         fan_in = cin * k * k
@@ -133,8 +243,13 @@ def resnet34_conv_specs(blocks=RESNET50_BLOCKS):
     return specs
 
 
-def resnet34_state(seed: int, prefix: str = '', blocks=RESNET50_BLOCKS) -> 'OrderedDict[str, np.ndarray]':
-    """Random ResNet-34 (18 by ``blocks``) trunk parameters, activations O(1) through the blocks (bn2 damps the residual branch)."""
+def resnet34_state(seed: int, prefix: str = '', blocks=RESNET50_BLOCKS, stats: str = 'benign') -> 'OrderedDict[str, np.ndarray]':
+    """Random ResNet-34 (18 by ``blocks``) trunk parameters, activations O(1) through the blocks (bn2 damps the residual branch);
+    ``stats='pretrained_like'`` as in ``resnet50_state``."""
+    if stats not in STATS:
+        raise ValueError(f'stats must be one of {STATS}')
+    if stats == 'pretrained_like':
+        return _pretrained_like_trunk(seed, prefix, resnet34_conv_specs(blocks), basic=True)
     sd = OrderedDict()
     for (name, cin, cout, k, _s, _p, bn) in resnet34_conv_specs(blocks):
         sd[f'{prefix}{name}.weight'] = normal(seed, name + '.weight', (cout, cin, k, k), std=math.sqrt(2.0 / (cin * k * k)))
@@ -185,19 +300,19 @@ def hrnet_state(seed: int, width: int = 32, use_conv: bool = True, prefix: str =
     return sd
 
 
-def resnet_family_state(seed: int, backbone: str, prefix: str = ''):
+def resnet_family_state(seed: int, backbone: str, prefix: str = '', stats: str = 'benign'):
     """(trunk state, feature width) of a torchvision-family trunk by name (resnet18 / 34 / 50 / 101 / 152)."""
     kind, blocks = RESNET_FAMILY[backbone]
     if kind == 'basic':
-        return resnet34_state(seed, prefix, blocks), 512
-    return resnet50_state(seed, prefix, blocks), 2048
+        return resnet34_state(seed, prefix, blocks, stats), 512
+    return resnet50_state(seed, prefix, blocks, stats), 2048
 
 
 def camcalib_state(seed: int = 1001, fc_std: float = 0.05, nbins: int = C.NUM_CAMCALIB_BINS, backbone: str = 'resnet50',
-                   num_fc_layers: int = 1, num_fc_channels: int = 1024):
+                   num_fc_layers: int = 1, num_fc_channels: int = 1024, stats: str = 'benign'):
     """CameraRegressorNetwork parameters (camcalib/model.py:40-70 layout): one Linear per angle, or the
     ``fc_*.{0..L-1}`` Linear chain of ``_get_fc_layers``."""
-    sd, feat = resnet_family_state(seed, backbone, 'backbone.')
+    sd, feat = resnet_family_state(seed, backbone, 'backbone.', stats)
     for head in ('fc_vfov', 'fc_pitch', 'fc_roll'):
         if num_fc_layers == 1:
             sd[f'{head}.weight'] = normal(seed, head + '.weight', (nbins, feat), std=fc_std)
@@ -222,16 +337,19 @@ def _random_rot6d(seed, name, n):
     return out.reshape(-1).astype(np.float32)
 
 
-def hmr_state(seed: int = 1002, use_cam_feats: bool = True, dec_gain: float = 1.0, backbone: str = 'resnet50'):
+def hmr_state(seed: int = 1002, use_cam_feats: bool = True, dec_gain: float = 1.0, backbone: str = 'resnet50',
+              stats: str = 'benign', cam_gain: float = None):
     """HMR parameters: trunk + HMRHead (fc1, fc2, decpose, decshape, deccam, init_*).  ``backbone``: 'resnet50' or
-    'hrnet_w32-conv' / 'hrnet_w32-interp' / 'hrnet_w48-...' (spec/models/hmr.py:44-53)."""
+    'hrnet_w32-conv' / 'hrnet_w32-interp' / 'hrnet_w48-...' (spec/models/hmr.py:44-53).  ``dec_gain`` 4 is Xavier gain 1 on the
+    decoders; ``cam_gain`` (default: ``dec_gain``) sizes ``deccam`` alone - a trained regressor keeps the weak-perspective scale
+    away from 0, where tz = 2f / (res * s) is ill-conditioned for the reference's own fp32 arithmetic too."""
     if backbone.startswith('hrnet'):
         name, mode = backbone.split('-')
         width = 32 if name == 'hrnet_w32' else 48
         sd = hrnet_state(seed, width, mode == 'conv', 'backbone.')
         feat = width * 15
     else:
-        sd, feat = resnet_family_state(seed, backbone, 'backbone.')
+        sd, feat = resnet_family_state(seed, backbone, 'backbone.', stats)
     nin = feat + 144 + 13 + (7 if use_cam_feats else 0)
 
     def linear(name, nout, nin_, bound=None, bias_bound=None):
@@ -245,7 +363,8 @@ def hmr_state(seed: int = 1002, use_cam_feats: bool = True, dec_gain: float = 1.
     # upstream uses xavier_uniform(gain=0.01); a larger gain makes the synthetic poses vary
     # between images so that parity tests exercise the full rot6d / LBS range.
     for name, nout in (('decpose', 144), ('decshape', 10), ('deccam', 3)):
-        xav = dec_gain * 0.25 * math.sqrt(6.0 / (1024 + nout))
+        gain = cam_gain if (name == 'deccam' and cam_gain is not None) else dec_gain
+        xav = gain * 0.25 * math.sqrt(6.0 / (1024 + nout))
         linear(name, nout, 1024, bound=xav, bias_bound=0.01)
     sd['head.init_pose'] = _random_rot6d(seed, 'head.init_pose', 24).reshape(1, 144)
     sd['head.init_shape'] = normal(seed, 'head.init_shape', (1, 10), std=0.5)
@@ -311,8 +430,9 @@ def h36m_regressor(seed: int = 1003, nv: int = C.NUM_SMPL_VERTS) -> np.ndarray:
 # inputs
 # --------------------------------------------------------------------------------------
 
-def images(seed: int, batch: int, h: int = 224, w: int = 224) -> np.ndarray:
-    """(B,3,H,W) fp32 crops: uniform[0,1) pixels, ImageNet-normalised (spec/constants.py:20-21)."""
+def images(seed: int, batch: int, h: int = 224, w: int = 224, saturate: bool = False) -> np.ndarray:
+    """(B,3,H,W) fp32 crops: uniform[0,1) pixels, ImageNet-normalised (spec/constants.py:20-21); ``saturate`` adds clipped
+    black / white rectangles."""
     x = uniform01(seed, 'images', batch * 3 * h * w).reshape(batch, 3, h, w)
     # per-image contrast / per-channel brightness / a horizontal ramp, so that images (and the
     # features, camera angles and poses regressed from them) differ from one another
@@ -321,6 +441,15 @@ def images(seed: int, batch: int, h: int = 224, w: int = 224) -> np.ndarray:
     ramp = (uniform01(seed, 'images.ramp', batch).reshape(batch, 1, 1, 1) - 0.5) \
         * np.linspace(-1.0, 1.0, w).reshape(1, 1, 1, w)
     x = np.clip(x * gain + offs * (1.0 - gain) + 0.5 * ramp, 0.0, 1.0)
+    if saturate:
+        # two rectangles per image clipped to pure black / pure white (blown highlights, letter-box bars of a real frame):
+        # constant regions whose stem and Winograd input tiles carry no variation at all
+        u = uniform01(seed, 'images.sat', batch * 8).reshape(batch, 2, 4)
+        for b in range(batch):
+            for j in range(2):
+                y0, x0 = int(u[b, j, 0] * h * 0.7), int(u[b, j, 1] * w * 0.7)
+                y1, x1 = y0 + 8 + int(u[b, j, 2] * h * 0.3), x0 + 8 + int(u[b, j, 3] * w * 0.3)
+                x[b, :, y0:y1, x0:x1] = float(j)
     mean = np.array(C.IMG_NORM_MEAN).reshape(1, 3, 1, 1)
     std = np.array(C.IMG_NORM_STD).reshape(1, 3, 1, 1)
     return ((x - mean) / std).astype(np.float32)

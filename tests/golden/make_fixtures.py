@@ -51,6 +51,7 @@ torch.set_grad_enabled(False)
 torch.manual_seed(0)
 
 SEED_CAMCALIB, SEED_HMR, SEED_SMPL, SEED_IMG = 1001, 1002, 1003, 20210001
+PL_SEED_CC, PL_SEED_HM, PL_SEED_IMG, PL_DEC_GAIN, PL_CAM_GAIN = 2101, 2102, 2103, 4.0, 1.0     # = tests/util.py
 
 
 def t(a):
@@ -179,6 +180,38 @@ def generate(OUT, upstream=False):
     mpjpe24, pampjpe24 = CE.eval_j_24(pj, gj)
     np.savez(os.path.join(OUT, 'metrics.npz'), seed=rng_seed, batch=Bm, seed_smpl=SEED_SMPL,
              mpjpe=mpjpe, pampjpe=pampjpe, v2v=v2v, mpjpe24=mpjpe24, pampjpe24=pampjpe24)
+
+    # ---- (7) the same two networks with released-checkpoint-like statistics (synth stats='pretrained_like') -------------
+    # BN variances over six decades, zero / negative gammas, dead filters, Student-t filters, O(1)-gain decoders, saturated
+    # crops: call sites that load such checkpoints are spec/tester.py:63-71 and scripts/camcalib_demo.py:74-81
+    B = 2
+    imgs = synth.images(PL_SEED_IMG + 100, B, saturate=True)
+    net = ref['camcalib_model'].CameraRegressorNetwork(backbone='resnet50', num_fc_layers=1, num_fc_channels=1024).eval()
+    load_numpy_state(net, synth.camcalib_state(PL_SEED_CC, stats='pretrained_like'))
+    lg = net(t(imgs))
+    ang = CU.convert_preds_to_angles(*lg, loss_type='softargmax_biased_l2')
+    np.savez(os.path.join(OUT, 'camcalib_e2e_pl.npz'), seed_weights=PL_SEED_CC, seed_images=PL_SEED_IMG + 100, batch=B,
+             logits_vfov=lg[0].numpy(), logits_pitch=lg[1].numpy(), logits_roll=lg[2].numpy(),
+             vfov=ang[0].numpy(), pitch=ang[1].numpy(), roll=ang[2].numpy())
+    scale, center, img_w, img_h = synth.bbox_inputs(PL_SEED_IMG + 100, B, img_w=640., img_h=480.)
+    Rl, Kl = [], []
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(os.path.join(td, 'camcalib'))
+        for i in range(B):
+            f_pix = np.float64(480 / 2. / np.tan(ang[0].numpy()[i] / 2.))              # scripts/camcalib_demo.py:129
+            joblib.dump({'vfov': ang[0].numpy()[i], 'f_pix': f_pix, 'pitch': ang[1].numpy()[i], 'roll': ang[2].numpy()[i]},
+                        os.path.join(td, 'camcalib', f'im{i}.jpg.pkl'))
+            R, K, *_ = CP.read_cam_params(td, f'im{i}.jpg', (480, 640))
+            Rl.append(R); Kl.append(K)
+    R, K = torch.stack(Rl), torch.stack(Kl)
+    model = HMR(backbone='resnet50', img_res=224, pretrained=None, use_cam=True, use_cam_feats=True).eval()
+    load_numpy_state(model, synth.hmr_state(PL_SEED_HM, True, dec_gain=PL_DEC_GAIN, cam_gain=PL_CAM_GAIN, stats='pretrained_like'))
+    out = model(t(imgs), cam_rotmat=R, cam_intrinsics=K, bbox_scale=t(scale), bbox_center=t(center), img_w=t(img_w), img_h=t(img_h))
+    np.savez_compressed(os.path.join(OUT, 'hmr_e2e_pl.npz'), seed_weights=PL_SEED_HM, seed_smpl=SEED_SMPL,
+                        seed_images=PL_SEED_IMG + 100, batch=B, dec_gain=PL_DEC_GAIN, cam_gain=PL_CAM_GAIN, cam_rotmat=R.numpy(),
+                        cam_intrinsics=K.numpy(), bbox_scale=scale, bbox_center=center, img_w=img_w, img_h=img_h,
+                        out_keys=np.array(list(out.keys())), **{f'out_{k}': v.numpy() for k, v in out.items()})
+    print('pretrained_like', {k: (tuple(v.shape), float(v.abs().max())) for k, v in out.items()})
 
     sz = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith('.npz'))
     print('fixtures written to', OUT, 'total bytes', sz)

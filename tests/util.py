@@ -78,3 +78,48 @@ def pinned_plan(plan, *modules):
     finally:
         for m, o in zip(modules, old):
             m.set_plan(o)
+
+
+# ---- released-checkpoint-like statistics (spec_amd.synth, stats='pretrained_like') -------------------
+PL_SEED_CC, PL_SEED_HM, PL_SEED_IMG = 2101, 2102, 2103
+PL_DEC_GAIN, PL_CAM_GAIN = 4.0, 1.0       # Xavier gain 1 on decpose / decshape; deccam keeps the weak-perspective scale off 0
+
+
+def pretrained_like_states():
+    """(CamCalib state, HMR state): BN variances over six decades, zero / negative / loud gammas, dead filters, Student-t
+    weights, calibrated running statistics, O(1)-gain decoders (~45 s of float64 CPU convolutions, once per process)."""
+    from spec_amd import synth
+    if 'pl_states' not in _cache:
+        _cache['pl_states'] = (synth.camcalib_state(PL_SEED_CC, stats='pretrained_like'),
+                               synth.hmr_state(PL_SEED_HM, True, dec_gain=PL_DEC_GAIN, cam_gain=PL_CAM_GAIN, stats='pretrained_like'))
+    return _cache['pl_states']
+
+
+def pl_oracle_models(double=False):
+    from oracle import heads
+    from oracle.models import CamCalibOracle, HMROracle, load_numpy_state
+    torch.set_grad_enabled(False)
+    heads.set_assets(smpl_model=smpl_model())
+    cs, hs = pretrained_like_states()
+    cc = load_numpy_state(CamCalibOracle().eval(), cs)
+    hm = load_numpy_state(HMROracle(use_cam=True, use_cam_feats=True).eval(), hs)
+    return (cc.double(), hm.double()) if double else (cc, hm)
+
+
+def pl_gpu_models(device='cuda:0'):
+    from spec_amd import assets
+    from spec_amd.modules import HMR, CameraRegressorNetwork
+    assets.use_synthetic_assets(SEED_SMPL)
+    cs, hs = pretrained_like_states()
+    cc = CameraRegressorNetwork()
+    cc.load_state_dict({k: t(v) for k, v in cs.items()}, strict=True)
+    hm = HMR(use_cam=True, use_cam_feats=True)
+    missing, unexpected = hm.load_state_dict({k: t(v) for k, v in hs.items()}, strict=False)
+    assert not unexpected and all(m.startswith('smpl.') for m in missing), (missing, unexpected)
+    return cc.to(device).eval(), hm.to(device).eval()
+
+
+def per_channel_errors(x, ref64):
+    """Per-channel max-norm error of an (..., C) map against a float64 reference of the same shape -> (C,) float64."""
+    d = np.abs(np.asarray(x, dtype=np.float64) - np.asarray(ref64, dtype=np.float64))
+    return d.reshape(-1, d.shape[-1]).max(axis=0)
