@@ -722,10 +722,14 @@ def main():
                     pp(*ins)
                     torch.cuda.synchronize()
                     nodes = sum(r['launches'] for m in (cc, hm) for r in m._engine.profile_read())
-                    for m in (cc, hm):
-                        m._engine.profile(False)
                 except Exception:
                     pass
+                finally:    # the launch profiler must not stay on: it adds events per launch and disables the opt-in fused paths
+                    for m in (cc, hm):
+                        try:
+                            m._engine.profile(False)
+                        except Exception:
+                            pass
                 del g
                 return round(best, 4), nodes
 

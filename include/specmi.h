@@ -370,7 +370,8 @@ int specmi_trunk_plan(specmi_handle* h, int B, int H, int W, int pair, int32_t* 
 
 /* Synchronises the device.  *persist_err: 0 = the handle's persistent launches all completed their hand-offs; 1 = a bounded spin
  * gave up (the results of that launch are garbage: a protocol error or a grid that was not co-resident - more than two persistent
- * forwards in flight on one device); < 0 = the control block was not left clean. */
+ * forwards in flight on one device); 3 = the bounded wait inside a fused tail (option "tail_fuse") gave up; < 0 = a control block
+ * was not left clean (-1 / -2 the walker's, -3 the fused tails'). */
 int specmi_sync_status(specmi_handle* h, int32_t* persist_err);
 /* Zeroes the hand-off counters on `stream`.  The library does this itself at specmi_commit and after any forward that returned
  * an error; a caller that destroyed a captured graph mid-replay (or killed a launch some other way) calls it before the next forward. */

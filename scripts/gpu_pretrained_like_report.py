@@ -40,19 +40,17 @@ def main():
     q = e_b[ok] / e_cpu[ok]
     print(f'a SECOND run of the CPU fp32 oracle (channels_last, 1 thread: another summation order) against the first, e_2 / e_1 per channel: '
           f'median {np.median(q):.3f}  p99 {np.quantile(q, 0.99):.3f}  max {q.max():.3f}  channels over 2x: {int((q > 2).sum())}')
-    print('=> per channel, e_cpu below is the larger of the two CPU runs; bound = max(2 e_cpu, 4 ulp of the channel maximum)')
+    print(f'=> per channel, e_cpu below is the larger of the two CPU runs; asserted: median <= {T.CHANNEL_MEDIAN}, p99 <= {T.CHANNEL_P99}, every channel <= max({T.CHANNEL_HARD:.0f} e_cpu, {T.CHANNEL_FLOOR:.0f} ulp of its maximum)')
     print()
     print(f'{"plan":11s} {"wino":>4s} {"fuse":>4s} {"tensor rel vs f64":>18s} {"vs CPU fp32":>12s} {"median e_gpu/e_cpu":>19s} {"p99":>7s} {"max":>7s} '
-          f'{"worst / bound":>13s} {"over":>5s}  worst channel (e_gpu, e_cpu, max |ref|)')
+          f'{"over 2x":>7s} {"worst / bound":>13s} {"over":>5s}  worst channel (e_gpu, e_cpu, max |ref|)')
     for plan in T.PLANS:
         for wino, fuse in T.STRUCTURES:
             feat = T.gpu_trunk(pl['hm'], pl['x'], plan, wino, fuse)
             rep = T.channel_report(feat, (f32, pl['f32b']), f64)
-            ok = (rep['e_cpu'] > 0)
-            q = rep['e_gpu'][ok] / rep['e_cpu'][ok]
             c = rep['argworst']
-            print(f'{plan:11s} {wino:4d} {fuse:4d} {rel_err(feat, f64):18.3e} {rel_err(feat, f32):12.3e} {np.median(q):19.3f} '
-                  f'{np.quantile(q, 0.99):7.3f} {q.max():7.3f} {rep["worst"]:13.3f} {rep["n_over"]:5d}  '
+            print(f'{plan:11s} {wino:4d} {fuse:4d} {rel_err(feat, f64):18.3e} {rel_err(feat, f32):12.3e} {rep["median"]:19.3f} '
+                  f'{rep["p99"]:7.3f} {rep["max"]:7.3f} {rep["n_over2"]:7d} {rep["worst"]:13.3f} {rep["n_over"]:5d}  '
                   f'c={c} ({rep["e_gpu"][c]:.3e}, {rep["e_cpu"][c]:.3e}, {rep["cmax"][c]:.3e})')
     print()
     from oracle.models import full_pipeline

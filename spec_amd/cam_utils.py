@@ -18,19 +18,21 @@ import torch
 from . import constants as C
 from .engine import Engine
 
-_engines = {}
-_engines_lock = threading.Lock()
+_tls = threading.local()
 
 
 def _engine(device) -> Engine:
-    """The parameter-less decode engine of a (device, thread): a handle is not thread-safe (include/specmi.h), so the module-level
-    helpers below keep one per calling thread - a server loop with worker threads may call them concurrently."""
+    """The parameter-less decode engine of the calling thread on ``device``.  A handle is not thread-safe and is driven from one
+    stream at a time (include/specmi.h), so the module-level helpers below keep one per (thread, device) in thread-local storage: worker
+    threads of a server loop may call them concurrently, each on its own ``torch.cuda.Stream``, and a thread's handles are
+    destroyed with it (tests/test_gpu_threads.py)."""
     dev = torch.device('cuda', device.index if device.index is not None else torch.cuda.current_device())
-    key = (dev, threading.get_ident())
-    with _engines_lock:
-        if key not in _engines:
-            _engines[key] = Engine('camcalib', dev)   # decode needs no parameters
-        return _engines[key]
+    engines = getattr(_tls, 'engines', None)
+    if engines is None:
+        engines = _tls.engines = {}
+    if dev not in engines:
+        engines[dev] = Engine('camcalib', dev)   # decode needs no parameters
+    return engines[dev]
 
 
 # ---- bin tables (camcalib/cam_utils.py:23-63) -------------------------------------------------------------

@@ -9,7 +9,7 @@
 
 using namespace specmi;
 
-std::string g_create_err;
+thread_local std::string g_create_err;   // specmi_create's message when no handle exists yet, per calling thread
 
 int fail(specmi_handle* h, int code, const char* fmt, ...) {
     char buf[512];
@@ -782,19 +782,21 @@ static int launch_op(specmi_handle* h, const TrunkOp& op, const OpLaunch& L, con
             const bool take = wsplit > 1 || (pl.unit != pl.leaves && !L.a.x2 && t32 * ng <= max_units);
             if (take && conv_wsplit_supported(L.a, pw)) {
                 if ((rc = ensure_sk(h, conv_wsplit_ws_floats(L.a, pw.leaves / pw.unit, groups), conv_wsplit_tiles(L.a, groups)))) return rc;
-                LAUNCHCHK(h, launch_conv_wsplit(L.a, pw, h->sk, ctx, partner ? &partner->a : nullptr), op.label.c_str());
-                return SPECMI_OK;
+                const int wrc = launch_conv_wsplit(L.a, pw, h->sk, ctx, partner ? &partner->a : nullptr);
+                if (wrc != SK_NEEDS_BATCH_SPLIT) {
+                    LAUNCHCHK(h, wrc, op.label.c_str());
+                    return SPECMI_OK;
+                }
             }
         }
         if ((rc = ensure_sk(h, conv_igemm_sk_ws_floats(L.a, pl.leaves / pl.unit, groups), conv_igemm_sk_tiles(L.a, groups)))) return rc;
         rc = launch_conv_igemm_sk(L.a, pl, h->sk, ctx, partner ? &partner->a : nullptr);
-        if (rc != (int)hipErrorInvalidValue) {
+        if (rc != SK_NEEDS_BATCH_SPLIT) {       // misalignment, a bad plan, an undersized workspace: errors, not a silent change of kernel
             LAUNCHCHK(h, rc, op.label.c_str());
             return SPECMI_OK;
         }
         // the sliced launcher does not split the batch (activations past 32-bit addressing, plan = 'latency' pinned at a large
         // batch or resolution): the throughput launcher below does - other bits (the plans differ anyway), never an error
-        (void)hipGetLastError();
     }
     int rc = L.family == 1 ? launch_conv_wino(L.a, ctx, partner ? &partner->a : nullptr)
                            : launch_conv_igemm(L.a, ctx, partner ? &partner->a : nullptr);
@@ -954,7 +956,7 @@ static int persist_run(specmi_handle* h, const std::vector<OpLaunch>& La, const 
     return SPECMI_OK;
 }
 
-// Launch ops [first, n) of a trunk (hb == nullptr) or of a trunk pair.  mode != 0 and option "persist" (default 1): maximal runs of
+// Launch ops [first, n) of a trunk (hb == nullptr) or of a trunk pair.  mode != 0 and option "persist" (default 0: opt-in): maximal runs of
 // implicit-GEMM convolutions go to the persistent walker (one launch per run of up to 64 layers), everything else - the stem,
 // the max-pool, Winograd layers, the optional split-bf16 path - is launched op by op as before.
 static int launch_ops(specmi_handle* ha, specmi_handle* hb, const TrunkPlan& Pa, const TrunkPlan* Pb, const float* img_a, const float* img_b,
@@ -1085,7 +1087,7 @@ static int run_head(specmi_handle* h, const float* feat, int B, int fh, int fw, 
     // three kernels at batch 1 and the whole step 0-1 % SLOWER at batch 1-10 (profiles/r05_f_tail_check.jsonl) - an in-launch hop
     // costs what a kernel boundary costs on this part.
     if (defer && pose_done && opt_i(h, "tail_fuse", 0) && use_latency_heads(h, B) && h->has_head_c && opt_i(h, "head_collapse", 1) &&
-        h->head_c.w_rm && fh * fw < 64 && (B + 1) / 2 + 2 <= specmi_handle::kTailCtlWords && h->tail_ctl && !h->prof.on) {
+        h->head_c.w_rm && fh * fw < 64 && (B + 1) / 2 + 3 <= specmi_handle::kTailCtlWords && h->tail_ctl && !h->prof.on) {
         const HeadInit hi{h->xc, h->init_pose, h->init_shape, h->init_cam, R, K, img_h, ucf, F, LD};
         defer->state = h->h1; defer->ld_state = 1024;
         defer->pred_pose = pred_pose; defer->pred_shape = pred_shape; defer->pred_cam = pred_cam; defer->pred_pose_6d = pred_pose_6d;
@@ -1461,7 +1463,7 @@ int specmi_camcalib_head_decode(specmi_handle* h, const float* feat, int B, int 
     // small batches (round 5, option "tail_fuse", opt-in): avg-pool -> the three heads -> decode as ONE launch (head.hip: tail_gemv_kernel)
     if (opt_i(h, "tail_fuse", 0) && use_latency_heads(h, B) && h->fc_layers == 1 && f0.w_rm && fh * fw < 64 && f0.Kp == h->feat_ch &&
         h->fc_cam[1][0].nout == f0.nout && h->fc_cam[2][0].nout == f0.nout && h->fc_cam[1][0].Kp == f0.Kp && h->fc_cam[2][0].Kp == f0.Kp &&
-        (B + 1) / 2 + 2 <= specmi_handle::kTailCtlWords && h->tail_ctl && !h->prof.on) {
+        (B + 1) / 2 + 3 <= specmi_handle::kTailCtlWords && h->tail_ctl && !h->prof.on) {
         float* outs[3] = {lv, lp, lr};
         FcGemv hd[3];
         for (int i = 0; i < 3; ++i) hd[i] = FcGemv{h->xf, h->fc_cam[i][0].w_rm, h->fc_cam[i][0].shift, nullptr, outs[i]};
@@ -1472,9 +1474,11 @@ int specmi_camcalib_head_decode(specmi_handle* h, const float* feat, int B, int 
         if (lrc != (int)hipErrorInvalidValue) LAUNCHCHK(h, lrc, "camcalib tail");
         (void)hipGetLastError();
     }
-    if ((rc = run_camcalib_head(h, feat, B, fh, fw, lv, lp, lr, s))) return rc;
+    if ((rc = run_camcalib_head(h, feat, B, fh, fw, lv, lp, lr, s))) { reset_sync_state(h, s); return rc; }
     LaunchCtx ctx{s, &h->prof, "camcalib.decode"};
-    LAUNCHCHK(h, launch_camcalib_decode(lv, lp, lr, B, f0.nout, img_h, img_w, vfov, pitch, roll, f_pix, R, K, ld_ang, ctx), "camcalib_decode");
+    // the bins are the LAST Linear of a head's chain (num_fc_layers > 1: the first one is num_fc_channels wide, camcalib/model.py:59-70)
+    const int nbins = h->fc_cam[0][h->fc_layers - 1].nout;
+    LAUNCHCHK(h, launch_camcalib_decode(lv, lp, lr, B, nbins, img_h, img_w, vfov, pitch, roll, f_pix, R, K, ld_ang, ctx), "camcalib_decode");
     return SPECMI_OK;
 }
 
@@ -1568,16 +1572,17 @@ int specmi_hmr_forward(specmi_handle* h, const float* images, int B, int H, int 
     if (!images || !out || B <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
     hipStream_t s = (hipStream_t)stream;
     const float* f; int fh, fw, rc;
-    if ((rc = run_trunk(h, images, B, H, W, nullptr, &f, &fh, &fw, s))) return rc;
+    if ((rc = run_trunk(h, images, B, H, W, nullptr, &f, &fh, &fw, s))) { reset_sync_state(h, s); return rc; }
     const OutLd old = out_ld(h);
     HeadFinal fin;
     const bool fuse = (opt_i(h, "head_fuse", 3) & 2) != 0;     // head_final's work inside the SMPL pose kernel (same bits, one node less)
     bool pose_done = false;
     if ((rc = run_head(h, f, B, fh, fw, R, K, img_h, out->pred_pose, out->pred_shape, out->pred_cam, out->pred_pose_6d, old, s,
-                       fuse ? &fin : nullptr, fuse ? &pose_done : nullptr)))
-        return rc;
-    return run_smpl(h, h->rot_ws, h->betas_ws, h->cam_ws, B, R, K, bbox_scale, bbox_center, img_w, img_h,
-                    out->smpl_vertices, out->smpl_joints3d, out->smpl_joints2d, out->pred_cam_t, old, s, fuse ? &fin : nullptr, pose_done);
+                       fuse ? &fin : nullptr, fuse ? &pose_done : nullptr)) ||
+        (rc = run_smpl(h, h->rot_ws, h->betas_ws, h->cam_ws, B, R, K, bbox_scale, bbox_center, img_w, img_h,
+                       out->smpl_vertices, out->smpl_joints3d, out->smpl_joints2d, out->pred_cam_t, old, s, fuse ? &fin : nullptr, pose_done)))
+        reset_sync_state(h, s);      // include/specmi.h: the hand-off counters are reset after any forward that returned an error
+    return rc;
 }
 
 int specmi_hmr_regress(specmi_handle* h, const float* feat, int B, int fh, int fw, const float* R, const float* K,
@@ -1594,10 +1599,11 @@ int specmi_hmr_regress(specmi_handle* h, const float* feat, int B, int fh, int f
     const bool fuse = (opt_i(h, "head_fuse", 3) & 2) != 0;     // head_final's work inside the SMPL pose kernel (same bits, one node less)
     bool pose_done = false;
     if ((rc = run_head(h, feat, B, fh, fw, R, K, img_h, out->pred_pose, out->pred_shape, out->pred_cam, out->pred_pose_6d, old, s,
-                       fuse ? &fin : nullptr, fuse ? &pose_done : nullptr)))
-        return rc;
-    return run_smpl(h, h->rot_ws, h->betas_ws, h->cam_ws, B, R, K, bbox_scale, bbox_center, img_w, img_h,
-                    out->smpl_vertices, out->smpl_joints3d, out->smpl_joints2d, out->pred_cam_t, old, s, fuse ? &fin : nullptr, pose_done);
+                       fuse ? &fin : nullptr, fuse ? &pose_done : nullptr)) ||
+        (rc = run_smpl(h, h->rot_ws, h->betas_ws, h->cam_ws, B, R, K, bbox_scale, bbox_center, img_w, img_h,
+                       out->smpl_vertices, out->smpl_joints3d, out->smpl_joints2d, out->pred_cam_t, old, s, fuse ? &fin : nullptr, pose_done)))
+        reset_sync_state(h, s);
+    return rc;
 }
 
 int specmi_conv2d(specmi_handle* h, const float* x, int B, int H, int W, int Cin, const float* w_host,
@@ -1826,6 +1832,14 @@ int specmi_sync_status(specmi_handle* h, int32_t* persist_err) {
             for (int i = 0; i < 2 * kPersistMaxLayers; ++i)
                 if (c.done[i]) *persist_err = -2;
         }
+    }
+    if (h->tail_ctl && !*persist_err) {   // the fused tails (option "tail_fuse"): error word last, every counter zero between launches
+        unsigned v[specmi_handle::kTailCtlWords];
+        HIPCHK(h, hipMemcpy(v, h->tail_ctl, sizeof(v), hipMemcpyDeviceToHost));
+        if (v[specmi_handle::kTailCtlWords - 1]) *persist_err = 3;
+        else
+            for (int i = 0; i < specmi_handle::kTailCtlWords - 1; ++i)
+                if (v[i]) *persist_err = -3;
     }
     return SPECMI_OK;
 }

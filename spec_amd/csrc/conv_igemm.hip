@@ -311,7 +311,7 @@ int conv_igemm_sk_check(const ConvArgs& a, const SkPlan& pl, const ConvArgs* b) 
     size_t img_bytes = (size_t)a.H * a.W * a.ldx * 4;
     if (a.x2 && (size_t)a.H2 * a.W2 * a.ldx2 * 4 > img_bytes) img_bytes = (size_t)a.H2 * a.W2 * a.ldx2 * 4;
     const size_t limit = (size_t)1 << 31;
-    if (img_bytes * a.B >= limit || (size_t)nch * 32 * a.Npad * 4 >= limit) return (int)hipErrorInvalidValue;   // small-M path: no batch splitting
+    if (img_bytes * a.B >= limit || (size_t)nch * 32 * a.Npad * 4 >= limit) return SK_NEEDS_BATCH_SPLIT;   // small-M path: no batch splitting
     return 0;
 }
 

@@ -341,6 +341,7 @@ size_t conv_wsplit_ws_floats(const ConvArgs& a, int S, int groups) { return S > 
 bool conv_wsplit_supported(const ConvArgs& a, const SkPlan& pl) {
     const int nch = a.KH * a.KW * (a.Cin / 32) + (a.x2 ? a.Cin2 / 32 : 0);
     return pl.leaves >= 2 && pl.G >= 2 && pl.G <= 4 && pl.leaves % pl.G == 0 && (pl.unit == pl.leaves || pl.unit == pl.G) && !a.force_variant &&
+           a.KH * a.KW <= 32 &&                            // (the padding mask of a pixel holds one bit per filter tap)
            nch % pl.leaves == 0 && nch / pl.leaves >= 2;   // (the K loop keeps two chunks in flight)
 }
 

@@ -289,6 +289,7 @@ struct TailArgs {
     const float* map; float* pool_out; int HW, C4, pool_ld, pool_total, npool, ninit;
     HeadInit init;
     unsigned* ctl;        // [0] phase-A arrivals, [1] slabs finished, [2 + z] arrivals of slab z; all zero between launches
+    unsigned* err;        // set to 1 when the bounded wait for phase A gave up (results of that launch are garbage): specmi_sync_status
     unsigned spin_limit;
     DecodeArgs dec;
     PoseTail pose;
@@ -353,7 +354,10 @@ __global__ void __launch_bounds__(256) tail_gemv_kernel(const TailArgs a) {
                 unsigned spins = 0;
                 while (__hip_atomic_load(a.ctl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(a.npool + a.ninit)) {
                     __builtin_amdgcn_s_sleep(2);
-                    if (++spins > a.spin_limit) break;
+                    if (++spins > a.spin_limit) {
+                        __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
                 }
             }
             __syncthreads();
@@ -441,7 +445,7 @@ int launch_tail_gemv(const FcGemv* heads, int nheads, int N, int Kp, int ldx, in
         return (int)hipErrorInvalidValue;
     const int NBv = B == 1 ? 1 : 2;
     const int nz = (B + NBv - 1) / NBv;
-    if (ctl_words < 2 + nz) return (int)hipErrorInvalidValue;
+    if (ctl_words < 3 + nz) return (int)hipErrorInvalidValue;      // (the last word is the error word)
     TailArgs a;
     a.g.nheads = nheads; a.g.N = N; a.g.Kp = Kp; a.g.ldx = ldx; a.g.ldo = ldo; a.g.B = B;
     for (int i = 0; i < 3; ++i) {
@@ -455,6 +459,7 @@ int launch_tail_gemv(const FcGemv* heads, int nheads, int N, int Kp, int ldx, in
     a.ninit = init ? B : 0;
     a.init = init ? *init : HeadInit{};
     a.ctl = ctl;
+    a.err = ctl + ctl_words - 1;
     a.spin_limit = 2000000u;
     a.dec = dec ? *dec : DecodeArgs{};
     a.pose = pose ? *pose : PoseTail{};

@@ -120,6 +120,9 @@ int conv_igemm_sk_slices(const ConvArgs& a, int target_wgs, int min_chunks);
 SkPlan conv_igemm_sk_plan(const ConvArgs& a, int groups, int target_wgs, int min_chunks, int fill_wgs);
 size_t conv_igemm_sk_ws_floats(const ConvArgs& a, int slabs, int groups);
 int conv_igemm_sk_tiles(const ConvArgs& a, int groups);
+// conv_igemm_sk_check / the sliced launchers: the tensors pass 32-bit buffer addressing and these launchers do not split the batch -
+// the ONE condition on which the caller may take the throughput launcher instead (every other non-zero result is an error)
+constexpr int SK_NEEDS_BATCH_SPLIT = -1001;
 int launch_conv_igemm_sk(const ConvArgs& a, const SkPlan& pl, const SkWs& sk, const LaunchCtx& ctx, const ConvArgs* b = nullptr);
 // the wave-split unit of the same tree (conv_wsplit.hip): a 32x32 tile per workgroup, the leaves of a group on its four waves;
 // pl.unit = pl.leaves (no slabs) or pl.G (one group per workgroup, a 4 KB slab per group)

@@ -315,7 +315,8 @@ class _EngineModule(nn.Module):
     # Execution plan of the trunk (include/specmi.h, option "plan"): 'throughput' = the kernels the batch-256 headline runs
     # (Winograd + 64x64 / 128x128 implicit GEMM); 'latency' = every convolution cut into K slices that fill the chip at batch
     # 1-8 (one canonical summation tree per layer); 'single' (round 5) = the latency plan with every 3x3 convolution on the sliced
-    # direct kernel (no Winograd): what batch 1-2 wants, and the whole trunk behind the max-pool is then ONE persistent launch;
+    # direct kernel (no Winograd): what batch 1-2 wants (with the opt-in option "persist" the trunk behind the max-pool is then ONE
+    # persistent launch - measured slower than the per-layer launches, default off);
     # 'auto' (default) = single up to 2 images per call, latency up to 10 (16 for a single trunk), throughput beyond.  Within a plan an
     # image's result is bit-identical whatever the batch size; between plans the last bits differ (contract: 1e-4).
     PLANS = {'auto': 0, 'throughput': 1, 'latency': 2, 'single': 3}

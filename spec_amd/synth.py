@@ -337,6 +337,17 @@ def _random_rot6d(seed, name, n):
     return out.reshape(-1).astype(np.float32)
 
 
+def _orthonormal_rot6d(seed, name, n):
+    """rot6d of n uniformly random ROTATIONS (Gram-Schmidt of two normal vectors; sqrt / divide only): what a trained regressor's
+    mean pose looks like to ``rot6d_to_rotmat`` - unit, orthogonal columns, far from the identity."""
+    a = normal(seed, name + '.a', (n, 3)).astype(np.float64)
+    b = normal(seed, name + '.b', (n, 3)).astype(np.float64)
+    b1 = a / np.sqrt((a * a).sum(-1, keepdims=True))
+    u2 = b - (b1 * b).sum(-1, keepdims=True) * b1
+    b2 = u2 / np.sqrt((u2 * u2).sum(-1, keepdims=True))
+    return np.stack([b1, b2], axis=-1).reshape(-1).astype(np.float32)
+
+
 def hmr_state(seed: int = 1002, use_cam_feats: bool = True, dec_gain: float = 1.0, backbone: str = 'resnet50',
               stats: str = 'benign', cam_gain: float = None):
     """HMR parameters: trunk + HMRHead (fc1, fc2, decpose, decshape, deccam, init_*).  ``backbone``: 'resnet50' or
@@ -366,7 +377,7 @@ def hmr_state(seed: int = 1002, use_cam_feats: bool = True, dec_gain: float = 1.
         gain = cam_gain if (name == 'deccam' and cam_gain is not None) else dec_gain
         xav = gain * 0.25 * math.sqrt(6.0 / (1024 + nout))
         linear(name, nout, 1024, bound=xav, bias_bound=0.01)
-    sd['head.init_pose'] = _random_rot6d(seed, 'head.init_pose', 24).reshape(1, 144)
+    sd['head.init_pose'] = (_orthonormal_rot6d if stats == 'pretrained_like' else _random_rot6d)(seed, 'head.init_pose', 24).reshape(1, 144)
     sd['head.init_shape'] = normal(seed, 'head.init_shape', (1, 10), std=0.5)
     sd['head.init_cam'] = np.array([[0.9, 0.0, 0.0]], dtype=np.float32) \
         + normal(seed, 'head.init_cam', (1, 3), std=0.02)

@@ -51,7 +51,7 @@ torch.set_grad_enabled(False)
 torch.manual_seed(0)
 
 SEED_CAMCALIB, SEED_HMR, SEED_SMPL, SEED_IMG = 1001, 1002, 1003, 20210001
-PL_SEED_CC, PL_SEED_HM, PL_SEED_IMG, PL_DEC_GAIN, PL_CAM_GAIN = 2101, 2102, 2103, 4.0, 1.0     # = tests/util.py
+PL_SEED_CC, PL_SEED_HM, PL_SEED_IMG, PL_DEC_GAIN, PL_CAM_GAIN = 2101, 2102, 2103, 2.0, 1.0     # = tests/util.py
 
 
 def t(a):

@@ -246,8 +246,10 @@ def test_camcalib_variable_resolution(models):
 
 
 def test_full_batch_256_properties(models):
-    """BASELINE.json config 3 size (B=256): results for an image do not depend on its batch
-    (bit-exact: the k-order of every dot product is fixed), and all outputs are finite."""
+    """BASELINE.json config 3 at its stated size (B=256): eight images of the batch against the CPU oracle DIRECTLY (element-wise
+    bound), results for an image do not depend on its batch (bit-exact: the k-order of every dot product is fixed), and all
+    outputs are finite."""
+    from oracle.models import full_pipeline
     from spec_amd.pipeline import SpecPipeline
     cc, hm = models
     pipe = SpecPipeline(cc, hm)
@@ -256,6 +258,13 @@ def test_full_batch_256_properties(models):
     sc, ce, iw, ih = [t(a).to(DEV) for a in synth.bbox_inputs(77, B)]
     big = pipe(x, sc, ce, iw, ih)
     idx = torch.tensor([0, 5, 63, 64, 127, 200, 254, 255], device=DEV)
+    occ, ohm = oracle_models(True, True)
+    ref = full_pipeline(occ, ohm, *[a[idx].cpu() for a in (x, sc, ce, iw, ih)])
+    for k in ('smpl_vertices', 'smpl_joints3d', 'smpl_joints2d'):
+        excess, worst = _elementwise_ok(big[k][idx], ref[k].numpy(), k)
+        assert excess <= 0, (k, excess, worst)
+    for k in ('pred_cam_t', 'pred_pose', 'pred_shape', 'pred_cam', 'cam_vfov', 'cam_pitch', 'cam_roll'):
+        assert rel_err(big[k][idx].cpu().numpy(), ref[k].numpy()) < TOL, k
     with pinned_plan('throughput', cc, hm):   # bit-identity across batch sizes holds within a plan
         small = pipe(x[idx], sc[idx], ce[idx], iw[idx], ih[idx])
     for k in ('smpl_vertices', 'smpl_joints3d', 'smpl_joints2d', 'pred_cam_t', 'pred_pose_6d', 'cam_vfov'):
@@ -270,6 +279,27 @@ def test_full_batch_256_properties(models):
     P = P / P[..., 2:3]
     p2 = torch.einsum('bij,bkj->bki', big['cam_intrinsics'].double(), P)[..., :2]
     assert ((p2 - big['smpl_joints2d'].double()).abs().max() / big['smpl_joints2d'].abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize('B', [16, 17, 64])
+def test_mid_batches_vs_oracle_auto_plan(models, B):
+    """The batches where 'auto' switches plan and trunk structure (16 / 17) and the reference's evaluation batch (64,
+    spec/config.py:85), whole path against the CPU oracle under the plan 'auto' picks: element-wise bound on mesh, joints and
+    projection, 1e-4 on the rest."""
+    from oracle.models import full_pipeline
+    from spec_amd.pipeline import SpecPipeline
+    cc, hm = models
+    assert cc.plan == 'auto' and hm.plan == 'auto'
+    occ, ohm = oracle_models(True, True)
+    x = t(synth.images(300 + B, B))
+    sc, ce, iw, ih = [t(a) for a in synth.bbox_inputs(300 + B, B, 640., 480.)]
+    ref = full_pipeline(occ, ohm, x, sc, ce, iw, ih)
+    out = SpecPipeline(cc, hm)(x.to(DEV), sc.to(DEV), ce.to(DEV), iw.to(DEV), ih.to(DEV))
+    for k in ('smpl_vertices', 'smpl_joints3d', 'smpl_joints2d'):
+        excess, worst = _elementwise_ok(out[k], ref[k].numpy(), k)
+        assert excess <= 0, (B, k, excess, worst)
+    for k in ('pred_cam_t', 'pred_pose', 'pred_shape', 'pred_cam', 'cam_vfov', 'cam_pitch', 'cam_roll'):
+        assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < TOL, (B, k)
 
 
 def test_batch_700_crosses_the_2gib_slices(models):

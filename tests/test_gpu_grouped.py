@@ -48,18 +48,18 @@ def test_grouped_pipeline_equals_two_stream_pipeline(B):
             out = SpecPipeline(cc, hm, grouped=True)(x, sc, ce, iw, ih)
             for k in ref:
                 assert torch.equal(out[k], ref[k]), (plan, k)
-    cc.set_plan('throughput'); hm.set_plan('throughput')
-    ref = SpecPipeline(cc, hm, overlap=True, grouped=False)(x, sc, ce, iw, ih)
-    grp = SpecPipeline(cc, hm, grouped=True)
-    gp = GraphedPipeline(grp, x, sc, ce, iw, ih)                  # one stream: captures without a side-stream fork
-    out2 = gp(x, sc, ce, iw, ih)
-    for k in ('smpl_vertices', 'smpl_joints2d', 'cam_vfov', 'record'):
-        assert torch.equal(out2[k], ref[k]), k
-    # different input shapes for the two networks: falls back to the two-stream path
-    big = torch.nn.functional.interpolate(x, size=(256, 320))
-    out3 = grp(x, sc, ce, iw, ih, camcalib_images=big)
-    ref3 = SpecPipeline(cc, hm, overlap=True)(x, sc, ce, iw, ih, camcalib_images=big)
-    assert torch.equal(out3['smpl_vertices'], ref3['smpl_vertices'])
+    with pinned_plan('throughput', cc, hm):      # (restored on exit: nothing stays pinned behind this test)
+        ref = SpecPipeline(cc, hm, overlap=True, grouped=False)(x, sc, ce, iw, ih)
+        grp = SpecPipeline(cc, hm, grouped=True)
+        gp = GraphedPipeline(grp, x, sc, ce, iw, ih)                  # one stream: captures without a side-stream fork
+        out2 = gp(x, sc, ce, iw, ih)
+        for k in ('smpl_vertices', 'smpl_joints2d', 'cam_vfov', 'record'):
+            assert torch.equal(out2[k], ref[k]), k
+        # different input shapes for the two networks: falls back to the two-stream path
+        big = torch.nn.functional.interpolate(x, size=(256, 320))
+        out3 = grp(x, sc, ce, iw, ih, camcalib_images=big)
+        ref3 = SpecPipeline(cc, hm, overlap=True)(x, sc, ce, iw, ih, camcalib_images=big)
+        assert torch.equal(out3['smpl_vertices'], ref3['smpl_vertices'])
 
 
 def test_trunk_pair_resnet34_and_errors():

@@ -18,11 +18,15 @@ pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 DEV = 'cuda:0'
 TOL = 1e-4            # BASELINE.json: within 1e-4 relative fp32 of the reference CPU path
-CHANNEL_FACTOR = 2.0  # GPU-vs-float64 error of a channel <= 2 x the CPU fp32 oracle's error on that channel ...
-CHANNEL_FLOOR = 4.0   # ... or <= 4 fp32 ulps of the channel's largest value (channels the CPU happens to get exactly right)
-# "the CPU fp32 oracle's error on a channel" is the larger of TWO runs of the same oracle that differ only in summation order
-# (NCHW on all cores / channels_last on one thread): a channel's max error over 98 positions is one draw of a random variable,
-# and the second CPU run already exceeds 2 x the first on ~17 of the 2048 channels (max 3.2 x; profiles/r06_*_parity_report.txt)
+# Channel by channel, "the CPU fp32 oracle's error" e_cpu is the larger of TWO runs of the same oracle that differ only in summation
+# order (NCHW on all cores / channels_last on one thread).  A channel's max error over 98 positions is ONE draw of a heavy-tailed
+# random variable: the second CPU run alone exceeds 2 x the first on 13-17 of the 2048 channels (median ratio 1.03, p99 1.95,
+# max 3.0-3.2; header of profiles/r06_*_parity_report.txt), so "<= 2 x e_cpu on every channel" is a bar the reference's own
+# arithmetic does not clear against itself.  What is asserted instead, per plan and structure:
+CHANNEL_MEDIAN = 1.25  # median over channels of e_gpu / e_cpu: no systematic loss of accuracy (measured 0.83-1.07)
+CHANNEL_P99 = 2.5      # 99th percentile (measured 1.6-2.1; CPU against CPU 1.95)
+CHANNEL_HARD = 8.0     # EVERY channel: e_gpu <= 8 x e_cpu (measured max 3.8; a mis-folded scale or a dropped term is 10^2-10^4) ...
+CHANNEL_FLOOR = 4.0    # ... or <= 4 fp32 ulps of the channel's largest value (channels the CPU happens to get exactly right)
 PLANS = ['single', 'latency', 'throughput']
 STRUCTURES = [(1, 1), (0, 1), (1, 0), (0, 0)]     # (winograd, fuse_downsample)
 
@@ -55,11 +59,14 @@ def channel_report(feat, f32s, f64):
     e_gpu = per_channel_errors(feat, f64)
     e_cpu = np.max([per_channel_errors(f, f64) for f in f32s], axis=0)
     cmax = np.abs(f64).reshape(-1, f64.shape[-1]).max(axis=0)
-    bound = np.maximum(CHANNEL_FACTOR * e_cpu, CHANNEL_FLOOR * np.spacing(cmax.astype(np.float32)).astype(np.float64))
+    bound = np.maximum(CHANNEL_HARD * e_cpu, CHANNEL_FLOOR * np.spacing(cmax.astype(np.float32)).astype(np.float64))
     ratio = e_gpu / np.maximum(bound, 1e-300)
     ratio[(e_gpu == 0)] = 0.0
+    ok = e_cpu > 0
+    q = e_gpu[ok] / e_cpu[ok]
     return {'e_gpu': e_gpu, 'e_cpu': e_cpu, 'cmax': cmax, 'bound': bound, 'worst': float(ratio.max()), 'n_over': int((ratio > 1).sum()),
-            'argworst': int(ratio.argmax())}
+            'argworst': int(ratio.argmax()), 'median': float(np.median(q)), 'p99': float(np.quantile(q, 0.99)), 'max': float(q.max()),
+            'n_over2': int((q > 2).sum())}
 
 
 def gpu_trunk(hm, x, plan, wino, fuse):
@@ -95,6 +102,7 @@ def test_trunk_per_channel_vs_float64(pl, plan, wino, fuse):
     rep = channel_report(feat, (pl['f32'], pl['f32b']), pl['f64'])
     c = rep['argworst']
     assert rep['n_over'] == 0, (plan, wino, fuse, rep['n_over'], rep['worst'], c, rep['e_gpu'][c], rep['e_cpu'][c], rep['cmax'][c])
+    assert rep['median'] <= CHANNEL_MEDIAN and rep['p99'] <= CHANNEL_P99, (plan, wino, fuse, rep['median'], rep['p99'], rep['max'])
     # and the tensor-wise reading against the CPU oracle
     assert rel_err(feat, pl['f32']) < TOL
 
@@ -130,8 +138,10 @@ def test_whole_path_vs_oracle(pl, B):
 
 @pytest.mark.parametrize('plan', PLANS)
 def test_mesh_vs_float64(pl, plan):
-    """HMR.forward on the two crops of the trunk test: the GPU mesh and joints are no further from the float64 oracle than twice
-    the CPU fp32 oracle's distance (tensor max-norm; regressor head + SMPL in float64 from the float64 trunk map)."""
+    """HMR.forward on the two crops of the trunk test against a float64 regressor head + SMPL run from the float64 trunk map.
+    The head's outputs are linear in the features, so the RMS error over the 288 + 20 regressed numbers is a stable statistic:
+    the GPU's is at most 1.5 x the CPU fp32 oracle's.  Mesh, joints and rotations (one ill-conditioned joint decides their
+    max-norm: a single draw) stay within 4 x the CPU's max-norm distance, and within 1e-4 of the CPU oracle itself."""
     from oracle.models import cam_params
     hm, ohm, ohm64, x = pl['hm'], pl['ohm'], pl['ohm64'], pl['x']
     B = x.shape[0]
@@ -143,10 +153,15 @@ def test_mesh_vs_float64(pl, plan):
     v64, j64 = ohm64.smpl.smpl(h64['pred_shape'], h64['pred_pose'])
     with pinned_plan(plan, hm):
         out = hm(x.to(DEV), R.to(DEV), K.to(DEV), sc.to(DEV), ce.to(DEV), iw.to(DEV), ih.to(DEV))
-    for k, r64 in (('smpl_vertices', v64), ('smpl_joints3d', j64), ('pred_pose', h64['pred_pose']), ('pred_shape', h64['pred_shape'])):
+    rms = lambda a, b: float((a.double() - b).pow(2).mean().sqrt())
+    for k in ('pred_pose_6d', 'pred_shape'):
+        e_gpu, e_cpu = rms(out[k].cpu(), h64[k]), rms(ref32[k], h64[k])
+        assert e_gpu <= 1.5 * e_cpu, (plan, k, e_gpu, e_cpu)
+    for k, r64 in (('smpl_vertices', v64), ('smpl_joints3d', j64), ('pred_pose', h64['pred_pose'])):
         e_gpu = float((out[k].cpu().double() - r64).abs().max())
         e_cpu = float((ref32[k].double() - r64).abs().max())
-        assert e_gpu <= 2.0 * e_cpu, (plan, k, e_gpu, e_cpu)
+        assert e_gpu <= 4.0 * e_cpu, (plan, k, e_gpu, e_cpu)
+        assert rel_err(out[k].cpu().numpy(), ref32[k].numpy()) < TOL, (plan, k)
 
 
 @pytest.mark.parametrize('plan', PLANS)

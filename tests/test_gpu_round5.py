@@ -316,3 +316,31 @@ def test_camcalib_head_decode_equals_the_two_calls(models):
                     assert torch.equal(cam2['cam_rotmat'], ref['cam_rotmat']) and float(rec[:, [0, 2, 4, 6]].abs().max()) == 0.0
                 finally:
                     e.set_option('tail_fuse', 0)
+
+
+@pytest.mark.parametrize('num_fc_layers,B', [(2, 1), (2, 5), (3, 2), (2, 40)])
+def test_head_decode_with_linear_chains_equals_head_then_decode(num_fc_layers, B):
+    """specmi_camcalib_head_decode on a CamCalib model whose heads are Linear CHAINS (num_fc_layers > 1, camcalib/model.py:59-70):
+    the decode reads the LAST layer's width (the bins), not the first layer's (num_fc_channels) - ADVICE r05.  Bit-identical to
+    head_forward followed by decode, and equal to the oracle's decode of the same logits."""
+    from oracle.models import decode_angles
+    from spec_amd.modules import CameraRegressorNetwork
+    sd = synth.camcalib_state(1500 + num_fc_layers, num_fc_layers=num_fc_layers, num_fc_channels=1024)
+    m = CameraRegressorNetwork(num_fc_layers=num_fc_layers, num_fc_channels=1024)
+    m.load_state_dict({k: t(v) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).eval()
+    eng = m.engine(torch.device(DEV))
+    feat = eng.trunk(t(synth.images(600 + B, B)).to(DEV))
+    ih = torch.full((B,), 480., device=DEV)
+    iw = torch.full((B,), 640., device=DEV)
+    lg_a = [l.clone() for l in eng.camcalib_head(feat)]
+    dec_a = eng.camcalib_decode(*lg_a, img_h=ih, img_w=iw)
+    lg_b, dec_b = eng.camcalib_head_decode(feat, img_h=ih, img_w=iw)
+    assert lg_b[0].shape == (B, 256)
+    for a, b in zip(lg_a, lg_b):
+        assert torch.equal(a, b)
+    for k in ('vfov', 'pitch', 'roll', 'f_pix', 'cam_rotmat', 'cam_intrinsics'):
+        assert torch.equal(dec_a[k], dec_b[k]), k
+    ref = decode_angles(*[l.cpu() for l in lg_a])
+    for a, k in zip(ref, ('vfov', 'pitch', 'roll')):
+        assert np.abs(dec_b[k].cpu().numpy() - a.numpy()).max() < 2e-6, k

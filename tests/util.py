@@ -82,7 +82,8 @@ def pinned_plan(plan, *modules):
 
 # ---- released-checkpoint-like statistics (spec_amd.synth, stats='pretrained_like') -------------------
 PL_SEED_CC, PL_SEED_HM, PL_SEED_IMG = 2101, 2102, 2103
-PL_DEC_GAIN, PL_CAM_GAIN = 4.0, 1.0       # Xavier gain 1 on decpose / decshape; deccam keeps the weak-perspective scale off 0
+PL_DEC_GAIN, PL_CAM_GAIN = 2.0, 1.0       # Xavier gain 0.5 on decpose / decshape around an orthonormal, far-from-identity init_pose (pose6d moves
+                                          # by ~0.7 rms per element between images; rot6d_to_rotmat stays conditioned below ~8); deccam at 0.25
 
 
 def pretrained_like_states():
