@@ -11,7 +11,13 @@ when fewer than N devices are visible - it never falls back to fewer GPUs silent
 A step = one pass of the whole hot path over one synthetic batch that is already resident in
 HBM: CamCalib trunk + 3 FC heads -> soft-argmax decode -> (R, K) -> SPEC trunk -> regressor
 -> SMPL LBS (6890 vertices) -> 49 joints -> perspective projection (+ for N > 1 the
-all-gather of the packed per-image records, which the kernels write in place).  Rank 0 prints ONE JSON line.
+all-gather of the packed per-image records, which the kernels write in place).  Rank 0 prints ONE JSON line on stdout and,
+as the LAST line of stderr, the compact ``[bench] summary {...}`` (headline + small-batch / C2 / demo scalars).
+
+``--backend gloo --fake-forward`` is the hardware-free dry run of the N > 1 control flow (tests/test_bench_dryrun.py): the same
+main() - self-launch, process group, 16-image probe incl. its ragged pad path, two alternating record buffers + AsyncGather,
+per-rank timing gather, the ``comm`` block, the CPU baseline on rank 0 - with the GPU forward replaced by a per-image stand-in on
+CPU tensors.  Its numbers mean nothing; its JSON line carries ``"dry_run": true``.
 """
 from __future__ import annotations
 
@@ -86,10 +92,10 @@ def log(*a):
 # ------------------------------------------------------------------------------------------------
 # multi-GPU self-launch
 # ------------------------------------------------------------------------------------------------
-def self_launch(n: int) -> int:
+def self_launch(n: int, need_gpus: bool = True) -> int:
     """Re-exec this script as n ranks under torch.distributed.run (one process per GPU, RCCL)."""
     have = torch.cuda.device_count()
-    if have < n:
+    if need_gpus and have < n:
         log(f'[bench] ERROR: --gpus {n} requested but only {have} GPU(s) are visible; refusing to run on fewer '
             f'devices (use --gpus {max(have, 1)})')
         return 2
@@ -412,6 +418,58 @@ def cpu_baseline_whole_host(physical, threads_per_proc=16, seconds=10.0, startup
 
 
 # ------------------------------------------------------------------------------------------------
+# --fake-forward: stand-ins that keep the N > 1 control flow runnable without a GPU (dry run; never measured)
+# ------------------------------------------------------------------------------------------------
+class FakeModule:
+    """set_plan / plan of the drop-in modules, nothing else."""
+    plan = 'auto'
+    _engine = None
+
+    def set_plan(self, plan):
+        self.plan = plan
+        return self
+
+
+class FakePipeline:
+    """SpecPipeline's call contract on any device: one (B, 21294)-float packed record per step whose row b depends on image b
+    only (so rank-sharded == unsharded, bit for bit, as the real kernels guarantee within a plan)."""
+    RECORD = 21294
+
+    def __call__(self, images, bbox_scale, bbox_center, img_w, img_h, record=None):
+        B = images.shape[0]
+        key = images.reshape(B, -1)[:, :97].double().sum(dim=1).float() + bbox_scale + img_w * 1e-3
+        cols = torch.arange(self.RECORD, dtype=torch.float32, device=images.device) * 1e-3
+        rec = key[:, None] + cols[None, :]
+        if record is not None:
+            record.copy_(rec)
+            rec = record
+        from spec_amd.pipeline import unpack_outputs
+        out = unpack_outputs(rec, 6890)          # the per-key views of the packed record, as SpecPipeline(packed=True) returns them
+        out['record'] = rec
+        return out
+
+
+class FakeGraphed:
+    """GraphedPipeline's contract: static inputs, ``buffers`` alternating static records marked ``specmi_static_buffers``."""
+
+    def __init__(self, pipeline, images, bbox_scale, bbox_center, img_w, img_h, buffers=1):
+        self.pipeline = pipeline
+        self.static_in = [t.clone() for t in (images, bbox_scale, bbox_center, img_w, img_h)]
+        self.records = [torch.empty(images.shape[0], FakePipeline.RECORD, device=images.device) for _ in range(max(1, buffers))]
+        for r in self.records:
+            r.specmi_static_buffers = max(1, buffers)
+        self.turn = 0
+
+    def __call__(self, images, bbox_scale, bbox_center, img_w, img_h):
+        for dst, src in zip(self.static_in, (images, bbox_scale, bbox_center, img_w, img_h)):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+        i = self.turn
+        self.turn = (i + 1) % len(self.records)
+        return self.pipeline(*self.static_in, record=self.records[i])
+
+
+# ------------------------------------------------------------------------------------------------
 def main():
     if len(sys.argv) >= 6 and sys.argv[1] == '--cpu-worker':
         _cpu_worker(int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), float(sys.argv[5]))
@@ -437,6 +495,10 @@ def main():
                                                         'group, asynchronous all-gather, two record buffers) even with --gpus 1')
     ap.add_argument('--gather', choices=('full', 'joints'), default='full',
                     help='N > 1 all-gather payload: the full 85,176-byte record per image, or the 2,496 bytes without vertices')
+    ap.add_argument('--backend', choices=('nccl', 'gloo'), default='nccl', help="process-group backend; 'gloo' only with --fake-forward")
+    ap.add_argument('--fake-forward', action='store_true', help='dry run of the N > 1 control flow on CPU tensors (no GPU, no kernels, '
+                                                                 'numbers meaningless): see the module docstring')
+    ap.add_argument('--cpu-baseline-seconds', type=float, default=22.0, help='budget of the CPU oracle timing on rank 0')
     ap.add_argument('--subbatch', type=int, default=-1, help='trunk sub-batch for the early stages (0 = off, -1 = library default)')
     ap.add_argument('--subbatch-layers', type=int, default=-1)
     args = ap.parse_args()
@@ -444,23 +506,51 @@ def main():
     if args.gpus < 1:
         log('[bench] ERROR: --gpus must be >= 1')
         sys.exit(2)
+    fake = args.fake_forward
+    if (args.backend == 'gloo') != fake:
+        log('[bench] ERROR: --backend gloo and --fake-forward go together (the dry run of the N > 1 control flow); the measured path is nccl = RCCL')
+        sys.exit(2)
+    if fake:     # nothing below the distributed control flow exists without a GPU
+        args.no_profile = args.no_c2 = args.no_small_batch = args.no_e2e = args.no_split_bf16 = True
     if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or args.dist):
-        sys.exit(self_launch(args.gpus))
+        sys.exit(self_launch(args.gpus, need_gpus=not fake))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         log(f'[bench] ERROR: launched with WORLD_SIZE={world} but --gpus {args.gpus}; they must agree')
         sys.exit(2)
-    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+    if not fake and (not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank):
         log(f'[bench] ERROR: rank {rank} needs GPU {local_rank}, {torch.cuda.device_count()} visible (no CPU path)')
         sys.exit(2)
     n_gpus = world
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    if fake:
+        device = torch.device('cpu')
+        torch.set_num_threads(2)
+    else:
+        torch.cuda.set_device(local_rank)
+        device = torch.device('cuda', local_rank)
+    sync = (lambda: None) if fake else torch.cuda.synchronize
+
+    def timed_ms(fn, n):
+        """Average time of n calls of fn in ms: HIP events on the current stream (wall clock in the dry run)."""
+        if fake:
+            t0_ = time.perf_counter()
+            for _ in range(n):
+                fn()
+            return (time.perf_counter() - t0_) / n * 1e3
+        e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0_.record()
+        for _ in range(n):
+            fn()
+        e1_.record()
+        torch.cuda.synchronize()
+        return e0_.elapsed_time(e1_) / n
+
     dist = None
     use_dist = world > 1 or args.dist
     if use_dist:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if 'MASTER_PORT' not in os.environ:     # (torch.distributed.run always sets it; a bare single-rank --dist run picks a free one)
@@ -470,20 +560,26 @@ def main():
             with socket.socket() as s_:
                 s_.bind(('127.0.0.1', 0))
                 os.environ['MASTER_PORT'] = str(s_.getsockname()[1])
-        dist.init_process_group('nccl', device_id=device, rank=rank, world_size=world)
+        # (the other ranks wait at the final barrier while rank 0 runs its single-GPU extras and the CPU baseline: minutes)
+        kw = {} if fake else {'device_id': device}
+        dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30), **kw)
 
     from spec_amd.pipeline import SpecPipeline, AsyncGather, gather_outputs
     torch.set_grad_enabled(False)
-    cc, hm, cs, hs = build_models(device)
-    pipe = SpecPipeline(cc, hm, overlap=not args.no_overlap)
-    seq_pipe = SpecPipeline(cc, hm, overlap=False)    # per-kernel profiling pass runs serially
-    for m in (cc, hm):
-        if args.subbatch >= 0:
-            m._engine.set_option('trunk_subbatch', args.subbatch)
-        if args.subbatch_layers >= 0:
-            m._engine.set_option('trunk_subbatch_layers', args.subbatch_layers)
-        if args.force_variant:
-            m._engine.set_option('force_conv_variant', args.force_variant)
+    if fake:
+        cc, hm, cs, hs = FakeModule(), FakeModule(), None, None
+        pipe = seq_pipe = FakePipeline()
+    else:
+        cc, hm, cs, hs = build_models(device)
+        pipe = SpecPipeline(cc, hm, overlap=not args.no_overlap)
+        seq_pipe = SpecPipeline(cc, hm, overlap=False)    # per-kernel profiling pass runs serially
+        for m in (cc, hm):
+            if args.subbatch >= 0:
+                m._engine.set_option('trunk_subbatch', args.subbatch)
+            if args.subbatch_layers >= 0:
+                m._engine.set_option('trunk_subbatch_layers', args.subbatch_layers)
+            if args.force_variant:
+                m._engine.set_option('force_conv_variant', args.force_variant)
     B = args.batch
     x, scale, center, img_w, img_h = make_inputs(B, device, 20210001 + rank)
     if use_dist:
@@ -505,7 +601,7 @@ def main():
         # (+1 % at B=256).  Same kernels, same work; falls back to eager launches if capture is unavailable.
         try:
             from spec_amd.pipeline import GraphedPipeline
-            run = GraphedPipeline(pipe, x, scale, center, img_w, img_h, buffers=2 if use_dist else 1)
+            run = (FakeGraphed if fake else GraphedPipeline)(pipe, x, scale, center, img_w, img_h, buffers=2 if use_dist else 1)
             launch_mode = 'hipGraph replay'
         except Exception as e:
             log('[bench] hipGraph capture failed, launching eagerly:', repr(e))
@@ -521,19 +617,19 @@ def main():
         return out
 
     def timed(nsteps, collect=True):
-        torch.cuda.synchronize()
+        sync()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         for _ in range(nsteps):
             step(collect)
         if gather is not None:
             gather.drain()
-        torch.cuda.synchronize()
+        sync()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         return time.perf_counter() - t0
 
     # N > 1 start-up probe (outside the timed region): a common 16-image batch, each rank runs its shard_range slice, one
@@ -598,17 +694,11 @@ def main():
     comm = None
     if use_dist:
         out = pipe(x, scale, center, img_w, img_h)
-        torch.cuda.synchronize()
+        sync()
         dist.barrier()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        gather_outputs(out)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(5):
-            full = gather_outputs(out)
-        e1.record()
-        torch.cuda.synchronize()
-        ag_ms = e0.elapsed_time(e1) / 5
+        full = gather_outputs(out)
+        sync()
+        ag_ms = timed_ms(lambda: gather_outputs(out), 5)
         # the same K steps with no collective at all: what the asynchronous gather costs on top of the compute
         el_nc = timed(args.steps, collect=False)
         tt = torch.tensor([el_nc], device=device, dtype=torch.float64)
@@ -1027,9 +1117,14 @@ def main():
             log('[bench] split-bf16 line failed:', repr(e))
 
     cpu = None
-    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:      # (N > 1 too: north_star wants it "in the same run"; the other ranks wait at the final barrier)
         try:
-            cpu = cpu_baseline(cs, hs)
+            if cs is None:
+                from spec_amd import synth
+                cs, hs = synth.camcalib_state(1001), synth.hmr_state(1002, True)
+            cpu = cpu_baseline(cs, hs, budget_s=args.cpu_baseline_seconds)
+            if n_gpus > 1:
+                cpu['ranks_waiting_at_the_barrier_meanwhile'] = n_gpus - 1
         except Exception as e:  # the baseline must never sink the bench line
             log('[bench] cpu baseline failed:', repr(e))
         if cpu is not None:
@@ -1039,7 +1134,7 @@ def main():
                 usable = cpu['host']['physical_cores'] if quota is None else min(cpu['host']['physical_cores'], int(quota))
                 cpu['host']['usable_cores'] = usable
                 whole = None
-                if usable >= 32:          # more than one 16-thread process fits: cover the host with pinned processes
+                if usable >= 32 and not fake:   # more than one 16-thread process fits: cover the host with pinned processes
                     whole = cpu_baseline_whole_host(usable)
                 else:
                     cpu['whole_host'] = (f'the container may use {usable} CPUs at once (cgroup cpu.max; {cpu["host"]["physical_cores"]} '
@@ -1094,7 +1189,17 @@ def main():
         except Exception as e:
             log('[bench] summary incomplete:', repr(e))
         line['summary'] = summary
+        if fake:
+            line['dry_run'] = True
+            line['data'] = 'none: --fake-forward dry run of the N > 1 control flow on CPU tensors (gloo); not a measurement'
         print(json.dumps(line), flush=True)
+        # the compact scalars once more as the LAST line of stderr (the driver keeps the tail of the streams, and drops the extra
+        # keys of the stdout line): <= 1.5 KB
+        if comm:
+            summary.update({'comm_world_size': comm.get('world_size'), 'comm_probe_equal_unsharded': comm.get('probe_gathered_16_images_equal_unsharded'),
+                            'comm_overlap_efficiency': comm.get('overlap_efficiency'), 'comm_all_gather_ms': comm.get('all_gather_ms_blocking_full_record')})
+        sys.stdout.flush()
+        log('[bench] summary ' + json.dumps(summary)[:1500])
     if use_dist:
         dist.barrier()          # rank 0 may still be in its profiling pass
         dist.destroy_process_group()
