@@ -573,6 +573,8 @@ def main():
         cc, hm, cs, hs = build_models(device)
         pipe = SpecPipeline(cc, hm, overlap=not args.no_overlap)
         seq_pipe = SpecPipeline(cc, hm, overlap=False)    # per-kernel profiling pass runs serially
+        if args.subbatch >= 0 or args.subbatch_layers >= 0 or args.force_variant:
+            os.environ['SPECMI_EXPERIMENTAL'] = '1'       # debug flags: names of the experimental list (include/specmi.h)
         for m in (cc, hm):
             if args.subbatch >= 0:
                 m._engine.set_option('trunk_subbatch', args.subbatch)
@@ -715,6 +717,9 @@ def main():
                 'receive_buffers': 'persistent x2', 'send': 'in place (record written by the kernels)' if args.gather == 'full' else '624-float slice copy',
                 'per_rank_images_per_s': per_rank}
 
+    # everything up to here - the timed headline, the sustained region, the collective - ran on the STABLE option surface; the
+    # informational extras below flip opt-in paths and the secondary arithmetic mode
+    os.environ['SPECMI_EXPERIMENTAL'] = '1'
     roof, stages, c2 = None, None, None
     if rank == 0 and not args.no_profile:
         for m in (cc, hm):

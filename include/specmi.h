@@ -96,69 +96,75 @@ const char* specmi_version(void);
 /* ---- parameters (replaces load_state_dict / load_pretrained_model,
  *      spec/tester.py:63-71, scripts/camcalib_demo.py:80-81) ---------------------------- */
 
-/* Integer options before commit.  CamCalib (camcalib/model.py:25-70): "backbone" (50 default | 18 | 34 | 101 | 152: the torchvision ResNet family the
- * reference's eval(backbone) resolves, spec/models/hmr.py:53, camcalib/model.py:33; HMR also 32 / 48 = HRNet-W32 / W48),
- * "num_fc_layers" (1..3), "num_fc_channels" (<= 1024, multiple of 32).  HMR: "use_cam" (SMPLCamHead vs SMPLHead, hmr.py:66-74),
- * "use_cam_feats" (hmr.py:55,94-98), "img_res" (hmr.py:69).  Float option: "focal_length".
- * Any time: "winograd" (default 1: 3x3 / stride-1 convolutions with Cin % 16 == 0 and Cout % 64 == 0
- * run as fused Winograd F(2x2,3x3) on the fp32 matrix cores; 0: always the direct implicit GEMM);
- * "fuse_downsample" (default 1: a bottleneck's downsample conv + BN is folded into its conv3 as one 1x1
- * GEMM over [conv2 output | block input]; 0: separate launch + residual add, as torchvision writes it);
- * "fc_splitk" (default 1: FC GEMMs with <= 1024 rows run as parallel K slices + a fixed-order reduction);
- * "head_collapse" (default 1; HMR, read at commit and at forward: the three IEF iterations of HMRHead - an affine map in
- * eval mode, no activation between fc1 / fc2 / dec* and dropout = identity - run as ONE (features + camera features) -> 157
- * GEMM whose matrix is composed in float64 at commit; 0: the nine GEMMs of the reference loop);
- * "output_ld" (HMR, default 0 = dense outputs; n > 0: every per-image output pointer of specmi_hmr_forward /
- * specmi_hmr_head_forward / specmi_smpl_forward addresses image 0 and image b lives at pointer + b*n floats, i.e. the outputs
- * are columns of ONE caller-owned (B, n) record - the packed all-gather record of SURVEY.md 8e - written by the kernels
- * directly); "angle_ld" (the same for vfov / pitch / roll of specmi_camcalib_decode);
- * "force_conv_variant" / "force_wino_variant" (tests and tuning: pin the tile variant of this handle's launches, 0 = auto);
- * "plan" (any time, read at every forward; round 4): the execution plan of the ResNet trunk -
+/* ---- options -------------------------------------------------------------------------------------------------------------
+ * specmi_set_option_i32 / _f32 accept the names below and refuse anything else (SPECMI_ERR_ARG).  The option table of the library
+ * (specmi_option_info) is the single list; tests/test_abi.py holds this comment and the code to it.
+ *
+ * STABLE (frozen in round 6: what a reference maintainer binds)
+ *   Model shape, before specmi_commit.  CamCalib (camcalib/model.py:25-70): "backbone" (50 default | 18 | 34 | 101 | 152: the
+ *   torchvision ResNet family the reference's eval(backbone) resolves, spec/models/hmr.py:53, camcalib/model.py:33; HMR also 32 / 48 =
+ *   HRNet-W32 / W48, with "hrnet_use_conv" 1 = the '-conv' variant, hmr.py:44-51), "num_fc_layers" (1..3), "num_fc_channels"
+ *   (<= 1024, multiple of 32).  HMR: "use_cam" (SMPLCamHead vs SMPLHead, hmr.py:66-74), "use_cam_feats" (hmr.py:55,94-98),
+ *   "img_res" (224; hmr.py:69).  Float option: "focal_length" (5000; hmr.py:31).
+ *   Execution, any time (read at every forward):
+ *   "plan" - the execution plan of the ResNet trunk:
  *     1 = throughput: the kernels the batch-256 benchmark runs (Winograd F(2x2,3x3) + 64x64 / 128x128 implicit GEMM);
  *     2 = latency: for the reference's own operating point - spec/tester.py:109-151 runs the path at batch = #detections of one
  *         frame, scripts/camcalib_demo.py:95-102 at batch 1 - every convolution with K >= 512 is cut into K slices that run as ONE
  *         launch (the last slice of a tile to arrive folds the partial tiles and applies BN / residual / ReLU), layer3 / layer4
  *         3x3 convolutions leave Winograd for the sliced direct kernel;
- *     3 = single (round 5): the latency plan with EVERY 3x3 convolution on the sliced direct kernels (no Winograd) - what batch
- *         1-2 wants (scripts/camcalib_demo.py:95-102 never runs anything else): layer1 / layer2 conv2 measured 21 / 12 us faster
- *         there at batch 1 / 2, slower from batch 4;
- *     0 = auto (default): single while the call carries no more pixels than "single_max_batch" (default 2) images of 224 x 224,
- *         latency up to N images - N = "latency_max_batch" (default 10) for specmi_trunk_forward_pair and the FC heads,
- *         "latency_max_batch_single" (default 16) for a single trunk (measured crossovers; one CamCalib frame at 600 x 1066 counts
- *         as 12.7 images) - throughput beyond.  specmi_trunk_plan reports the choice for a shape.
- *   WITHIN a plan an image's result is bit-identical whatever the batch size, the grouping (specmi_trunk_forward_pair) or the
- *   replay (every k sum has one association fixed by the layer's shape: the latency plan's is a canonical tree - leaves of L chunks,
- *   groups of G leaves - of which a workgroup computes a leaf, a group or the whole by batch size; 8 x 256 rank shards == 2048
- *   unsharded).  BETWEEN plans the last bits differ (other association of the same products, other algorithm on layer3 / layer4
- *   conv2); all meet the 1e-4 contract on every reference fixture (tests/test_gpu_e2e.py).  Callers that need bit-reproducibility
- *   across batch sizes on both sides of a switch pin a plan - the library's own batch-splitting callers do (spec_amd.tester runs a
- *   whole folder under ONE plan whatever --frame_batch; bench.py pins 'throughput' for rank-sharded runs).
- *   Round 5, same bits as before (speed choices inside the latency / single plans):
- *     "wsplit" (default 1): sliced layers whose 64x64 launch would need slabs run on the wave-split unit of the SAME canonical tree
- *       (spec_amd/csrc/conv_wsplit.hip: a 32x32 tile per workgroup, a group's leaves on its four waves, 4 KB group slabs or none) while
- *       the launch has at most "wsplit_max_units" (1400, trunk pair) / "wsplit_max_units_single" (500) leaf-units; 0 = never; 2 / 3 =
- *       always with one group / all groups per workgroup (tests).  "conv2d_wsplit" (specmi_conv2d only: 0 | 2 | 3).
- *     "persist" (default 0, opt-in): every run of implicit-GEMM layers of the latency / single plan as ONE persistent launch
- *       (spec_amd/csrc/conv_persist.hip: resident workgroups walk the layers, completion counters instead of kernel boundaries,
- *       write-through hand-offs).  Bit-identical to the per-layer launches and measured SLOWER on MI355X (0.68 vs 0.55 ms for the trunk
- *       pair at batch 1, profiles/r05_a_persist_ab.jsonl) - kept for the record and for other parts; at most two such forwards may be
- *       in flight per device (the grid must be co-resident).  "persist_wgs" (512 pair / 256 single), "persist_l2_prefetch",
- *       "persist_spin_limit", "persist_min_run"; specmi_sync_status reports a spin that gave up.
- *   Tuning / tests: "latency_target_wgs" (256), "latency_min_chunks" (4), "latency_wino_min_tiles" (128), "latency_fill_wgs" (240; beyond ten
- *   224 x 224 crops' worth of pixels "latency_fill_wgs_large", 400), "latency_unit_model" (0; 1 = pick the unit by a round model with
- *   "latency_unit_slots" 256 instead of the threshold: measured equal or worse, kept for tuning),
- *   "latency_force_unit" (0 = by batch, 1 / 2 / 3 = a leaf / a group / the whole K per workgroup: same bits),
- *   "conv2d_sk" (specmi_conv2d only: 0 = throughput kernel, -1 = the latency plan's rule, n > 1 = n leaves),
- *   "smpl_skin_split" (-1 = by batch: three waves per 32-vertex group up to 64 images, one beyond; 0 / 1 = never / always: same bits),
- *   "head_fuse" (default 3; bit 0: the regressor's state init rides in the pooling launch, bit 1: head_final's work is done by the
- *   SMPL pose kernel of specmi_hmr_forward / specmi_hmr_regress - two graph nodes less per step, same bits);
- *   "tail_fuse" (default 0, round 5, opt-in): at small batches each network's tail as ONE launch - HMR: avg-pool + state init ->
- *   composed regressor map -> pose chains; CamCalib (specmi_camcalib_head_decode): avg-pool -> three heads -> decode - instead of
- *   three: the first workgroups pool, every workgroup waits on one counter, the last arriver per image pair runs the epilogue (same
- *   code, same bits; spec_amd/csrc/head.hip).  Four graph nodes less per step and NOT faster on MI355X (15.2 vs 16.3 us per tail, the
- *   whole step 0-1 % slower: profiles/r05_f_tail_check.jsonl) - an in-launch hand-off costs what a kernel boundary costs. */
+ *     3 = single: the latency plan with EVERY 3x3 convolution on the sliced direct kernels (no Winograd) - what batch 1-2 wants;
+ *     0 = auto (default): single up to 2 images of 224 x 224 per call, latency up to 10 (trunk pair, FC heads) / 16 (single trunk;
+ *         one CamCalib frame at 600 x 1066 counts as 12.7 images), throughput beyond.  specmi_trunk_plan reports the choice.
+ *     WITHIN a plan an image's result is bit-identical whatever the batch size, the grouping (specmi_trunk_forward_pair) or the
+ *     replay (every k sum has one association fixed by the layer's shape; 8 x 256 rank shards == 2048 unsharded).  BETWEEN plans the
+ *     last bits differ (other association of the same products, other algorithm on layer3 / layer4 conv2); all meet the 1e-4
+ *     contract on every reference fixture (tests/test_gpu_e2e.py, tests/test_gpu_pretrained_like.py).  Callers that need
+ *     bit-reproducibility across batch sizes on both sides of a switch pin a plan (spec_amd.tester runs a whole folder under ONE plan
+ *     whatever --frame_batch; bench.py pins 'throughput' for rank-sharded runs).
+ *   "winograd" (default 1: 3x3 / stride-1 convolutions with Cin % 16 == 0 and Cout % 64 == 0 run as fused Winograd F(2x2,3x3) on the
+ *     fp32 matrix cores under the throughput / latency plans; 0: always the direct implicit GEMM);
+ *   "fuse_downsample" (default 1: a bottleneck's downsample conv + BN is folded into its conv3 as one 1x1 GEMM over
+ *     [conv2 output | block input]; 0: separate launch + residual add, as torchvision writes it);
+ *   "head_collapse" (default 1; HMR, read at commit and at forward: the three IEF iterations of HMRHead - an affine map in eval mode,
+ *     no activation between fc1 / fc2 / dec* and dropout = identity - run as ONE (features + camera features) -> 157 GEMM whose
+ *     matrix is composed in float64 at commit; 0: the nine GEMMs of the reference loop);
+ *   "output_ld" (HMR, default 0 = dense outputs; n > 0: every per-image output pointer of specmi_hmr_forward /
+ *     specmi_hmr_head_forward / specmi_smpl_forward addresses image 0 and image b lives at pointer + b*n floats, i.e. the outputs are
+ *     columns of ONE caller-owned (B, n) record - the packed all-gather record of SURVEY.md 8e - written by the kernels directly);
+ *   "angle_ld" (the same for vfov / pitch / roll of specmi_camcalib_decode / specmi_camcalib_head_decode);
+ *   "experimental" (default 0; 1 = this handle accepts the names of the next list).
+ *
+ * EXPERIMENTAL (refused with SPECMI_ERR_STATE unless the environment has SPECMI_EXPERIMENTAL=1 or the handle's "experimental" is 1;
+ * setting one to its default is a no-op and always accepted).  Tuning thresholds from single-box sweeps, debug pins, opt-ins that
+ * measured slower or neutral on MI355X, and the narrower-arithmetic secondary mode: scaffolding of the experiments recorded in
+ * docs/ROUNDS.md and profiles/, same bits as the defaults unless stated, no compatibility promise.
+ *   secondary arithmetic: "conv_precision" (0; 3 / 6 = the 1x1 (6: and strided 3x3) convolutions as that many bf16 piece products on
+ *     the bf16 matrix cores: NOT the reference's fp32 arithmetic per product, tests/test_gpu_bf16split.py), "conv_precision_3x3" (0);
+ *   debug pins: "force_conv_variant" / "force_wino_variant" (0 = auto), "latency_force_unit" (0 = by batch, 1 / 2 / 3 = a leaf / a
+ *     group / the whole K per workgroup), "conv2d_sk" (specmi_conv2d only: 0 = throughput kernel, -1 = the latency plan's rule,
+ *     n > 1 = n leaves), "conv2d_wsplit" (specmi_conv2d only: 0 | 2 | 3), "smpl_skin_split" (-1 = by batch, 0 / 1 = never / always),
+ *     "trunk_subbatch" (0) / "trunk_subbatch_layers" (2), "fc_splitk" (1), "fc_gemv" (1), "head_fuse" (3; bit 0: the regressor's state
+ *     init rides in the pooling launch, bit 1: head_final's work is done by the SMPL pose kernel);
+ *   plan thresholds: "single_max_batch" (2), "latency_max_batch" (10), "latency_max_batch_single" (16), "latency_target_wgs" (256),
+ *     "latency_min_chunks" (4), "latency_wino_min_tiles" (128), "latency_fill_wgs" (240) / "latency_fill_wgs_large" (400),
+ *     "latency_unit_model" (0; 1 = pick the unit by a round model with "latency_unit_slots" 256: measured equal or worse);
+ *   wave-split unit of the latency / single plans (spec_amd/csrc/conv_wsplit.hip): "wsplit" (1; 0 = never, 2 / 3 = always with one
+ *     group / all groups per workgroup), "wsplit_max_units" (1400, trunk pair), "wsplit_max_units_single" (500), "wsplit_slots" (256);
+ *   "persist" (0, opt-in): every run of implicit-GEMM layers of the latency / single plan as ONE persistent launch
+ *     (spec_amd/csrc/conv_persist.hip).  Bit-identical to the per-layer launches and measured SLOWER on MI355X (0.68 vs 0.55 ms,
+ *     profiles/r05_a_persist_ab.jsonl); at most two such forwards may be in flight per device.  "persist_wgs" (0 = 512 pair / 256
+ *     single), "persist_fill_wgs" (0 = the latency fill), "persist_l2_prefetch" (0), "persist_spin_limit" (400000), "persist_min_run"
+ *     (2), "persist_allow_full" (0); specmi_sync_status reports a spin that gave up;
+ *   "tail_fuse" (0, opt-in): at small batches each network's tail as ONE launch (spec_amd/csrc/head.hip) - same bits, four graph
+ *     nodes less per step and NOT faster on MI355X (profiles/r05_f_tail_check.jsonl). */
 int specmi_set_option_i32(specmi_handle* h, const char* name, int value);
 int specmi_set_option_f32(specmi_handle* h, const char* name, float value);
+/* The effective value of an integer option on this handle: what was set, else the default of the table. */
+int specmi_get_option_i32(specmi_handle* h, const char* name, int* value);
+/* Entry `index` (0 .. n-1; SPECMI_ERR_ARG past the end) of the option table: name, default and whether it is on the STABLE list.
+ * Needs no handle and no GPU. */
+int specmi_option_info(int index, const char** name, int* default_value, int* is_stable);
 
 /* Host tensors under state_dict key names, e.g. "backbone.layer1.0.conv1.weight" (OIHW),
  * "backbone.bn1.running_var", "fc_vfov.weight" (out,in), "head.fc1.weight",

@@ -1,4 +1,6 @@
 """Whole-step time (hipGraph replay, auto structure) vs option latency_fill_wgs at batch 4-16."""
+import os
+os.environ.setdefault('SPECMI_EXPERIMENTAL', '1')   # this script sets options of the experimental list (include/specmi.h)
 import json, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

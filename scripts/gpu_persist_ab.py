@@ -2,6 +2,7 @@
 Each variant runs in its own process (SPECMI_LIB selects the library).  Output: gpurun_out/persist_ab.jsonl"""
 import json
 import os
+os.environ.setdefault('SPECMI_EXPERIMENTAL', '1')   # this script sets options of the experimental list (include/specmi.h)
 import subprocess
 import sys
 

@@ -10,6 +10,7 @@ Writes JSON lines to gpurun_out/persist_check.jsonl.   python scripts/gpu_persis
 import argparse
 import json
 import os
+os.environ.setdefault('SPECMI_EXPERIMENTAL', '1')   # this script sets options of the experimental list (include/specmi.h)
 import sys
 import time
 

@@ -1,5 +1,7 @@
 """Whole-step time (hipGraph replay) per batch: launch structure (grouped / two streams) x wave-split rule on / off x max-units
 threshold.  Output: gpurun_out/structure_sweep.jsonl"""
+import os
+os.environ.setdefault('SPECMI_EXPERIMENTAL', '1')   # this script sets options of the experimental list (include/specmi.h)
 import json, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,4 +1,6 @@
 """Fused tails (head.hip: tail_gemv_kernel): bit-equality vs the separate kernels and whole-step time, batch 1..10."""
+import os
+os.environ.setdefault('SPECMI_EXPERIMENTAL', '1')   # this script sets options of the experimental list (include/specmi.h)
 import json, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

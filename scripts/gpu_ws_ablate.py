@@ -1,6 +1,8 @@
 """Timing ablation of the wave-split kernel at a mid batch (WRONG results by design): variants that make every tile read the same
 A rows / B columns (spec_amd/lib/variants/libspecmi_ws{A,B,AB}.so, scripts/build_variants.sh) - is the unit operand-bandwidth bound
 when 3 workgroups share a CU?  Per-layer HIP-event times, trunk pair, wsplit forced (all groups per workgroup)."""
+import os
+os.environ.setdefault('SPECMI_EXPERIMENTAL', '1')   # this script sets options of the experimental list (include/specmi.h)
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 W = r'''

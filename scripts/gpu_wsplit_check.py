@@ -8,6 +8,7 @@ Output: gpurun_out/wsplit_check.jsonl, gpurun_out/wsplit_layers.txt"""
 import argparse
 import json
 import os
+os.environ.setdefault('SPECMI_EXPERIMENTAL', '1')   # this script sets options of the experimental list (include/specmi.h)
 import sys
 
 import numpy as np

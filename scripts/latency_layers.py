@@ -2,6 +2,8 @@
 """Per-layer time (library HIP-event profiler, grouped launches of both trunks, eager) of every alternative the latency plan
 can choose from, per batch size: throughput kernels, and the sliced kernel with a leaf / a group / the whole K per workgroup,
 Winograd kept or not.  Prints one table per batch: rows = layers, columns = alternatives."""
+import os
+os.environ.setdefault('SPECMI_EXPERIMENTAL', '1')   # this script sets options of the experimental list (include/specmi.h)
 import argparse, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Small-batch step time (hipGraph replay, grouped launches) over the latency plan's knobs: slices per layer
 (latency_target_wgs, latency_min_chunks), where Winograd stays (latency_wino_min_tiles), and the throughput plan beside it."""
+import os
+os.environ.setdefault('SPECMI_EXPERIMENTAL', '1')   # this script sets options of the experimental list (include/specmi.h)
 import argparse, itertools, json, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """One small-batch step under hipGraph replay, N times - the command to run under `rocprofv3 --kernel-trace` for the
 per-kernel timeline of the latency plan (scripts/rocprof_summary.py timeline)."""
+import os
+os.environ.setdefault('SPECMI_EXPERIMENTAL', '1')   # this script sets options of the experimental list (include/specmi.h)
 import argparse, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """GPU box: time the SMPL stage (pose chain + skinning + joints / projection) per batch size with the skinning variant forced
 (option "smpl_skin_split": 0 = one wave per 32-vertex group, 1 = three) - the measurement behind SKIN_SPLIT_MAX_TILES."""
+import os
+os.environ.setdefault('SPECMI_EXPERIMENTAL', '1')   # this script sets options of the experimental list (include/specmi.h)
 import os, sys, json
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -62,6 +62,8 @@ PROTOTYPES = {
     'specmi_version': (C.c_char_p, []),
     'specmi_set_option_i32': (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     'specmi_set_option_f32': (C.c_int, [C.c_void_p, C.c_char_p, C.c_float]),
+    'specmi_get_option_i32': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
+    'specmi_option_info': (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'specmi_set_tensor_f32': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_int64_p, C.c_int]),
     'specmi_set_tensor_i32': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_int64_p, C.c_int]),
     'specmi_commit': (C.c_int, [C.c_void_p]),

@@ -64,6 +64,17 @@ class Engine:
         else:
             _lib.check(self.h, self.lib.specmi_set_option_i32(self.h, name.encode(), int(value)))
 
+    def get_option(self, name: str) -> int:
+        """The effective value of an integer option on this handle (what was set, else the library's default)."""
+        v = C.c_int(0)
+        _lib.check(self.h, self.lib.specmi_get_option_i32(self.h, name.encode(), C.byref(v)))
+        return int(v.value)
+
+    def experimental(self, on: bool = True):
+        """Let this handle accept the experimental option names (include/specmi.h): tuning thresholds, debug pins, opt-ins."""
+        self.set_option('experimental', int(bool(on)))
+        return self
+
     PLAN_NAMES = ('throughput', 'latency', 'single')
 
     def trunk_plan(self, B: int, H: int = 224, W: int = 224, pair: bool = False) -> str:

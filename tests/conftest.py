@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The tests pin tile variants, flip opt-in paths and sweep tuning thresholds: names on the EXPERIMENTAL list of include/specmi.h, which
+# the library refuses unless asked (tests/test_gpu_options.py checks the refusal with this variable removed).
+os.environ.setdefault('SPECMI_EXPERIMENTAL', '1')
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
