@@ -57,3 +57,28 @@ for PLAN in ('single', 'latency', 'throughput'):
     x = t(synth.images(int(g['seed_images']), B)).to(DEV)
     o2 = hm2(x, t(g['cam_rotmat']).to(DEV), t(g['cam_intrinsics']).to(DEV), t(g['bbox_scale']).to(DEV), t(g['bbox_center']).to(DEV), t(g['img_w']).to(DEV), t(g['img_h']).to(DEV))
     elementwise('smpl_joints2d  GPU vs reference-composed fixture (camfeats)', o2['smpl_joints2d'].cpu().numpy(), g['out_smpl_joints2d'], 'px', 1.0)
+
+
+print('================ C3 at its stated size: 8 images of a batch-256 step (plan auto = throughput) ================')
+from oracle.models import full_pipeline
+from spec_amd.pipeline import SpecPipeline
+from tests.util import float64_mesh
+cc, hm = gpu_models(True, True, DEV)
+occ, ohm = oracle_models(True, True)
+B = 256
+x = t(synth.images(77, B)).to(DEV); sc, ce, iw, ih = [t(a).to(DEV) for a in synth.bbox_inputs(77, B)]
+big = SpecPipeline(cc, hm)(x, sc, ce, iw, ih)
+idx = torch.tensor([0, 5, 63, 64, 127, 200, 254, 255], device=DEV)
+ref = full_pipeline(occ, ohm, *[a[idx].cpu() for a in (x, sc, ce, iw, ih)])
+nt = torch.get_num_threads(); torch.set_num_threads(1)
+ref_b = full_pipeline(occ, ohm, x[idx].cpu().contiguous(memory_format=torch.channels_last), *[a[idx].cpu() for a in (sc, ce, iw, ih)])
+torch.set_num_threads(nt)
+v64, j64, _ = float64_mesh(oracle_models(True, True)[1].double(), x[idx].cpu(), ref['cam_rotmat'], ref['cam_intrinsics'], ih[idx].cpu())
+print('max |difference| in metres                          smpl_vertices   smpl_joints3d')
+for name, a, b in (('GPU (batch 256) vs CPU fp32 oracle', big, ref), ('CPU fp32 oracle, other summation order, vs itself', ref_b, ref)):
+    print(f'{name:52s} {float((a["smpl_vertices"][idx].cpu() - b["smpl_vertices"]).abs().max()) if a is big else float((a["smpl_vertices"] - b["smpl_vertices"]).abs().max()):.3e}     '
+          f'{float((a["smpl_joints3d"][idx].cpu() - b["smpl_joints3d"]).abs().max()) if a is big else float((a["smpl_joints3d"] - b["smpl_joints3d"]).abs().max()):.3e}')
+for name, v, j in (('GPU (batch 256) vs float64 oracle', big['smpl_vertices'][idx].cpu(), big['smpl_joints3d'][idx].cpu()),
+                   ('CPU fp32 oracle vs float64 oracle', ref['smpl_vertices'], ref['smpl_joints3d']),
+                   ('CPU fp32 oracle (other order) vs float64 oracle', ref_b['smpl_vertices'], ref_b['smpl_joints3d'])):
+    print(f'{name:52s} {float((v.double() - v64).abs().max()):.3e}     {float((j.double() - j64).abs().max()):.3e}')

@@ -126,13 +126,17 @@ def test_hmr_vs_reference_fixture(tag, use_cam, ucf, plan):
         assert hasattr(out[k], 'cpu')      # spec/tester.py:153-154 contract
 
 
-def _elementwise_ok(out, ref, key):
+def _elementwise_ok(out, ref, key, floor_scale=1.0):
     """The element-wise reading of BASELINE.json's "1e-4 relative fp32": |err| <= 1e-5 |ref| + floor per element, with an
     absolute floor of 2e-6 m for vertices / joints3d (one fp32 ulp of a 2 m body is 2.4e-7 m; the trunk's rounding noise reaches
-    the mesh through the regressor) and 1e-4 px (or normalised units) for joints2d.  DESIGN.md section 2 states both readings."""
+    the mesh through the regressor) and 1e-4 px (or normalised units) for joints2d.  DESIGN.md section 2 states both readings.
+    ``floor_scale`` = 2 where MANY fresh images meet the CPU oracle directly (batch 16-256): the CPU fp32 oracle run in another
+    summation order differs from itself by 1.4e-6 m on the eight probe images of the batch-256 test (70 % of the floor), the GPU by
+    2.8e-6 m, while both sit at the same distance from a float64 oracle (profiles/r06_*_parity_report.txt, last section) - the floor
+    is the sum of two fp32 paths' noise, not a kernel property; 4e-6 m = 0.004 mm, 25 x below the 0.1 mm W-MPJPE criterion."""
     a = out.detach().cpu().numpy().astype(np.float64)
     b = np.asarray(ref, dtype=np.float64)
-    floor = 1e-4 if key == 'smpl_joints2d' else 2e-6
+    floor = (1e-4 if key == 'smpl_joints2d' else 2e-6) * floor_scale
     excess = np.abs(a - b) - (1e-5 * np.abs(b) + floor)
     return float(excess.max()), float(np.abs(a - b).max())
 
@@ -261,10 +265,19 @@ def test_full_batch_256_properties(models):
     occ, ohm = oracle_models(True, True)
     ref = full_pipeline(occ, ohm, *[a[idx].cpu() for a in (x, sc, ce, iw, ih)])
     for k in ('smpl_vertices', 'smpl_joints3d', 'smpl_joints2d'):
-        excess, worst = _elementwise_ok(big[k][idx], ref[k].numpy(), k)
+        excess, worst = _elementwise_ok(big[k][idx], ref[k].numpy(), k, floor_scale=2.0)
         assert excess <= 0, (k, excess, worst)
     for k in ('pred_cam_t', 'pred_pose', 'pred_shape', 'pred_cam', 'cam_vfov', 'cam_pitch', 'cam_roll'):
         assert rel_err(big[k][idx].cpu().numpy(), ref[k].numpy()) < TOL, k
+    # the arbiter: a float64 oracle (trunk, regressor, SMPL) on the same eight images - the GPU mesh is no further from it than
+    # twice the CPU fp32 oracle's distance (tensor max-norm over 8 x 6890 x 3 coordinates + 8 x 49 x 3 joints)
+    from tests.util import float64_mesh
+    ohm64 = oracle_models(True, True)[1].double()
+    v64, j64, _ = float64_mesh(ohm64, x[idx].cpu(), ref['cam_rotmat'], ref['cam_intrinsics'], ih[idx].cpu())
+    for k, r64 in (('smpl_vertices', v64), ('smpl_joints3d', j64)):
+        e_gpu = float((big[k][idx].cpu().double() - r64).abs().max())
+        e_cpu = float((ref[k].double() - r64).abs().max())
+        assert e_gpu <= 2.0 * e_cpu + 1e-6, (k, e_gpu, e_cpu)
     with pinned_plan('throughput', cc, hm):   # bit-identity across batch sizes holds within a plan
         small = pipe(x[idx], sc[idx], ce[idx], iw[idx], ih[idx])
     for k in ('smpl_vertices', 'smpl_joints3d', 'smpl_joints2d', 'pred_cam_t', 'pred_pose_6d', 'cam_vfov'):
@@ -296,7 +309,7 @@ def test_mid_batches_vs_oracle_auto_plan(models, B):
     ref = full_pipeline(occ, ohm, x, sc, ce, iw, ih)
     out = SpecPipeline(cc, hm)(x.to(DEV), sc.to(DEV), ce.to(DEV), iw.to(DEV), ih.to(DEV))
     for k in ('smpl_vertices', 'smpl_joints3d', 'smpl_joints2d'):
-        excess, worst = _elementwise_ok(out[k], ref[k].numpy(), k)
+        excess, worst = _elementwise_ok(out[k], ref[k].numpy(), k, floor_scale=2.0)
         assert excess <= 0, (B, k, excess, worst)
     for k in ('pred_cam_t', 'pred_pose', 'pred_shape', 'pred_cam', 'cam_vfov', 'cam_pitch', 'cam_roll'):
         assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < TOL, (B, k)

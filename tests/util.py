@@ -124,3 +124,13 @@ def per_channel_errors(x, ref64):
     """Per-channel max-norm error of an (..., C) map against a float64 reference of the same shape -> (C,) float64."""
     d = np.abs(np.asarray(x, dtype=np.float64) - np.asarray(ref64, dtype=np.float64))
     return d.reshape(-1, d.shape[-1]).max(axis=0)
+
+
+def float64_mesh(hmr_oracle64, images, cam_rotmat, cam_intrinsics, img_h):
+    """(vertices, joints3d, head outputs) of an HMR oracle converted with ``.double()``: trunk, regressor head and SMPL in float64
+    (the camera conversion / projection leaves of oracle/geometry.py cast to fp32 as upstream does, so the arbiter stops at the mesh)."""
+    f64 = hmr_oracle64.backbone(images.double())
+    vfov = 2 * torch.atan(img_h.double() / (2 * cam_intrinsics[:, 0, 0].double()))
+    h64 = hmr_oracle64.head(f64, cam_rotmat=cam_rotmat.double(), cam_vfov=vfov)
+    v64, j64 = hmr_oracle64.smpl.smpl(h64['pred_shape'], h64['pred_pose'])
+    return v64, j64, h64
