@@ -374,9 +374,8 @@ static void build_resnet(specmi_handle* h, int depth) {
 // (include/specmi.h).  Experimental names - tuning thresholds, debug pins, measured-slower opt-ins, the narrower-arithmetic
 // secondary mode - are refused unless the process sets SPECMI_EXPERIMENTAL=1 or the handle's (stable) option "experimental" is 1;
 // setting one to its default is always a no-op and allowed.  tests/test_abi.py checks the defaults here against the opt_i(...) call
-// sites and against the header.  kCtx: the default depends on the call (documented per option).
+// sites and against the header.  (0 = "by context" for persist_wgs / persist_fill_wgs.)
 namespace {
-constexpr int kCtx = INT_MIN;
 struct OptSpec { const char* name; int def; bool stable; };
 const OptSpec kOptions[] = {
     // stable: model shape (before commit)
@@ -395,7 +394,7 @@ const OptSpec kOptions[] = {
     {"latency_unit_slots", 256, false}, {"latency_force_unit", 0, false},
     {"wsplit", 1, false}, {"wsplit_max_units", 1400, false}, {"wsplit_max_units_single", 500, false}, {"wsplit_slots", 256, false},
     {"conv2d_sk", 0, false}, {"conv2d_wsplit", 0, false},
-    {"persist", 0, false}, {"persist_min_run", 2, false}, {"persist_wgs", kCtx, false}, {"persist_fill_wgs", kCtx, false},
+    {"persist", 0, false}, {"persist_min_run", 2, false}, {"persist_wgs", 0, false}, {"persist_fill_wgs", 0, false},
     {"persist_l2_prefetch", 0, false}, {"persist_spin_limit", 400000, false}, {"persist_allow_full", 0, false},
     {"tail_fuse", 0, false},
 };
@@ -942,7 +941,7 @@ static int persist_run(specmi_handle* h, const std::vector<OpLaunch>& La, const 
     const int groups = Lb ? 2 : 1;
     std::vector<PersistLayerHost> lay((size_t)nl);
     float *out0 = nullptr, *out1 = nullptr;
-    const int fill = opt_i(h, "persist_fill_wgs", sk_fill(h));
+    const int fill = opt_i(h, "persist_fill_wgs", 0) > 0 ? opt_i(h, "persist_fill_wgs", 0) : sk_fill(h);      // 0 = the latency fill
     const int fu = opt_i(h, "latency_force_unit", 0);
     for (int l = 0; l < nl; ++l) {
         PersistLayerHost& P = lay[(size_t)l];
@@ -961,7 +960,7 @@ static int persist_run(specmi_handle* h, const std::vector<OpLaunch>& La, const 
             if (Lb) P.b.out = nullptr;
         }
     }
-    const int nwg = opt_i(h, "persist_wgs", Lb ? 512 : 256);
+    const int nwg = opt_i(h, "persist_wgs", 0) > 0 ? opt_i(h, "persist_wgs", 0) : (Lb ? 512 : 256);           // 0 = by context
     const int l2pf = opt_i(h, "persist_l2_prefetch", 0);
     size_t ws_need = 0;
     int cnt_need = 0;
@@ -1298,7 +1297,7 @@ int specmi_get_option_i32(specmi_handle* h, const char* name, int* value) {
     const OptSpec* o = find_option(name);
     if (!o) return fail(h, SPECMI_ERR_ARG, "unknown option '%s'", name);
     auto it = h->opt_i.find(name);
-    *value = it != h->opt_i.end() ? it->second : (o->def == kCtx ? 0 : o->def);
+    *value = it != h->opt_i.end() ? it->second : o->def;
     return SPECMI_OK;
 }
 
@@ -1306,7 +1305,7 @@ int specmi_option_info(int index, const char** name, int* default_value, int* is
     const int n = (int)(sizeof(kOptions) / sizeof(kOptions[0]));
     if (index < 0 || index >= n) return SPECMI_ERR_ARG;
     if (name) *name = kOptions[index].name;
-    if (default_value) *default_value = kOptions[index].def == kCtx ? 0 : kOptions[index].def;
+    if (default_value) *default_value = kOptions[index].def;
     if (is_stable) *is_stable = kOptions[index].stable ? 1 : 0;
     return SPECMI_OK;
 }
