@@ -155,7 +155,9 @@ const char* specmi_version(void);
  *     (spec_amd/csrc/conv_persist.hip).  Bit-identical to the per-layer launches and measured SLOWER on MI355X (0.68 vs 0.55 ms,
  *     profiles/r05_a_persist_ab.jsonl); at most two such forwards may be in flight per device.  "persist_wgs" (0 = 512 pair / 256
  *     single), "persist_fill_wgs" (0 = the latency fill), "persist_l2_prefetch" (0), "persist_spin_limit" (400000), "persist_min_run"
- *     (2), "persist_allow_full" (0); specmi_sync_status reports a spin that gave up;
+ *     (2), "persist_max_run" (64; 1 = every layer its own walker launch: resident workgroups walk the layer's tiles, no in-launch
+ *     waits - the round-6 tile-walking ablation, profiles/r06_*_walk_ablation.*), "persist_allow_full" (0); specmi_sync_status
+ *     reports a spin that gave up;
  *   "tail_fuse" (0, opt-in): at small batches each network's tail as ONE launch (spec_amd/csrc/head.hip) - same bits, four graph
  *     nodes less per step and NOT faster on MI355X (profiles/r05_f_tail_check.jsonl). */
 int specmi_set_option_i32(specmi_handle* h, const char* name, int value);

@@ -394,7 +394,7 @@ const OptSpec kOptions[] = {
     {"latency_unit_slots", 256, false}, {"latency_force_unit", 0, false},
     {"wsplit", 1, false}, {"wsplit_max_units", 1400, false}, {"wsplit_max_units_single", 500, false}, {"wsplit_slots", 256, false},
     {"conv2d_sk", 0, false}, {"conv2d_wsplit", 0, false},
-    {"persist", 0, false}, {"persist_min_run", 2, false}, {"persist_wgs", 0, false}, {"persist_fill_wgs", 0, false},
+    {"persist", 0, false}, {"persist_min_run", 2, false}, {"persist_max_run", 64, false}, {"persist_wgs", 0, false}, {"persist_fill_wgs", 0, false},
     {"persist_l2_prefetch", 0, false}, {"persist_spin_limit", 400000, false}, {"persist_allow_full", 0, false},
     {"tail_fuse", 0, false},
 };
@@ -1027,13 +1027,15 @@ static int launch_ops(specmi_handle* ha, specmi_handle* hb, const TrunkPlan& Pa,
     // (the built-in launch profiler wants one record per layer: it sees the per-layer launches)
     const bool persist = mode != 0 && opt_i(ha, "persist", 0) && !ha->prof.on;   // opt-in: measured slower than the per-layer launches (profiles/r05_a_*)
     const size_t min_run = (size_t)opt_i(ha, "persist_min_run", 2);
+    size_t max_run = (size_t)opt_i(ha, "persist_max_run", 64);     // 1: every layer its own walker launch (tiles walked, no in-launch waits)
+    if (max_run < 1 || max_run > (size_t)kPersistMaxLayers) max_run = (size_t)kPersistMaxLayers;
     auto eligible = [&](size_t i) { return La[i].kind == 2 && La[i].family == 0 && !La[i].a.force_variant; };
     int rc;
     size_t i = first;
     while (i < n) {
         if (persist && eligible(i)) {
             size_t j = i;
-            while (j < n && eligible(j) && j - i < (size_t)kPersistMaxLayers) ++j;
+            while (j < n && eligible(j) && j - i < max_run) ++j;
             if (j - i >= min_run) {
                 rc = persist_run(ha, La, hb ? &Lb : nullptr, Pa.ops, i, j, feat_a, feat_b, s);
                 if (rc == SPECMI_OK) { i = j; continue; }

@@ -88,6 +88,7 @@ struct TileCtx {
     float* out = nullptr;            // != nullptr: overrides the layer's output pointer (caller-owned feature buffer)
     unsigned spin_limit = 0;
     int l2_prefetch = 0;             // touch the workgroup's weight slice (one load per 128-byte line) before waiting
+    int walk_first = 1;              // 1: the first item this workgroup runs in this layer (SPECMI_WALK_ABLATE builds only)
 };
 
 constexpr unsigned kOutOfRange = 0x80000000u;  // >= any buffer extent: the load returns zeros

@@ -57,6 +57,7 @@ __global__ void __launch_bounds__(256, 4) conv_persist_kernel(const PLayer* __re
         const int nitems = nblk8 * S * L.groups;
         int i = w - L.rot;
         if (i < 0) i += nwg;
+        int first_item = 1;
         for (; i < nitems; i += nwg) {
             const int r = i / nblk8, bid = i - r * nblk8;
             if (bid >= nblk) continue;
@@ -75,6 +76,8 @@ __global__ void __launch_bounds__(256, 4) conv_persist_kernel(const PLayer* __re
             t.out = L.out_arg ? (z ? out1 : out0) : nullptr;
             t.spin_limit = spin_limit;
             t.l2_prefetch = L.l2_prefetch;
+            t.walk_first = first_item;
+            first_item = 0;
             if (L.body == 0) igemm_tile<64, 64, 2, 2, true, 32, true, true, true, true, CKArgs>(L.k, t);
             else             igemm_tile<64, 64, 2, 2, false, 32, false, true, true, true, CKArgs>(L.k, t);
         }
