@@ -1,5 +1,7 @@
-"""Whole-step time (hipGraph replay) around the latency / throughput crossover: batch 8-20, plans latency and throughput, grouped and two streams."""
-import json, os, sys
+"""Whole-step time (hipGraph replay) around the plan / launch-structure switch points of plan 'auto': plans single (batch <= 4),
+latency and throughput, both trunks grouped per layer and two trunks on two streams.  Every row carries the box it ran on (host name
++ GPU unique id), so sweeps of different gpurun calls can be told apart (round 6: the rules are kept only where two boxes agree)."""
+import json, os, socket, subprocess, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -32,9 +34,29 @@ def step_ms(pp, b, iters=150):
     del g
     return round(best, 4)
 out = open(os.path.join(ROOT, 'gpurun_out', 'plan_crossover.jsonl'), 'a')
+def _box_id():
+    """GPU unique id: sysfs first, rocm-smi's table as a fallback."""
+    import glob
+    for f in sorted(glob.glob('/sys/class/drm/card*/device/unique_id')):
+        try:
+            v = open(f).read().strip()
+            if v:
+                return v
+        except Exception:
+            pass
+    try:
+        txt = subprocess.run(['rocm-smi', '--showuniqueid'], capture_output=True, text=True, timeout=30).stdout
+        for l in txt.splitlines():
+            if l.startswith('GPU[') and 'Unique ID' in l:
+                return l.split(':')[-1].strip()
+    except Exception:
+        pass
+    return None
+uid = [_box_id()]
+BOX = {'host': socket.gethostname(), 'gpu_unique_id': uid[0] if uid else None}
 for b in [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else '8,10,11,12,14,16,20,24').split(',')]:
-    row = {'batch': b}
-    for plan in ('latency', 'throughput'):
+    row = {'batch': b, 'box': BOX}
+    for plan in (('single',) if b <= 4 else ()) + ('latency', 'throughput'):
         cc.set_plan(plan); hm.set_plan(plan)
         row[f'{plan}_grouped'] = step_ms(SpecPipeline(cc, hm, grouped=True), b)
         row[f'{plan}_two_streams'] = step_ms(SpecPipeline(cc, hm, overlap=True, grouped=False), b)

@@ -1234,7 +1234,7 @@ static int run_smpl(specmi_handle* h, const float* rotmat, const float* betas, c
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
-const char* specmi_version(void) { return "specmi 0.5 (gfx950, fp32 MFMA)"; }
+const char* specmi_version(void) { return "specmi 0.6 (gfx950, fp32 MFMA)"; }
 
 int specmi_create(specmi_handle** out, int device_id, int model_kind) {
     if (!out) return fail(nullptr, SPECMI_ERR_ARG, "out is NULL");
