@@ -187,3 +187,76 @@ def test_reference_composed_fixture(pl, plan):
     for k in out:
         err = rel_err(out[k].cpu().numpy(), g[f'out_{k}'])
         assert err < TOL, (plan, k, err)
+
+
+# ---- one layer at a time: folded BatchNorm scales over five decades, zero / negative scales, loud channels --------------------------
+# (Cin, Cout, k, stride, H): the distinct convolution shapes of a ResNet-50 trunk at 224 x 224 (tests/test_gpu_kernels.py)
+from tests.test_gpu_kernels import RESNET_SHAPES  # noqa: E402
+
+LAYER_PATHS = {'throughput': dict(winograd=1, conv2d_sk=0, conv2d_wsplit=0),      # Winograd on the 3x3 stride-1 shapes, 64x64 / 128x128 tiles
+               'direct': dict(winograd=0, conv2d_sk=0, conv2d_wsplit=0),
+               'latency': dict(winograd=0, conv2d_sk=-1, conv2d_wsplit=0),         # the sliced 64x64 kernel with the plan's own tree
+               'wave_split': dict(winograd=0, conv2d_sk=-1, conv2d_wsplit=2)}      # the 32x32 wave-split unit of the same tree
+
+
+@pytest.fixture(scope='module')
+def conv_eng():
+    from spec_amd.engine import Engine
+    e = Engine('camcalib', torch.device(DEV))
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize('path', list(LAYER_PATHS))
+@pytest.mark.parametrize('shape', RESNET_SHAPES, ids=lambda s: 'c%d_%d_k%d_s%d_h%d' % s)
+def test_conv_layer_per_channel_with_wide_scales(conv_eng, shape, path):
+    """A single fused conv + BN (+ residual) launch with released-checkpoint-like folds: scale = gamma / sigma over five decades with
+    exact zeros and negatives, shifts that cancel a large pre-BN mean, a few all-zero filters, heavy-tailed filters and post-ReLU-like
+    inputs with outliers.  Every OUTPUT CHANNEL against a float64 reference, next to a CPU fp32 evaluation of the same formula: a channel
+    whose folded scale is 10^3 below its neighbours' cannot hide behind the tensor's max-norm."""
+    cin, cout, k, stride, H = shape
+    g = torch.Generator().manual_seed(cin * 11 + cout * 3 + k + H)
+    B = 2 if H >= 28 else 3
+    x = torch.relu(torch.randn(B, H, H, cin, generator=g) * 1.5 + 0.5)
+    x = x * torch.where(torch.rand(cin, generator=g) < 0.02, 10.0, 1.0)                      # a few loud input channels
+    tdist = torch.randn(cout, cin, k, k, generator=g) / torch.sqrt((torch.randn(3, cout, cin, k, k, generator=g) ** 2).mean(0).clamp_min(1e-3))
+    w = tdist.clamp(-12, 12) * (1.0 / (3 * cin * k * k)) ** 0.5
+    w[torch.rand(cout, generator=g) < 0.01] = 0.0                                            # dead filters
+    sigma = torch.exp2(torch.randint(-8, 9, (cout,), generator=g).float()) * (1 + torch.rand(cout, generator=g))    # 2^-8 .. 2^9
+    gamma = 0.5 + 0.4 * torch.randn(cout, generator=g)
+    gamma[torch.rand(cout, generator=g) < 0.05] = 0.0
+    sc = gamma / sigma
+    sh = 0.5 * torch.randn(cout, generator=g) - (torch.randn(cout, generator=g) * 2.0) * sc
+    pad = 1 if k == 3 else 0
+    oh = (H + 2 * pad - k) // stride + 1
+    use_res = (k == 1 and cout >= 2 * cin)
+    res = torch.relu(torch.randn(B, oh, oh, cout, generator=g) * 2.0) if use_res else None
+    relu = bool((cin + cout + k) % 2)
+
+    def ref(dtype):
+        y = torch.nn.functional.conv2d(x.to(dtype).permute(0, 3, 1, 2), w.to(dtype), stride=stride, padding=pad)
+        y = (y * sc.to(dtype).view(1, -1, 1, 1) + sh.to(dtype).view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+        if res is not None:
+            y = y + res.to(dtype)
+        return (torch.relu(y) if relu else y).contiguous()
+
+    r64, r32 = ref(torch.float64).numpy(), ref(torch.float32).numpy()
+    opts = LAYER_PATHS[path]
+    for n_, v_ in opts.items():
+        conv_eng.set_option(n_, v_)
+    try:
+        y = conv_eng.conv2d(x.to(DEV), w.numpy(), sc.numpy(), sh.numpy(), stride, pad, residual=None if res is None else res.to(DEV),
+                            relu=relu).cpu().numpy()
+    finally:
+        for n_, v_ in (('winograd', 1), ('conv2d_sk', 0), ('conv2d_wsplit', 0)):
+            conv_eng.set_option(n_, v_)
+    assert y.shape == r64.shape and np.isfinite(y).all()
+    e_gpu, e_cpu = per_channel_errors(y, r64), per_channel_errors(r32, r64)
+    # the magnitude a channel's rounding errors scale with: its largest |term sum| before the ReLU clips it
+    pre = np.abs(r64).reshape(-1, cout).max(axis=0) + np.abs(sh.numpy().astype(np.float64))
+    bound = np.maximum(8.0 * e_cpu, 64 * np.spacing(pre.astype(np.float32)).astype(np.float64))
+    over = e_gpu > bound
+    c = int(np.argmax(e_gpu / np.maximum(bound, 1e-300)))
+    assert not over.any(), (path, shape, int(over.sum()), c, e_gpu[c], e_cpu[c], pre[c], float(sc[c]))
+    ok = e_cpu > 0
+    assert np.median(e_gpu[ok] / e_cpu[ok]) <= 2.0, (path, shape, float(np.median(e_gpu[ok] / e_cpu[ok])))
