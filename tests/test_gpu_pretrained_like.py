@@ -25,7 +25,8 @@ TOL = 1e-4            # BASELINE.json: within 1e-4 relative fp32 of the referenc
 # arithmetic does not clear against itself.  What is asserted instead, per plan and structure:
 CHANNEL_MEDIAN = 1.25  # median over channels of e_gpu / e_cpu: no systematic loss of accuracy (measured 0.83-1.07)
 CHANNEL_P99 = 2.5      # 99th percentile (measured 1.6-2.1; CPU against CPU 1.95)
-CHANNEL_HARD = 8.0     # EVERY channel: e_gpu <= 8 x e_cpu (measured max 3.8; a mis-folded scale or a dropped term is 10^2-10^4) ...
+CHANNEL_HARD = 8.0     # EVERY channel: e_gpu <= 8 x max(e_cpu, the CPU's median relative error x the channel's maximum) (measured max
+                       # 3.8 x e_cpu on ResNet-50; a mis-folded scale or a dropped term is 10^2-10^4) ...
 CHANNEL_FLOOR = 4.0    # ... or <= 4 fp32 ulps of the channel's largest value (channels the CPU happens to get exactly right)
 PLANS = ['single', 'latency', 'throughput']
 STRUCTURES = [(1, 1), (0, 1), (1, 0), (0, 0)]     # (winograd, fuse_downsample)
@@ -59,7 +60,11 @@ def channel_report(feat, f32s, f64):
     e_gpu = per_channel_errors(feat, f64)
     e_cpu = np.max([per_channel_errors(f, f64) for f in f32s], axis=0)
     cmax = np.abs(f64).reshape(-1, f64.shape[-1]).max(axis=0)
-    bound = np.maximum(CHANNEL_HARD * e_cpu, CHANNEL_FLOOR * np.spacing(cmax.astype(np.float32)).astype(np.float64))
+    # a channel the CPU happens to get right to half an ulp (its value rides on the identity path, or every term is exact) is not
+    # held against the GPU: the CPU error of a channel counts for at least the CPU's MEDIAN relative error x the channel's maximum
+    live = cmax > 0
+    med_rel = float(np.median(e_cpu[live] / cmax[live])) if live.any() else 0.0
+    bound = np.maximum(CHANNEL_HARD * np.maximum(e_cpu, med_rel * cmax), CHANNEL_FLOOR * np.spacing(cmax.astype(np.float32)).astype(np.float64))
     ratio = e_gpu / np.maximum(bound, 1e-300)
     ratio[(e_gpu == 0)] = 0.0
     ok = e_cpu > 0
@@ -260,3 +265,47 @@ def test_conv_layer_per_channel_with_wide_scales(conv_eng, shape, path):
     assert not over.any(), (path, shape, int(over.sum()), c, e_gpu[c], e_cpu[c], pre[c], float(sc[c]))
     ok = e_cpu > 0
     assert np.median(e_gpu[ok] / e_cpu[ok]) <= 2.0, (path, shape, float(np.median(e_gpu[ok] / e_cpu[ok])))
+
+
+@pytest.fixture(scope='module')
+def pl34():
+    """CameraRegressorNetwork(backbone='resnet34') - the default of camcalib/config.py:81 - with released-checkpoint-like statistics:
+    BasicBlock trunks take other fused paths (Winograd on both 3x3 convolutions of a block, the second through its residual epilogue)."""
+    from oracle.models import CamCalibOracle, load_numpy_state
+    from spec_amd.modules import CameraRegressorNetwork
+    sd = synth.camcalib_state(2134, backbone='resnet34', stats='pretrained_like')
+    ref = load_numpy_state(CamCalibOracle('resnet34').eval(), sd)
+    ref64 = load_numpy_state(CamCalibOracle('resnet34').eval(), sd).double()
+    m = CameraRegressorNetwork(backbone='resnet34')
+    m.load_state_dict({k: t(v) for k, v in sd.items()}, strict=True)
+    x = t(synth.images(PL_SEED_IMG + 34, 2, saturate=True))
+    f64 = ref64.backbone(x.double()).permute(0, 2, 3, 1).contiguous().numpy()
+    f32 = ref.backbone(x).permute(0, 2, 3, 1).contiguous().numpy()
+    nt = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        f32b = ref.backbone(x.contiguous(memory_format=torch.channels_last)).permute(0, 2, 3, 1).contiguous().numpy()
+    finally:
+        torch.set_num_threads(nt)
+    return {'m': m.to(DEV).eval(), 'ref': ref, 'x': x, 'f64': f64, 'f32': f32, 'f32b': f32b}
+
+
+@pytest.mark.parametrize('wino', [1, 0])
+@pytest.mark.parametrize('plan', PLANS)
+def test_resnet34_trunk_per_channel_vs_float64(pl34, plan, wino):
+    m, x = pl34['m'], pl34['x']
+    eng = m.engine(torch.device(DEV))
+    eng.set_option('winograd', wino)
+    try:
+        with pinned_plan(plan, m):
+            feat = eng.trunk(x.to(DEV)).cpu().numpy()
+            logits = [l.cpu().numpy() for l in m(x.to(DEV))]
+    finally:
+        eng.set_option('winograd', 1)
+    assert feat.shape == pl34['f64'].shape == (2, 7, 7, 512) and np.isfinite(feat).all()
+    rep = channel_report(feat, (pl34['f32'], pl34['f32b']), pl34['f64'])
+    c = rep['argworst']
+    assert rep['n_over'] == 0, (plan, wino, rep['n_over'], rep['worst'], c, rep['e_gpu'][c], rep['e_cpu'][c], rep['cmax'][c])
+    assert rep['median'] <= CHANNEL_MEDIAN and rep['p99'] <= CHANNEL_P99 * 1.2, (plan, wino, rep['median'], rep['p99'], rep['max'])   # (512 channels: p99 = 5 channels)
+    for a, b in zip(logits, pl34['ref'](x)):
+        assert rel_err(a, b.numpy()) < TOL, (plan, wino)
