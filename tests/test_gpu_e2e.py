@@ -130,11 +130,12 @@ def _elementwise_ok(out, ref, key, floor_scale=1.0):
     """The element-wise reading of BASELINE.json's "1e-4 relative fp32": |err| <= 1e-5 |ref| + floor per element, with an
     absolute floor of 2e-6 m for vertices / joints3d (one fp32 ulp of a 2 m body is 2.4e-7 m; the trunk's rounding noise reaches
     the mesh through the regressor) and 1e-4 px (or normalised units) for joints2d.  DESIGN.md section 2 states both readings.
-    ``floor_scale`` = 2 where MANY fresh images meet the CPU oracle directly (batch 16-256).  On the eight probe images of the
+    ``floor_scale`` = 3 where MANY fresh images meet the CPU oracle directly (batch 16-256; the worst of 64 x 6890 x 3 coordinates
+    measured 3.7e-6 m at batch 64, 2.8e-6 m on the batch-256 probe: profiles/r06_*_parity_report*.txt).  On the eight probe images of the
     batch-256 test the CPU fp32 oracle run in another summation order differs FROM ITSELF by 2.6e-6 m (1.4e-6 on the build
     container's CPU) and the GPU differs from it by 2.8e-6 m, while against a float64 oracle the GPU is at 1.27e-6 m and the CPU
     oracle at 1.85e-6 m (profiles/r06_d_parity_report_benign.txt, last section): the floor is the sum of two fp32 paths' noise, not
-    a kernel property; 4e-6 m = 0.004 mm, 25 x below the 0.1 mm W-MPJPE criterion."""
+    a kernel property, and the float64 arbiter is asserted next to it; 6e-6 m = 0.006 mm, 16 x below the 0.1 mm W-MPJPE criterion."""
     a = out.detach().cpu().numpy().astype(np.float64)
     b = np.asarray(ref, dtype=np.float64)
     floor = (1e-4 if key == 'smpl_joints2d' else 2e-6) * floor_scale
@@ -266,7 +267,7 @@ def test_full_batch_256_properties(models):
     occ, ohm = oracle_models(True, True)
     ref = full_pipeline(occ, ohm, *[a[idx].cpu() for a in (x, sc, ce, iw, ih)])
     for k in ('smpl_vertices', 'smpl_joints3d', 'smpl_joints2d'):
-        excess, worst = _elementwise_ok(big[k][idx], ref[k].numpy(), k, floor_scale=2.0)
+        excess, worst = _elementwise_ok(big[k][idx], ref[k].numpy(), k, floor_scale=3.0)
         assert excess <= 0, (k, excess, worst)
     for k in ('pred_cam_t', 'pred_pose', 'pred_shape', 'pred_cam', 'cam_vfov', 'cam_pitch', 'cam_roll'):
         assert rel_err(big[k][idx].cpu().numpy(), ref[k].numpy()) < TOL, k
@@ -310,10 +311,21 @@ def test_mid_batches_vs_oracle_auto_plan(models, B):
     ref = full_pipeline(occ, ohm, x, sc, ce, iw, ih)
     out = SpecPipeline(cc, hm)(x.to(DEV), sc.to(DEV), ce.to(DEV), iw.to(DEV), ih.to(DEV))
     for k in ('smpl_vertices', 'smpl_joints3d', 'smpl_joints2d'):
-        excess, worst = _elementwise_ok(out[k], ref[k].numpy(), k, floor_scale=2.0)
+        excess, worst = _elementwise_ok(out[k], ref[k].numpy(), k, floor_scale=3.0)
         assert excess <= 0, (B, k, excess, worst)
     for k in ('pred_cam_t', 'pred_pose', 'pred_shape', 'pred_cam', 'cam_vfov', 'cam_pitch', 'cam_roll'):
         assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < TOL, (B, k)
+    # the arbiter on the four images where GPU and CPU oracle disagree most: a float64 oracle (trunk, regressor, SMPL) - the GPU mesh
+    # is no further from it than twice the CPU fp32 oracle's distance
+    from tests.util import float64_mesh
+    dev = (out['smpl_vertices'].cpu() - ref['smpl_vertices']).abs().flatten(1).amax(dim=1)
+    worst_imgs = torch.topk(dev, 4).indices
+    ohm64 = oracle_models(True, True)[1].double()
+    v64, j64, _ = float64_mesh(ohm64, x[worst_imgs], ref['cam_rotmat'][worst_imgs], ref['cam_intrinsics'][worst_imgs], ih[worst_imgs])
+    for k, r64 in (('smpl_vertices', v64), ('smpl_joints3d', j64)):
+        e_gpu = float((out[k].cpu()[worst_imgs].double() - r64).abs().max())
+        e_cpu = float((ref[k][worst_imgs].double() - r64).abs().max())
+        assert e_gpu <= 2.0 * e_cpu + 1e-6, (B, k, e_gpu, e_cpu)
 
 
 def test_batch_700_crosses_the_2gib_slices(models):
