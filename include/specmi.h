@@ -105,7 +105,10 @@ const char* specmi_version(void);
  *   torchvision ResNet family the reference's eval(backbone) resolves, spec/models/hmr.py:53, camcalib/model.py:33; HMR also 32 / 48 =
  *   HRNet-W32 / W48, with "hrnet_use_conv" 1 = the '-conv' variant, hmr.py:44-51), "num_fc_layers" (1..3), "num_fc_channels"
  *   (<= 1024, multiple of 32).  HMR: "use_cam" (SMPLCamHead vs SMPLHead, hmr.py:66-74), "use_cam_feats" (hmr.py:55,94-98),
- *   "img_res" (224; hmr.py:69).  Float option: "focal_length" (5000; hmr.py:31).
+ *   "img_res" (224; hmr.py:69), "estimate_var" (0; 1 = HMRHead's uncertainty outputs, hmr.py:35-38,57-64: the library then also wants
+ *   "head.decpose_var.*" (144 rows) and "head.decshape_var.*" (10 rows) - the separate-branch layout; a binding splits the doubled
+ *   decoders of the other layout - and serves specmi_hmr_uncertainty), "uncertainty_activation" (0 none | 1 relu | 2 softplus |
+ *   3 sigmoid | 4 tanh | 5 elu: the torch.nn.functional the reference evaluates by name).  Float option: "focal_length" (5000; hmr.py:31).
  *   Execution, any time (read at every forward):
  *   "plan" - the execution plan of the ResNet trunk:
  *     1 = throughput: the kernels the batch-256 benchmark runs (Winograd F(2x2,3x3) + 64x64 / 128x128 implicit GEMM);
@@ -246,6 +249,13 @@ int specmi_hmr_forward(specmi_handle* h, const float* images_nchw, int B, int H,
                        const float* cam_rotmat, const float* cam_intrinsics,
                        const float* bbox_scale, const float* bbox_center, const float* img_w,
                        const float* img_h, const specmi_hmr_outputs* out, void* stream);
+
+/* The two extra outputs of HMR.forward when the model was built with estimate_var = True (spec/models/hmr.py:35-38,57-64; consumed
+ * by spec/losses.py:61-62): pred_pose_var (B, 288) = [pred_pose_6d | var_pose], pred_shape_var (B, 20) = [pred_shape | var_shape],
+ * the variances being the extra decoder outputs of the LAST regressor iteration through option "uncertainty_activation".  Call after
+ * specmi_hmr_forward / specmi_hmr_regress / specmi_hmr_head_forward of the same batch on the same stream (it reads what that call
+ * left in the handle's workspace); dense outputs.  SPECMI_ERR_STATE without option "estimate_var". */
+int specmi_hmr_uncertainty(specmi_handle* h, int B, float* pred_pose_var, float* pred_shape_var, void* stream);
 
 /* Everything of HMR.forward after `features = self.backbone(images)` (spec/models/hmr.py:94-122): regressor head +
  * SMPL head from an NHWC layer-4 map (B, fh, fw, C).  Lets a caller run the SPEC trunk beside the CamCalib network

@@ -29,6 +29,13 @@ class HMRHead(nn.Module):
 
     fc1 input = [xf(2048), pose6d(144), shape(10), cam(3)] (+ [rot6d(cam_rotmat)(6), vfov(1)]
     when ``use_cam_feats``) - ``spec/models/hmr.py:57-64,94-98``.
+
+    ``estimate_var`` (constructor flags passed at ``spec/models/hmr.py:59-61``; the two extra outputs are consumed by
+    ``spec/losses.py:61-62`` as ``pred['pred_pose_var']`` / ``pred['pred_shape_var']`` against 144- / 10-wide targets): the
+    decoders also emit one variance per pose / shape number - doubled ``decpose`` / ``decshape`` whose first half is the mean
+    update and whose second half is the variance, or separate ``decpose_var`` / ``decshape_var`` layers
+    (``use_separate_var_branch``); the variance of the LAST iteration, through ``F.<uncertainty_activation>`` when one is named,
+    is returned concatenated behind the final mean.
     """
 
     def __init__(self, num_input_features, smpl_mean_params=None, estimate_var=False,
@@ -37,6 +44,9 @@ class HMRHead(nn.Module):
         super().__init__()
         npose = 24 * 6
         self.npose = npose
+        self.estimate_var = estimate_var
+        self.use_separate_var_branch = use_separate_var_branch
+        self.uncertainty_activation = uncertainty_activation
         self.use_cam_feats = use_cam_feats
         if use_cam_feats:
             num_input_features += 7
@@ -45,9 +55,20 @@ class HMRHead(nn.Module):
         self.drop1 = nn.Dropout()
         self.fc2 = nn.Linear(1024, 1024)
         self.drop2 = nn.Dropout()
-        self.decpose = nn.Linear(1024, npose)
-        self.decshape = nn.Linear(1024, 10)
-        self.deccam = nn.Linear(1024, 3)
+        if estimate_var and use_separate_var_branch:
+            self.decpose = nn.Linear(1024, npose)
+            self.decshape = nn.Linear(1024, 10)
+            self.deccam = nn.Linear(1024, 3)
+            self.decpose_var = nn.Linear(1024, npose)
+            self.decshape_var = nn.Linear(1024, 10)
+        elif estimate_var:
+            self.decpose = nn.Linear(1024, npose * 2)       # double the output sizes to estimate var
+            self.decshape = nn.Linear(1024, 10 * 2)
+            self.deccam = nn.Linear(1024, 3)
+        else:
+            self.decpose = nn.Linear(1024, npose)
+            self.decshape = nn.Linear(1024, 10)
+            self.deccam = nn.Linear(1024, 3)
         mp = smpl_mean_params if smpl_mean_params is not None else _ASSETS['mean_params']
         if mp is None:
             mp = {'pose': np.tile(np.array([1, 0, 0, 1, 0, 0], np.float32), 24),
@@ -68,6 +89,7 @@ class HMRHead(nn.Module):
         xf = self.avgpool(features)
         xf = xf.view(xf.size(0), -1)
         pred_pose, pred_shape, pred_cam = init_pose, init_shape, init_cam
+        pred_pose_var = pred_shape_var = None
         for _ in range(n_iter):
             if self.use_cam_feats:
                 xc = torch.cat([xf, pred_pose, pred_shape, pred_cam,
@@ -76,12 +98,31 @@ class HMRHead(nn.Module):
                 xc = torch.cat([xf, pred_pose, pred_shape, pred_cam], 1)
             xc = self.drop1(self.fc1(xc))
             xc = self.drop2(self.fc2(xc))
-            pred_pose = self.decpose(xc) + pred_pose
-            pred_shape = self.decshape(xc) + pred_shape
-            pred_cam = self.deccam(xc) + pred_cam
+            if self.estimate_var:
+                pred_pose = self.decpose(xc)[:, :self.npose] + pred_pose
+                pred_shape = self.decshape(xc)[:, :10] + pred_shape
+                pred_cam = self.deccam(xc) + pred_cam
+                if self.use_separate_var_branch:
+                    pred_pose_var = self.decpose_var(xc)
+                    pred_shape_var = self.decshape_var(xc)
+                else:
+                    pred_pose_var = self.decpose(xc)[:, self.npose:]
+                    pred_shape_var = self.decshape(xc)[:, 10:]
+                if self.uncertainty_activation != '':
+                    act = getattr(torch.nn.functional, self.uncertainty_activation)     # eval(f'F.{name}') upstream
+                    pred_pose_var = act(pred_pose_var)
+                    pred_shape_var = act(pred_shape_var)
+            else:
+                pred_pose = self.decpose(xc) + pred_pose
+                pred_shape = self.decshape(xc) + pred_shape
+                pred_cam = self.deccam(xc) + pred_cam
         pred_rotmat = rot6d_to_rotmat(pred_pose).view(batch_size, 24, 3, 3)
-        return {'pred_pose': pred_rotmat, 'pred_cam': pred_cam, 'pred_shape': pred_shape,
-                'pred_pose_6d': pred_pose}
+        output = {'pred_pose': pred_rotmat, 'pred_cam': pred_cam, 'pred_shape': pred_shape,
+                  'pred_pose_6d': pred_pose}
+        if self.estimate_var:
+            output.update({'pred_pose_var': torch.cat([pred_pose, pred_pose_var], dim=1),
+                           'pred_shape_var': torch.cat([pred_shape, pred_shape_var], dim=1)})
+        return output
 
 
 class SMPLCamHead(nn.Module):

@@ -113,7 +113,9 @@ class HMROracle(nn.Module):
             self.backbone = getattr(_resnet, backbone)()      # eval(backbone)(pretrained=True), hmr.py:53
         self.use_cam_feats = use_cam_feats
         self.head = HMRHead(num_input_features=get_backbone_info(backbone)['n_output_channels'],
-                            backbone=backbone, use_cam_feats=use_cam_feats)
+                            estimate_var=estimate_var, use_separate_var_branch=use_separate_var_branch,
+                            uncertainty_activation=uncertainty_activation,
+                            backbone=backbone, use_cam_feats=use_cam_feats)                  # hmr.py:57-64
         self.use_cam = use_cam
         self.smpl = SMPLCamHead(img_res=img_res) if use_cam else SMPLHead(focal_length=focal_length, img_res=img_res)
 

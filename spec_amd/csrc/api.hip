@@ -303,10 +303,40 @@ static int commit_head_collapsed(specmi_handle* h, int F, int ucf) {
     matmul(E2, E, E3);
     for (int i = 0; i < NS; ++i)
         for (int j = 0; j < NS; ++j) G[(size_t)i * NS + j] = (i == j ? 1.0 : 0.0) + E[(size_t)i * NS + j] + E2[(size_t)i * NS + j];
+    // option "estimate_var": the variance decoders read xc of the LAST iteration, i.e. the state s2 after two iterations:
+    //     var = Wv (W2 (W1 [xf | s2 | c] + b1) + b2) + bv = [Pv | Qv | Tv] [xf | s2 | c] + rv,   s2 = G2 (P xf + T c) + (E2 s0 + G2 r),  G2 = I + E
+    // -> 154 more rows of the same affine map (composed in float64 like the rest)
+    const int NV = h->has_var ? 154 : 0, NO = NS + NV;
+    std::vector<double> PQTv((size_t)NV * nin, 0.0), rv(NV, 0.0);
+    if (NV) {
+        const HostTensor *wpv, *bpv, *wsv, *bsv;
+        if ((rc = need(h, "head.decpose_var.weight", {144, NH}, false, &wpv)) || (rc = need(h, "head.decpose_var.bias", {144}, false, &bpv)) ||
+            (rc = need(h, "head.decshape_var.weight", {10, NH}, false, &wsv)) || (rc = need(h, "head.decshape_var.bias", {10}, false, &bsv)))
+            return rc;
+        std::vector<double> mv(NH);
+        for (int i = 0; i < NV; ++i) {
+            const float* wrow = i < 144 ? wpv->f.data() + (size_t)i * NH : wsv->f.data() + (size_t)(i - 144) * NH;
+            std::fill(mv.begin(), mv.end(), 0.0);
+            for (int k = 0; k < NH; ++k) {
+                const double a = wrow[k];
+                const float* w2k = w2->f.data() + (size_t)k * NH;
+                for (int j = 0; j < NH; ++j) mv[j] += a * (double)w2k[j];
+            }
+            double* pi = PQTv.data() + (size_t)i * nin;
+            double ri = i < 144 ? bpv->f[i] : bsv->f[i - 144];
+            for (int k = 0; k < NH; ++k) {
+                const double a = mv[k];
+                const float* w1k = w1->f.data() + (size_t)k * nin;
+                for (int j = 0; j < nin; ++j) pi[j] += a * (double)w1k[j];
+                ri += a * (double)b1->f[k] + (double)wrow[k] * (double)b2->f[k];
+            }
+            rv[i] = ri;
+        }
+    }
     // composed weight over the xc row layout [xf | state (zero columns) | c], bias = E3 s0 + G r
     FcW& fc = h->head_c;
-    fc.nin = nin; fc.nout = NS; fc.Kp = round_up(nin, 32); fc.Npad = round_up(NS, 64);
-    std::vector<float> wcat((size_t)NS * nin, 0.f), bias(fc.Npad, 0.f), ones(fc.Npad, 1.f), packed;
+    fc.nin = nin; fc.nout = NO; fc.Kp = round_up(nin, 32); fc.Npad = round_up(NO, 64);
+    std::vector<float> wcat((size_t)NO * nin, 0.f), bias(fc.Npad, 0.f), ones(fc.Npad, 1.f), packed;
     for (int i = 0; i < NS; ++i) {
         double bi = 0.0;
         for (int k = 0; k < NS; ++k) bi += E3[(size_t)i * NS + k] * s0[k] + G[(size_t)i * NS + k] * r[k];
@@ -320,11 +350,40 @@ static int commit_head_collapsed(specmi_handle* h, int F, int ucf) {
         }
         for (int j = 0; j < nin; ++j) wcat[(size_t)i * nin + j] = (float)row[j];
     }
-    pack_gemm_weights(wcat.data(), NS, nin, 1, 1, fc.Kp, fc.Npad, packed);
+    if (NV) {
+        // s2 = G2 (P xf + T c) + c2,  c2 = E2 s0 + G2 r
+        std::vector<double> G2((size_t)NS * NS), c2(NS, 0.0);
+        for (int i = 0; i < NS; ++i)
+            for (int j = 0; j < NS; ++j) G2[(size_t)i * NS + j] = (i == j ? 1.0 : 0.0) + E[(size_t)i * NS + j];
+        for (int i = 0; i < NS; ++i)
+            for (int k = 0; k < NS; ++k) c2[i] += E2[(size_t)i * NS + k] * s0[k] + G2[(size_t)i * NS + k] * r[k];
+        std::vector<double> qg(NS), row(nin);
+        for (int i = 0; i < NV; ++i) {
+            const double* pv = PQTv.data() + (size_t)i * nin;
+            // qg = Qv[i] G2 (1 x 157)
+            std::fill(qg.begin(), qg.end(), 0.0);
+            double bi = rv[i];
+            for (int k = 0; k < NS; ++k) {
+                const double q = pv[F + k];
+                bi += q * c2[k];
+                for (int j = 0; j < NS; ++j) qg[j] += q * G2[(size_t)k * NS + j];
+            }
+            for (int j = 0; j < nin; ++j) row[j] = (j < F || j >= F + NS) ? pv[j] : 0.0;
+            for (int k = 0; k < NS; ++k) {
+                const double g = qg[k];
+                const double* pk = PQT.data() + (size_t)k * nin;
+                for (int j = 0; j < F; ++j) row[j] += g * pk[j];
+                for (int j = F + NS; j < nin; ++j) row[j] += g * pk[j];
+            }
+            bias[NS + i] = (float)bi;
+            for (int j = 0; j < nin; ++j) wcat[(size_t)(NS + i) * nin + j] = (float)row[j];
+        }
+    }
+    pack_gemm_weights(wcat.data(), NO, nin, 1, 1, fc.Kp, fc.Npad, packed);
     if ((rc = dev_upload(h, packed.data(), packed.size() * 4, (void**)&fc.w, h->param_allocs))) return rc;
     if ((rc = dev_upload(h, ones.data(), ones.size() * 4, (void**)&fc.scale, h->param_allocs))) return rc;
     if ((rc = dev_upload(h, bias.data(), bias.size() * 4, (void**)&fc.shift, h->param_allocs))) return rc;
-    if ((rc = upload_row_major(h, wcat.data(), NS, nin, fc))) return rc;
+    if ((rc = upload_row_major(h, wcat.data(), NO, nin, fc))) return rc;
     h->has_head_c = true;
     return SPECMI_OK;
 }
@@ -380,7 +439,7 @@ struct OptSpec { const char* name; int def; bool stable; };
 const OptSpec kOptions[] = {
     // stable: model shape (before commit)
     {"backbone", 50, true}, {"num_fc_layers", 1, true}, {"num_fc_channels", 1024, true}, {"use_cam", 0, true}, {"use_cam_feats", 0, true},
-    {"img_res", 224, true}, {"hrnet_use_conv", 1, true},
+    {"img_res", 224, true}, {"hrnet_use_conv", 1, true}, {"estimate_var", 0, true}, {"uncertainty_activation", 0, true},
     // stable: execution (any time)
     {"plan", 0, true}, {"winograd", 1, true}, {"fuse_downsample", 1, true}, {"head_collapse", 1, true}, {"output_ld", 0, true},
     {"angle_ld", 0, true}, {"experimental", 0, true},
@@ -1131,7 +1190,7 @@ static int run_head(specmi_handle* h, const float* feat, int B, int fh, int fw, 
     // head_final deferred into the pose chain and a map that pools in one part.  Opt-in: measured 15.2 us against 16.3 us for the
     // three kernels at batch 1 and the whole step 0-1 % SLOWER at batch 1-10 (profiles/r05_f_tail_check.jsonl) - an in-launch hop
     // costs what a kernel boundary costs on this part.
-    if (defer && pose_done && opt_i(h, "tail_fuse", 0) && use_latency_heads(h, B) && h->has_head_c && opt_i(h, "head_collapse", 1) &&
+    if (defer && pose_done && !h->has_var && opt_i(h, "tail_fuse", 0) && use_latency_heads(h, B) && h->has_head_c && opt_i(h, "head_collapse", 1) &&
         h->head_c.w_rm && fh * fw < 64 && (B + 1) / 2 + 3 <= specmi_handle::kTailCtlWords && h->tail_ctl && !h->prof.on) {
         const HeadInit hi{h->xc, h->init_pose, h->init_shape, h->init_cam, R, K, img_h, ucf, F, LD};
         defer->state = h->h1; defer->ld_state = 1024;
@@ -1178,14 +1237,21 @@ static int run_head(specmi_handle* h, const float* feat, int B, int fh, int fw, 
         if ((rc = fc(h->head_c, h->xc, LD, nullptr, h->h1, 1024, "head.ief_collapsed"))) return rc;
         state = h->h1;
         ld_state = 1024;
+        h->last_var = h->has_var ? h->h1 + 157 : nullptr;      // (the composed map's 154 extra output columns)
+        h->last_ld_var = 1024;
     } else {
         for (int it = 0; it < 3; ++it) {
             if ((rc = fc(h->fc1, h->xc, LD, nullptr, h->h1, 1024, "head.fc1"))) return rc;
             if ((rc = fc(h->fc2, h->h1, 1024, nullptr, h->h2, 1024, "head.fc2"))) return rc;
+            // the variance decoders read the SAME xc as this iteration's mean decoders; only the last iteration's survive
+            if (it == 2 && h->has_var && (rc = fc(h->head_var, h->h2, 1024, nullptr, h->h1, 1024, "head.dec_var"))) return rc;
             float* st = h->xc + F;  // dec* + running estimate, in place
             if ((rc = fc(h->dec, h->h2, 1024, st, st, LD, "head.dec"))) return rc;
         }
+        h->last_var = h->has_var ? h->h1 : nullptr;
+        h->last_ld_var = 1024;
     }
+    h->last_state = state; h->last_ld_state = ld_state; h->last_B = B;
     if (defer) {
         defer->state = state; defer->ld_state = ld_state;
         defer->pred_pose = pred_pose; defer->pred_shape = pred_shape; defer->pred_cam = pred_cam; defer->pred_pose_6d = pred_pose_6d;
@@ -1399,6 +1465,9 @@ int specmi_commit(specmi_handle* h) {
         if ((rc = commit_fc(h, {"head.fc1"}, {1024}, nin, h->fc1))) return rc;
         if ((rc = commit_fc(h, {"head.fc2"}, {1024}, 1024, h->fc2))) return rc;
         if ((rc = commit_fc(h, {"head.decpose", "head.decshape", "head.deccam"}, {144, 10, 3}, 1024, h->dec))) return rc;
+        h->has_var = opt_i(h, "estimate_var", 0) != 0;
+        if (h->has_var && (rc = commit_fc(h, {"head.decpose_var", "head.decshape_var"}, {144, 10}, 1024, h->head_var))) return rc;
+        h->last_state = h->last_var = nullptr; h->last_B = 0;
         const HostTensor *ip, *is, *ic;
         if ((rc = need(h, "head.init_pose", {144}, false, &ip))) return rc;
         if ((rc = need(h, "head.init_shape", {10}, false, &is))) return rc;
@@ -1673,6 +1742,20 @@ int specmi_hmr_regress(specmi_handle* h, const float* feat, int B, int fh, int f
                        out->smpl_vertices, out->smpl_joints3d, out->smpl_joints2d, out->pred_cam_t, old, s, fuse ? &fin : nullptr, pose_done)))
         reset_sync_state(h, s);
     return rc;
+}
+
+int specmi_hmr_uncertainty(specmi_handle* h, int B, float* pred_pose_var, float* pred_shape_var, void* stream) {
+    ENTER(h); NEED_COMMIT(h);
+    if (h->kind != SPECMI_MODEL_HMR) return fail(h, SPECMI_ERR_STATE, "handle is not an HMR model");
+    if (!h->has_var) return fail(h, SPECMI_ERR_STATE, "the model was committed without option \"estimate_var\"");
+    if (!pred_pose_var || !pred_shape_var || B <= 0) return fail(h, SPECMI_ERR_ARG, "bad argument");
+    if (!h->last_state || !h->last_var || h->last_B != B)
+        return fail(h, SPECMI_ERR_STATE, "specmi_hmr_uncertainty follows a head forward of the same batch (%d) on the same stream; the last one had %d",
+                    B, h->last_B);
+    LaunchCtx ctx{(hipStream_t)stream, &h->prof, "head.var"};
+    LAUNCHCHK(h, launch_head_var(h->last_state, h->last_ld_state, h->last_var, h->last_ld_var, opt_i(h, "uncertainty_activation", 0), pred_pose_var,
+                                 pred_shape_var, B, ctx), "head_var");
+    return SPECMI_OK;
 }
 
 int specmi_conv2d(specmi_handle* h, const float* x, int B, int H, int W, int Cin, const float* w_host,

@@ -68,6 +68,14 @@ struct specmi_handle {
     FcW fc1, fc2, dec;         // HMR head (dec = decpose|decshape|deccam)
     FcW head_c;                // the 3 IEF iterations composed into ONE affine map [xf | cam feats] -> 157 (commit_head_collapsed)
     bool has_head_c = false;
+    // option "estimate_var" (HMRHead's uncertainty outputs, spec/models/hmr.py:35-38,57-64): the variance decoders
+    // [decpose_var (144) ; decshape_var (10)] for the nine-GEMM loop; the collapsed map carries them as 154 extra output rows
+    FcW head_var;
+    bool has_var = false;
+    // where the last head forward left the regressed state [pose6d | shape | cam] and the raw variance columns (specmi_hmr_uncertainty)
+    const float* last_state = nullptr; long last_ld_state = 0;
+    const float* last_var = nullptr; long last_ld_var = 0;
+    int last_B = 0;
     int xc_ld = 2240;          // row stride of the IEF state [xf (feat_ch) | pose6d | shape | cam | rot6d(R) | vfov | 0-pad]
     float *init_pose = nullptr, *init_shape = nullptr, *init_cam = nullptr;
     SmplDev smpl;

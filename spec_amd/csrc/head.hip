@@ -72,6 +72,36 @@ int launch_head_final(const float* state, long ld_state, float* pred_pose, float
     return (int)hipGetLastError();
 }
 
+// HMRHead with estimate_var (un-vendored pare; constructor flags at spec/models/hmr.py:35-38,57-64, consumer spec/losses.py:61-62):
+// 'pred_pose_var' = cat([pred_pose_6d, var_pose]), 'pred_shape_var' = cat([pred_shape, var_shape]), the variances being the
+// (optionally activated) extra decoder outputs of the LAST iteration
+__device__ __forceinline__ float uncertainty_act(float x, int act) {
+    switch (act) {
+        case 1: return fmaxf(x, 0.f);                                  // F.relu
+        case 2: return x > 20.f ? x : log1pf(expf(x));                 // F.softplus (beta 1, threshold 20)
+        case 3: return 1.f / (1.f + expf(-x));                         // F.sigmoid
+        case 4: return tanhf(x);                                       // F.tanh
+        case 5: return x > 0.f ? x : expm1f(x);                        // F.elu (alpha 1)
+        default: return x;
+    }
+}
+__global__ void __launch_bounds__(320) head_var_kernel(const float* __restrict__ state, long ld_state, const float* __restrict__ var, long ld_var,
+                                                       int act, float* __restrict__ pose_var, float* __restrict__ shape_var) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float* s = state + (size_t)b * ld_state;
+    const float* v = var + (size_t)b * ld_var;
+    if (t < 144) pose_var[(size_t)b * 288 + t] = s[t];
+    else if (t < 288) pose_var[(size_t)b * 288 + t] = uncertainty_act(v[t - 144], act);
+    else if (t < 298) shape_var[(size_t)b * 20 + t - 288] = s[144 + t - 288];
+    else if (t < 308) shape_var[(size_t)b * 20 + t - 288] = uncertainty_act(v[144 + t - 298], act);
+}
+int launch_head_var(const float* state, long ld_state, const float* var, long ld_var, int act, float* pose_var, float* shape_var,
+                    int B, const LaunchCtx& ctx) {
+    ProfScope ps(ctx, "head_var", 0.0, 4.0 * B * (308 + 308));
+    hipLaunchKernelGGL(head_var_kernel, dim3(B), dim3(320), 0, ctx.stream, state, ld_state, var, ld_var, act, pose_var, shape_var);
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -248,6 +248,10 @@ struct HeadFinal {
 int launch_head_final(const float* state, long ld_state, float* pred_pose, float* pred_shape, float* pred_cam,
                       float* pred_pose_6d, const long ld[4], float* rotmat_ws, float* betas_ws, float* cam_ws,
                       int B, const LaunchCtx& ctx);
+// pred_pose_var (B, 288) = [pose6d | act(var_pose)], pred_shape_var (B, 20) = [shape | act(var_shape)] (pare HMRHead, estimate_var);
+// act: 0 none, 1 relu, 2 softplus, 3 sigmoid, 4 tanh, 5 elu (torch.nn.functional defaults)
+int launch_head_var(const float* state, long ld_state, const float* var, long ld_var, int act, float* pose_var, float* shape_var,
+                    int B, const LaunchCtx& ctx);
 // ld_ang: per-image stride of vfov / pitch / roll (1 when dense)
 int launch_camcalib_decode(const float* lv, const float* lp, const float* lr, int B, int nbins,
                            const float* img_h, const float* img_w, float* vfov, float* pitch,

@@ -348,6 +348,15 @@ class Engine:
             C.byref(o), self._stream()))
         return out
 
+    def hmr_uncertainty(self, B: int):
+        """(pred_pose_var (B, 288), pred_shape_var (B, 20)) of a model committed with ``estimate_var``: call right after the head
+        forward of the same batch on the same stream (``specmi_hmr_uncertainty``)."""
+        pv = torch.empty(B, 288, device=self.device, dtype=torch.float32)
+        sv = torch.empty(B, 20, device=self.device, dtype=torch.float32)
+        if B > 0:
+            _lib.check(self.h, self.lib.specmi_hmr_uncertainty(self.h, int(B), _ptr(pv), _ptr(sv), self._stream()))
+        return pv, sv
+
     def hmr_head(self, feat_nhwc, cam_rotmat=None, cam_intrinsics=None, img_h=None, record=None):
         f = _dev_f32(feat_nhwc, self.device)
         B, fh, fw, _ = f.shape

@@ -206,16 +206,30 @@ def _resnet_family():
             'resnet152': (resnet152, 152)}
 
 
+UNCERTAINTY_ACTIVATIONS = {'': 0, 'relu': 1, 'softplus': 2, 'sigmoid': 3, 'tanh': 4, 'elu': 5}     # F.<name> the reference evaluates
+
+
 class HMRHeadParams(nn.Module):
-    def __init__(self, num_input_features=2048, use_cam_feats=False, mean_params=None):
+    """Parameters of pare's HMRHead in its state_dict layout (call site spec/models/hmr.py:57-64).  ``estimate_var``: the decoders
+    also emit a variance per pose / shape number - doubled ``decpose`` (288 rows: mean | var) / ``decshape`` (20), or, with
+    ``use_separate_var_branch``, the plain decoders plus ``decpose_var`` (144) / ``decshape_var`` (10)."""
+
+    def __init__(self, num_input_features=2048, use_cam_feats=False, mean_params=None, estimate_var=False,
+                 use_separate_var_branch=False):
         super().__init__()
         npose = 24 * 6
         nin = num_input_features + (7 if use_cam_feats else 0) + npose + 13
         self.fc1 = nn.Linear(nin, 1024)
         self.fc2 = nn.Linear(1024, 1024)
-        self.decpose = nn.Linear(1024, npose)
-        self.decshape = nn.Linear(1024, 10)
+        doubled = estimate_var and not use_separate_var_branch
+        self.decpose = nn.Linear(1024, npose * (2 if doubled else 1))
+        self.decshape = nn.Linear(1024, 10 * (2 if doubled else 1))
         self.deccam = nn.Linear(1024, 3)
+        if estimate_var and use_separate_var_branch:
+            self.decpose_var = nn.Linear(1024, npose)
+            self.decshape_var = nn.Linear(1024, 10)
+            nn.init.xavier_uniform_(self.decpose_var.weight, gain=0.01)
+            nn.init.xavier_uniform_(self.decshape_var.weight, gain=0.01)
         nn.init.xavier_uniform_(self.decpose.weight, gain=0.01)
         nn.init.xavier_uniform_(self.decshape.weight, gain=0.01)
         nn.init.xavier_uniform_(self.deccam.weight, gain=0.01)
@@ -296,6 +310,10 @@ class _EngineModule(nn.Module):
     def _options(self):
         return {}
 
+    def _engine_state(self, sd):
+        """state_dict -> the tensors the library stages (identity unless a module's layout differs from the library's)."""
+        return sd
+
     # Optional: the plain 1x1 / stride-1 convolutions of the ResNet trunk as sums of bf16 x bf16 piece products on the bf16
     # matrix cores (conv_bf16s.hip).  0 = exact fp32 MFMA (default, what the benchmark's headline measures), 6 = three-way
     # split, six products: fp32-class results; 3 = two-way split, three products: ~1e-5 on the trunk output.
@@ -347,6 +365,7 @@ class _EngineModule(nn.Module):
             self._engine = Engine(self._kind, device)
         sd = {k: v for k, v in self.state_dict().items()
               if not k.startswith('smpl.') and v.dtype.is_floating_point}
+        sd = self._engine_state(sd)
         self._engine.load(sd, smpl=self._smpl_model(), conv_precision=int(self.conv_precision), plan=self.PLANS[self.plan],
                           **self._options())
         self._tracked = None
@@ -424,9 +443,12 @@ class HMR(_EngineModule):
                  p=0.0, estimate_var=False, use_separate_var_branch=False, uncertainty_activation='',
                  use_cam_feats=False):
         super().__init__()
-        if estimate_var:
-            raise NotImplementedError('estimate_var (uncertainty outputs of HMRHead) is a training-time option the '
-                                      'inference callers never set (spec/tester.py:53-59, spec/trainer.py:50-56)')
+        if uncertainty_activation not in UNCERTAINTY_ACTIVATIONS:
+            raise NotImplementedError(f'uncertainty_activation {uncertainty_activation!r}: one of {sorted(UNCERTAINTY_ACTIVATIONS)} '
+                                      '(the reference evaluates torch.nn.functional.<name>)')
+        self.estimate_var = bool(estimate_var)
+        self.use_separate_var_branch = bool(use_separate_var_branch)
+        self.uncertainty_activation = uncertainty_activation
         self._hrnet_use_conv = 1
         if backbone.startswith('hrnet'):                       # hrnet_w32-conv, hrnet_w32-interp (hmr.py:44-51)
             backbone, use_conv = backbone.split('-')
@@ -443,7 +465,8 @@ class HMR(_EngineModule):
             raise NotImplementedError(f'backbone {backbone!r}: resnet18 / 34 / 50 / 101 / 152, hrnet_w32-(conv|interp), '
                                       'hrnet_w48-(conv|interp) are built (pare also ships a mobilenet trunk: not built)')
         self.use_cam_feats = use_cam_feats
-        self.head = HMRHeadParams(get_backbone_info(backbone)['n_output_channels'], use_cam_feats)
+        self.head = HMRHeadParams(get_backbone_info(backbone)['n_output_channels'], use_cam_feats, estimate_var=self.estimate_var,
+                                  use_separate_var_branch=self.use_separate_var_branch)
         self.use_cam = use_cam
         self.smpl = SMPLHeadParams(img_res=img_res, focal_length=focal_length)
         self.img_res = img_res
@@ -458,7 +481,18 @@ class HMR(_EngineModule):
     def _options(self):
         return {'use_cam': int(self.use_cam), 'use_cam_feats': int(self.use_cam_feats),
                 'img_res': int(self.img_res), 'focal_length': float(self.focal_length),
-                'backbone': self._backbone_id, 'hrnet_use_conv': self._hrnet_use_conv}
+                'backbone': self._backbone_id, 'hrnet_use_conv': self._hrnet_use_conv,
+                'estimate_var': int(self.estimate_var), 'uncertainty_activation': UNCERTAINTY_ACTIVATIONS[self.uncertainty_activation]}
+
+    def _engine_state(self, sd):
+        """The library takes the variance decoders in the separate-branch layout: the doubled decoders are split here."""
+        if self.estimate_var and not self.use_separate_var_branch:
+            sd = dict(sd)
+            for name, n in (('decpose', 144), ('decshape', 10)):
+                for part in ('weight', 'bias'):
+                    full = sd[f'head.{name}.{part}']
+                    sd[f'head.{name}.{part}'], sd[f'head.{name}_var.{part}'] = full[:n], full[n:]
+        return sd
 
     def _smpl_model(self):
         return self.smpl.smpl.as_model()
@@ -468,10 +502,14 @@ class HMR(_EngineModule):
                 img_w=None, img_h=None):
         eng = self.engine(images.device)
         if self.use_cam:
-            return eng.hmr_forward(images, cam_rotmat, cam_intrinsics, bbox_scale, bbox_center, img_w, img_h)
-        if self.use_cam_feats:
-            return eng.hmr_forward(images, cam_rotmat, cam_intrinsics, None, None, None, img_h)
-        return eng.hmr_forward(images)
+            out = eng.hmr_forward(images, cam_rotmat, cam_intrinsics, bbox_scale, bbox_center, img_w, img_h)
+        elif self.use_cam_feats:
+            out = eng.hmr_forward(images, cam_rotmat, cam_intrinsics, None, None, None, img_h)
+        else:
+            out = eng.hmr_forward(images)
+        if self.estimate_var:        # pare HMRHead: the two extra keys spec/losses.py:61-62 reads
+            out['pred_pose_var'], out['pred_shape_var'] = eng.hmr_uncertainty(images.shape[0])
+        return out
 
     # spec/models/hmr.py:124-136
     def load_pretrained(self, file):

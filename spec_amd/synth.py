@@ -349,7 +349,7 @@ def _orthonormal_rot6d(seed, name, n):
 
 
 def hmr_state(seed: int = 1002, use_cam_feats: bool = True, dec_gain: float = 1.0, backbone: str = 'resnet50',
-              stats: str = 'benign', cam_gain: float = None):
+              stats: str = 'benign', cam_gain: float = None, estimate_var: bool = False, use_separate_var_branch: bool = False):
     """HMR parameters: trunk + HMRHead (fc1, fc2, decpose, decshape, deccam, init_*).  ``backbone``: 'resnet50' or
     'hrnet_w32-conv' / 'hrnet_w32-interp' / 'hrnet_w48-...' (spec/models/hmr.py:44-53).  ``dec_gain`` 4 is Xavier gain 1 on the
     decoders; ``cam_gain`` (default: ``dec_gain``) sizes ``deccam`` alone - a trained regressor keeps the weak-perspective scale
@@ -377,6 +377,15 @@ def hmr_state(seed: int = 1002, use_cam_feats: bool = True, dec_gain: float = 1.
         gain = cam_gain if (name == 'deccam' and cam_gain is not None) else dec_gain
         xav = gain * 0.25 * math.sqrt(6.0 / (1024 + nout))
         linear(name, nout, 1024, bound=xav, bias_bound=0.01)
+    if estimate_var:
+        # pare HMRHead with estimate_var (spec/models/hmr.py:35-38,59-61): variance decoders as their own layers, or as the second
+        # half of doubled decpose / decshape (the mean half keeps the values above)
+        for name, nout in (('decpose', 144), ('decshape', 10)):
+            xav = 4.0 * 0.25 * math.sqrt(6.0 / (1024 + nout))
+            linear(name + '_var', nout, 1024, bound=xav, bias_bound=0.3)
+            if not use_separate_var_branch:
+                for part in ('weight', 'bias'):
+                    sd[f'head.{name}.{part}'] = np.concatenate([sd[f'head.{name}.{part}'], sd.pop(f'head.{name}_var.{part}')], axis=0)
     sd['head.init_pose'] = (_orthonormal_rot6d if stats == 'pretrained_like' else _random_rot6d)(seed, 'head.init_pose', 24).reshape(1, 144)
     sd['head.init_shape'] = normal(seed, 'head.init_shape', (1, 10), std=0.5)
     sd['head.init_cam'] = np.array([[0.9, 0.0, 0.0]], dtype=np.float32) \

@@ -213,6 +213,25 @@ def generate(OUT, upstream=False):
                         out_keys=np.array(list(out.keys())), **{f'out_{k}': v.numpy() for k, v in out.items()})
     print('pretrained_like', {k: (tuple(v.shape), float(v.abs().max())) for k, v in out.items()})
 
+    # ---- (8) HMR(estimate_var=True) through the reference's spec/models/hmr.py: both decoder layouts of pare's HMRHead ----------
+    B = 2
+    imgs = synth.images(SEED_IMG + 2, B)
+    scale, center, img_w, img_h = synth.bbox_inputs(SEED_IMG + 2, B, img_w=640., img_h=480.)
+    from oracle.models import cam_params as _cam_params
+    R, K = _cam_params(t(synth.uniform(6, 'pitch', (B,), -0.5, 0.5)), t(synth.uniform(6, 'roll', (B,), -0.4, 0.4)),
+                       synth.uniform(6, 'fpix', (B,), 300., 900.), t(img_w), t(img_h))
+    for tag, separate, act in (('doubled', False, 'softplus'), ('separate', True, 'sigmoid')):
+        model = HMR(backbone='resnet50', img_res=224, pretrained=None, use_cam=True, use_cam_feats=True, estimate_var=True,
+                    use_separate_var_branch=separate, uncertainty_activation=act).eval()
+        load_numpy_state(model, synth.hmr_state(SEED_HMR, True, estimate_var=True, use_separate_var_branch=separate))
+        out = model(t(imgs), cam_rotmat=R, cam_intrinsics=K, bbox_scale=t(scale), bbox_center=t(center), img_w=t(img_w), img_h=t(img_h))
+        np.savez_compressed(os.path.join(OUT, f'hmr_e2e_var_{tag}.npz'), seed_weights=SEED_HMR, seed_smpl=SEED_SMPL, seed_images=SEED_IMG + 2,
+                            batch=B, uncertainty_activation=np.array(act), cam_rotmat=R.numpy(), cam_intrinsics=K.numpy(), bbox_scale=scale,
+                            bbox_center=center, img_w=img_w, img_h=img_h, out_keys=np.array(list(out.keys())),
+                            state_keys=np.array([k for k in model.state_dict().keys() if k.startswith('head.')]),
+                            **{f'out_{k}': v.numpy() for k, v in out.items()})
+        print('estimate_var', tag, {k: tuple(v.shape) for k, v in out.items() if k.endswith('_var')})
+
     sz = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith('.npz'))
     print('fixtures written to', OUT, 'total bytes', sz)
     return sorted(f for f in os.listdir(OUT) if f.endswith('.npz'))

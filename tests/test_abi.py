@@ -76,6 +76,7 @@ def _option_table(lib):
 
 
 STABLE = {'backbone': 50, 'num_fc_layers': 1, 'num_fc_channels': 1024, 'use_cam': 0, 'use_cam_feats': 0, 'img_res': 224, 'hrnet_use_conv': 1,
+          'estimate_var': 0, 'uncertainty_activation': 0,
           'plan': 0, 'winograd': 1, 'fuse_downsample': 1, 'head_collapse': 1, 'output_ld': 0, 'angle_ld': 0, 'experimental': 0}
 
 
