@@ -40,25 +40,31 @@ def _inputs(B, seed):
     return x, R, K, sc, ce, iw, ih
 
 
-@pytest.mark.parametrize('act', ['', 'relu', 'softplus', 'sigmoid', 'tanh', 'elu'])
 @pytest.mark.parametrize('separate', [False, True])
-def test_uncertainty_outputs_vs_oracle(separate, act):
-    m, ref = _models(separate, act)
+def test_uncertainty_outputs_vs_oracle(separate):
+    from spec_amd.modules import UNCERTAINTY_ACTIVATIONS
+    m, ref = _models(separate, 'softplus')
+    eng = m.engine(torch.device(DEV))
     assert [k for k in m.state_dict() if k.startswith('head.')] == [k for k in ref.state_dict() if k.startswith('head.')]
-    for B, collapse in ((1, 1), (3, 0), (3, 1), (40, 1), (40, 0)):           # GEMV (<= 10 rows) and GEMM head paths, composed map and loop
-        ins = _inputs(B, 700 + B)
-        want = ref(*ins)
-        m.engine(torch.device(DEV)).set_option('head_collapse', collapse)
-        out = m(*[a.to(DEV) for a in ins])
-        assert sorted(out.keys()) == sorted(want.keys())
-        assert out['pred_pose_var'].shape == (B, 288) and out['pred_shape_var'].shape == (B, 20)
-        for k in want:
-            assert rel_err(out[k].cpu().numpy(), want[k].numpy()) < TOL, (separate, act, B, collapse, k)
-        # the mean halves ARE the regressed pose / shape; the variance halves on their own scale
-        assert torch.equal(out['pred_pose_var'][:, :144], out['pred_pose_6d']) and torch.equal(out['pred_shape_var'][:, :10], out['pred_shape'])
-        for k, n in (('pred_pose_var', 144), ('pred_shape_var', 10)):
-            assert rel_err(out[k][:, n:].cpu().numpy(), want[k][:, n:].numpy()) < TOL, (separate, act, B, collapse, k, 'variance half')
-    m.engine(torch.device(DEV)).set_option('head_collapse', 1)
+    for act in ('softplus', '', 'relu', 'sigmoid', 'tanh', 'elu'):
+        # the activation is read at every call: one committed model serves all of them
+        m.uncertainty_activation = ref.head.uncertainty_activation = act
+        eng.set_option('uncertainty_activation', UNCERTAINTY_ACTIVATIONS[act])
+        # GEMV (<= 10 rows) and GEMM head paths, composed map and nine-GEMM loop (all five for the first activation)
+        for B, collapse in (((1, 1), (3, 0), (3, 1), (40, 1), (40, 0)) if act == 'softplus' else ((3, 1), (3, 0))):
+            ins = _inputs(B, 700 + B)
+            want = ref(*ins)
+            eng.set_option('head_collapse', collapse)
+            out = m(*[a.to(DEV) for a in ins])
+            assert sorted(out.keys()) == sorted(want.keys())
+            assert out['pred_pose_var'].shape == (B, 288) and out['pred_shape_var'].shape == (B, 20)
+            for k in want:
+                assert rel_err(out[k].cpu().numpy(), want[k].numpy()) < TOL, (separate, act, B, collapse, k)
+            # the mean halves ARE the regressed pose / shape; the variance halves on their own scale
+            assert torch.equal(out['pred_pose_var'][:, :144], out['pred_pose_6d']) and torch.equal(out['pred_shape_var'][:, :10], out['pred_shape'])
+            for k, n in (('pred_pose_var', 144), ('pred_shape_var', 10)):
+                assert rel_err(out[k][:, n:].cpu().numpy(), want[k][:, n:].numpy()) < TOL, (separate, act, B, collapse, k, 'variance half')
+    eng.set_option('head_collapse', 1)
 
 
 def test_uncertainty_call_order_and_errors():
