@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libspecmi.so')
-SOURCES = ['api.hip', 'hrnet.hip', 'conv_igemm.hip', 'conv_persist.hip', 'conv_wsplit.hip', 'conv_wino.hip', 'conv_bf16s.hip', 'stem.hip', 'head.hip', 'smpl.hip', 'eval.hip', 'preprocess.hip']
+SOURCES = ['api.hip', 'commit.hip', 'options.hip', 'hrnet.hip', 'conv_igemm.hip', 'conv_persist.hip', 'conv_wsplit.hip', 'conv_wino.hip', 'conv_bf16s.hip', 'stem.hip', 'head.hip', 'smpl.hip', 'eval.hip', 'preprocess.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
 

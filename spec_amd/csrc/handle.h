@@ -130,7 +130,7 @@ int fail(specmi_handle* h, int code, const char* fmt, ...);
     } while (0)
 
 
-// ---- shared host helpers (api.hip) -------------------------------------------------------------------------
+// ---- shared host helpers (api.hip; find / need: commit.hip; opt_i / opt_f: options.hip) -------------------------------------------------------------------------
 int round_up(int x, int m);
 int conv_out(int x, int k, int s, int p);
 int dev_upload(specmi_handle* h, const void* src, size_t bytes, void** out, std::vector<void*>& pool);
@@ -140,8 +140,16 @@ const HostTensor* find(specmi_handle* h, const std::string& name);
 int need(specmi_handle* h, const std::string& name, std::initializer_list<int64_t> shape, bool is_int, const HostTensor** out);
 int opt_i(specmi_handle* h, const char* name, int dflt);
 float opt_f(specmi_handle* h, const char* name, float dflt);
+// ---- commit.hip: packing, BatchNorm folding, the composed regressor, layer tables, SMPL constants ----------
 // conv weight + eval-mode BatchNorm under state-dict names prefix + c.name / c.bn_name -> packed device tensors
 int commit_conv(specmi_handle* h, const std::string& prefix, ConvW& c);
+// OIHW -> [Kp/4][Npad][4], k = (ky*KW + kx)*Cin + ci (zero padded): the MFMA B-fragment layout of the implicit-GEMM kernels
+void pack_gemm_weights(const float* w, int cout, int cin, int kh, int kw, int Kp, int Npad, std::vector<float>& out);
+int commit_fused_ds(specmi_handle* h, const std::string& prefix, Bneck& b);
+int commit_fc(specmi_handle* h, const std::vector<std::string>& names, const std::vector<int>& nouts, int nin, FcW& fc);
+int commit_head_collapsed(specmi_handle* h, int F, int ucf);
+void build_resnet(specmi_handle* h, int depth);
+int commit_smpl(specmi_handle* h);
 
 // ---- HRNet trunks (hrnet.hip) ------------------------------------------------------------------------------
 struct HrNet;
