@@ -309,3 +309,22 @@ def test_resnet34_trunk_per_channel_vs_float64(pl34, plan, wino):
     assert rep['median'] <= CHANNEL_MEDIAN and rep['p99'] <= CHANNEL_P99 * 1.2, (plan, wino, rep['median'], rep['p99'], rep['max'])   # (512 channels: p99 = 5 channels)
     for a, b in zip(logits, pl34['ref'](x)):
         assert rel_err(a, b.numpy()) < TOL, (plan, wino)
+
+
+def test_camcalib_full_frame_vs_oracle(pl):
+    """The demo's operating point for CamCalib (scripts/camcalib_demo.py:95-129: one full frame at short side 600, batch 1) with the
+    stand-in checkpoint - a resolution the running statistics were NOT calibrated at: logits within 1e-4 of the CPU oracle, decoded
+    angles within 2e-5 rad, under the plan 'auto' picks and under the throughput plan."""
+    from spec_amd.cam_utils import convert_preds_to_angles
+    from oracle.models import decode_angles
+    cc, occ = pl['cc'], pl['occ']
+    x = t(synth.images(PL_SEED_IMG + 600, 1, 600, 1066, saturate=True))
+    want = occ(x)
+    wang = decode_angles(*want)
+    for plan in ('auto', 'throughput'):
+        with pinned_plan(plan, cc):
+            got = cc(x.to(DEV))
+        for a, b in zip(got, want):
+            assert rel_err(a.cpu().numpy(), b.numpy()) < TOL, plan
+        for a, b in zip(convert_preds_to_angles(*got, loss_type='softargmax_l2'), wang):
+            assert np.abs(a.cpu().numpy() - b.numpy()).max() < 2e-5, plan
