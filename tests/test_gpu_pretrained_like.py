@@ -328,3 +328,33 @@ def test_camcalib_full_frame_vs_oracle(pl):
             assert rel_err(a.cpu().numpy(), b.numpy()) < TOL, plan
         for a, b in zip(convert_preds_to_angles(*got, loss_type='softargmax_l2'), wang):
             assert np.abs(a.cpu().numpy() - b.numpy()).max() < 2e-5, plan
+
+
+@pytest.mark.parametrize('use_cam,ucf', [(True, False), (False, False)], ids=['cam', 'nocam'])
+def test_other_head_variants_vs_oracle(use_cam, ucf):
+    """The two other constructor variants of HMR (spec/models/hmr.py:66-74: SMPLCamHead without camera features, and the non-camera
+    SMPLHead) on the same stand-in trunk: every output within 1e-4 of the CPU oracle, three plans, B = 2."""
+    from oracle import heads
+    from oracle.models import HMROracle, cam_params, load_numpy_state
+    from spec_amd import assets
+    from spec_amd.modules import HMR
+    from tests.util import PL_CAM_GAIN, PL_DEC_GAIN, PL_SEED_HM
+    assets.use_synthetic_assets(1003)
+    heads.set_assets(smpl_model=smpl_model())
+    sd = synth.hmr_state(PL_SEED_HM, ucf, dec_gain=PL_DEC_GAIN, cam_gain=PL_CAM_GAIN, stats='pretrained_like')
+    ref = load_numpy_state(HMROracle(use_cam=use_cam, use_cam_feats=ucf).eval(), sd)
+    m = HMR(use_cam=use_cam, use_cam_feats=ucf)
+    missing, unexpected = m.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(k.startswith('smpl.') for k in missing)
+    m = m.to(DEV).eval()
+    B = 2
+    x = t(synth.images(PL_SEED_IMG + 50, B, saturate=True))
+    sc, ce, iw, ih = [t(a) for a in synth.bbox_inputs(PL_SEED_IMG + 50, B, 640., 480.)]
+    R, K = cam_params(t(np.array([-0.3, 0.2], np.float32)), t(np.array([0.1, -0.15], np.float32)), np.array([480., 640.]), iw, ih)
+    want = ref(x, R, K, sc, ce, iw, ih) if use_cam else ref(x)
+    for plan in PLANS:
+        with pinned_plan(plan, m):
+            out = m(x.to(DEV), R.to(DEV), K.to(DEV), sc.to(DEV), ce.to(DEV), iw.to(DEV), ih.to(DEV)) if use_cam else m(x.to(DEV))
+        assert sorted(out.keys()) == sorted(want.keys())
+        for k in want:
+            assert rel_err(out[k].cpu().numpy(), want[k].numpy()) < TOL, (plan, k)
