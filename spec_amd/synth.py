@@ -170,6 +170,16 @@ def _calibrate_trunk(sd, seed, prefix, specs, basic):
             * g.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
         return y.clamp_(min=0) if relu else y
 
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(nthreads, 16)))   # float64 convolutions crawl when oversubscribed (containers with a CPU quota)
+    try:
+        _calibrate_blocks(x, specs, basic, conv_bn, F)
+    finally:
+        torch.set_num_threads(nthreads)
+    return sd
+
+
+def _calibrate_blocks(x, specs, basic, conv_bn, F):
     x = F.max_pool2d(conv_bn(x, specs[0], True), 3, 2, 1)
     blocks = OrderedDict()                          # 'layer1.0' -> {member name: spec}
     for s_ in specs[1:]:
@@ -182,7 +192,6 @@ def _calibrate_trunk(sd, seed, prefix, specs, basic):
             out = conv_bn(conv_bn(out, members['conv2'], True), members['conv3'], False)
         identity = conv_bn(x, members['downsample.0'], False) if 'downsample.0' in members else x
         x = (out + identity).clamp_(min=0)
-    return sd
 
 
 def _pretrained_like_trunk(seed, prefix, specs, basic=False):
@@ -349,7 +358,8 @@ def _orthonormal_rot6d(seed, name, n):
 
 
 def hmr_state(seed: int = 1002, use_cam_feats: bool = True, dec_gain: float = 1.0, backbone: str = 'resnet50',
-              stats: str = 'benign', cam_gain: float = None, estimate_var: bool = False, use_separate_var_branch: bool = False):
+              stats: str = 'benign', cam_gain: float = None, estimate_var: bool = False, use_separate_var_branch: bool = False,
+              with_trunk: bool = True):
     """HMR parameters: trunk + HMRHead (fc1, fc2, decpose, decshape, deccam, init_*).  ``backbone``: 'resnet50' or
     'hrnet_w32-conv' / 'hrnet_w32-interp' / 'hrnet_w48-...' (spec/models/hmr.py:44-53).  ``dec_gain`` 4 is Xavier gain 1 on the
     decoders; ``cam_gain`` (default: ``dec_gain``) sizes ``deccam`` alone - a trained regressor keeps the weak-perspective scale
@@ -357,8 +367,10 @@ def hmr_state(seed: int = 1002, use_cam_feats: bool = True, dec_gain: float = 1.
     if backbone.startswith('hrnet'):
         name, mode = backbone.split('-')
         width = 32 if name == 'hrnet_w32' else 48
-        sd = hrnet_state(seed, width, mode == 'conv', 'backbone.')
+        sd = hrnet_state(seed, width, mode == 'conv', 'backbone.') if with_trunk else OrderedDict()
         feat = width * 15
+    elif not with_trunk:            # head parameters only (the caller brings its own trunk)
+        sd, feat = OrderedDict(), (512 if RESNET_FAMILY[backbone][0] == 'basic' else 2048)
     else:
         sd, feat = resnet_family_state(seed, backbone, 'backbone.', stats)
     nin = feat + 144 + 13 + (7 if use_cam_feats else 0)

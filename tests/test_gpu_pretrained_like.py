@@ -12,7 +12,7 @@ import pytest
 import torch
 
 from spec_amd import synth
-from tests.util import (PL_SEED_IMG, golden, per_channel_errors, pinned_plan, pl_gpu_models, pl_oracle_models, rel_err, smpl_model, t)
+from tests.util import (PL_SEED_IMG, cpu_threads, golden, per_channel_errors, pinned_plan, pl_gpu_models, pl_oracle_models, rel_err, smpl_model, t)
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
@@ -38,7 +38,8 @@ def build_pl():
     occ, ohm = pl_oracle_models()
     _, ohm64 = pl_oracle_models(double=True)
     x = t(synth.images(PL_SEED_IMG, 2, saturate=True))
-    f64 = ohm64.backbone(x.double()).permute(0, 2, 3, 1).contiguous()
+    with cpu_threads():
+        f64 = ohm64.backbone(x.double()).permute(0, 2, 3, 1).contiguous()
     f32 = ohm.backbone(x).permute(0, 2, 3, 1).contiguous()
     nt = torch.get_num_threads()
     torch.set_num_threads(1)
@@ -154,7 +155,7 @@ def test_mesh_vs_float64(pl, plan):
     R, K = cam_params(t(np.array([-0.4, 0.25], np.float32)), t(np.array([0.15, -0.2], np.float32)), np.array([520., 610.]), iw, ih)
     ref32 = ohm(x, R, K, sc, ce, iw, ih)
     vfov64 = 2 * torch.atan(ih.double() / (2 * K[:, 0, 0].double()))
-    h64 = ohm64.head(t(pl['f64']).permute(0, 3, 1, 2), cam_rotmat=R.double(), cam_vfov=vfov64)
+    h64 = ohm64.head(t(pl['f64']).permute(0, 3, 1, 2), cam_rotmat=R.double(), cam_vfov=vfov64)      # (the float64 trunk map of the fixture)
     v64, j64 = ohm64.smpl.smpl(h64['pred_shape'], h64['pred_pose'])
     with pinned_plan(plan, hm):
         out = hm(x.to(DEV), R.to(DEV), K.to(DEV), sc.to(DEV), ce.to(DEV), iw.to(DEV), ih.to(DEV))
@@ -279,7 +280,8 @@ def pl34():
     m = CameraRegressorNetwork(backbone='resnet34')
     m.load_state_dict({k: t(v) for k, v in sd.items()}, strict=True)
     x = t(synth.images(PL_SEED_IMG + 34, 2, saturate=True))
-    f64 = ref64.backbone(x.double()).permute(0, 2, 3, 1).contiguous().numpy()
+    with cpu_threads():
+        f64 = ref64.backbone(x.double()).permute(0, 2, 3, 1).contiguous().numpy()
     f32 = ref.backbone(x).permute(0, 2, 3, 1).contiguous().numpy()
     nt = torch.get_num_threads()
     torch.set_num_threads(1)
@@ -358,3 +360,48 @@ def test_other_head_variants_vs_oracle(use_cam, ucf):
         assert sorted(out.keys()) == sorted(want.keys())
         for k in want:
             assert rel_err(out[k].cpu().numpy(), want[k].numpy()) < TOL, (plan, k)
+
+
+@pytest.mark.parametrize('backbone', ['hrnet_w32-conv', 'hrnet_w48-interp'])
+def test_hrnet_trunk_per_channel_vs_float64(backbone):
+    """HRNet-W32 / W48 (spec/models/hmr.py:44-51) with released-checkpoint-like statistics (hook-calibrated on the oracle trunk,
+    tests/util.py): exchange-unit sums of branches whose scales differ by decades, the padded 48-wide branch, both head modes.  The
+    480 / 720-channel map per channel against a float64 oracle like the ResNet trunks, and HMR end to end within 1e-4 of the oracle."""
+    from oracle import heads
+    from oracle.models import HMROracle, cam_params, load_numpy_state
+    from spec_amd import assets
+    from spec_amd.modules import HMR
+    from tests.util import PL_CAM_GAIN, PL_DEC_GAIN, pretrained_like_by_hooks
+    assets.use_synthetic_assets(1003)
+    heads.set_assets(smpl_model=smpl_model())
+    sd = synth.hmr_state(2148, True, dec_gain=PL_DEC_GAIN, cam_gain=PL_CAM_GAIN, backbone=backbone, with_trunk=False)      # head only
+    ref = HMROracle(backbone=backbone, use_cam=True, use_cam_feats=True).eval()
+    trunk_sd = pretrained_like_by_hooks(ref.backbone, 2148, t(synth.images(2148 + 7919, 4, saturate=True)))
+    sd.update({'backbone.' + k: v for k, v in trunk_sd.items()})
+    sd['head.init_pose'] = synth._orthonormal_rot6d(2148, 'head.init_pose', 24).reshape(1, 144)
+    load_numpy_state(ref, sd)
+    ref64 = load_numpy_state(HMROracle(backbone=backbone, use_cam=True, use_cam_feats=True).eval(), sd).double()
+    m = HMR(backbone=backbone, use_cam=True, use_cam_feats=True)
+    missing, unexpected = m.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(k.startswith('smpl.') for k in missing), (missing, unexpected)
+    m = m.to(DEV).eval()
+    B = 2
+    x = t(synth.images(PL_SEED_IMG + 32, B, saturate=True))
+    with cpu_threads():
+        f64 = ref64.backbone(x.double()).permute(0, 2, 3, 1).contiguous().numpy()
+    f32 = ref.backbone(x).permute(0, 2, 3, 1).contiguous().numpy()
+    f32b = ref.backbone(x.contiguous(memory_format=torch.channels_last)).permute(0, 2, 3, 1).contiguous().numpy()
+    var = np.concatenate([v.ravel() for k, v in trunk_sd.items() if k.endswith('running_var')])
+    assert var.max() / var.min() > 1e5 and np.abs(f64).max() > 5
+    feat = m.engine(torch.device(DEV)).trunk(x.to(DEV)).cpu().numpy()
+    assert feat.shape == f64.shape and np.isfinite(feat).all()
+    rep = channel_report(feat, (f32, f32b), f64)
+    c = rep['argworst']
+    assert rep['n_over'] == 0, (backbone, rep['n_over'], rep['worst'], c, rep['e_gpu'][c], rep['e_cpu'][c], rep['cmax'][c])
+    assert rep['median'] <= CHANNEL_MEDIAN * 1.2 and rep['p99'] <= CHANNEL_P99 * 1.2, (backbone, rep['median'], rep['p99'], rep['max'])
+    sc, ce, iw, ih = [t(a) for a in synth.bbox_inputs(PL_SEED_IMG + 32, B, 640., 480.)]
+    R, K = cam_params(t(np.array([-0.3, 0.2], np.float32)), t(np.array([0.1, -0.15], np.float32)), np.array([480., 640.]), iw, ih)
+    want = ref(x, R, K, sc, ce, iw, ih)
+    out = m(x.to(DEV), R.to(DEV), K.to(DEV), sc.to(DEV), ce.to(DEV), iw.to(DEV), ih.to(DEV))
+    for k in want:
+        assert rel_err(out[k].cpu().numpy(), want[k].numpy()) < TOL, (backbone, k)

@@ -67,6 +67,18 @@ def gpu_models(use_cam=True, use_cam_feats=True, device='cuda:0'):
 
 
 @contextlib.contextmanager
+def cpu_threads(n=16):
+    """Cap torch's intra-op threads for the float64 oracle passes: on the GPU boxes the container sees 128 logical CPUs but may use
+    16 (cgroup quota) - float64 convolutions run 3-5 x slower oversubscribed (bench.py's thread sweep peaks at 16 for the same reason)."""
+    old = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(old, n)))
+    try:
+        yield
+    finally:
+        torch.set_num_threads(old)
+
+
+@contextlib.contextmanager
 def pinned_plan(plan, *modules):
     """Run a block with the trunk execution plan of ``modules`` pinned ('throughput' | 'latency' | 'auto').  Bit-identity
     across batch sizes holds WITHIN a plan; 'auto' (the default) switches to the latency plan at 10 images or fewer (16 for a single trunk)."""
@@ -129,8 +141,69 @@ def per_channel_errors(x, ref64):
 def float64_mesh(hmr_oracle64, images, cam_rotmat, cam_intrinsics, img_h):
     """(vertices, joints3d, head outputs) of an HMR oracle converted with ``.double()``: trunk, regressor head and SMPL in float64
     (the camera conversion / projection leaves of oracle/geometry.py cast to fp32 as upstream does, so the arbiter stops at the mesh)."""
-    f64 = hmr_oracle64.backbone(images.double())
+    with cpu_threads():
+        f64 = hmr_oracle64.backbone(images.double())
     vfov = 2 * torch.atan(img_h.double() / (2 * cam_intrinsics[:, 0, 0].double()))
     h64 = hmr_oracle64.head(f64, cam_rotmat=cam_rotmat.double(), cam_vfov=vfov)
     v64, j64 = hmr_oracle64.smpl.smpl(h64['pred_shape'], h64['pred_pose'])
     return v64, j64, h64
+
+
+def pretrained_like_by_hooks(trunk, seed, images):
+    """Released-checkpoint-like statistics for ANY oracle trunk made of Conv2d -> BatchNorm2d pairs (HRNet: only the oracle knows
+    the wiring), the hook-driven twin of ``spec_amd.synth._calibrate_trunk``: Student-t(3) filters with a few dead ones, running_var
+    log-uniform over six decades, gamma ~ N(0.5, 0.4) with exact zeros / negatives / loud channels, beta ~ N(0, 0.5); then ONE float64
+    pass over ``images`` in which every BatchNorm, just before it runs, scales the filters of the convolution that fed it by the power
+    of two that brings the channel's standard deviation within [0.71, 1.41] sigma and sets running_mean to the channel mean + N(0, 0.3
+    sigma) rounded to sigma / 32.  Returns the state as {name: float32 ndarray}; ``trunk`` is left in float32 with that state."""
+    from spec_amd import synth
+    torch.set_grad_enabled(False)
+    g = torch.Generator().manual_seed(seed)       # (the filters come from torch's generator: this state is used inside ONE process,
+    for name, m in trunk.named_modules():         #  by the oracle and the GPU module alike - no cross-host reproducibility needed)
+        if isinstance(m, torch.nn.Conv2d):
+            cout, cin, k, _ = m.weight.shape
+            z = torch.randn(4, cout, cin, k, k, generator=g)
+            w = (z[0] / torch.sqrt((z[1:] ** 2).mean(0).clamp_min(1e-3)) / 3 ** 0.5).clamp_(-12, 12) * (1.0 / (cin * k * k)) ** 0.5
+            w[torch.rand(cout, generator=g) < 0.005] = 0.0
+            m.weight.copy_(w)
+        elif isinstance(m, torch.nn.BatchNorm2d):
+            n = m.num_features
+            gamma = synth.normal(seed, name + '.weight', (n,), std=0.4, mean=0.5)
+            gamma[synth.uniform01(seed, name + '.zero', n) < 0.05] = 0.0
+            gamma[synth.uniform01(seed, name + '.outlier', n) < 0.01] *= 6.0
+            m.weight.copy_(t(gamma))
+            m.bias.copy_(t(synth.normal(seed, name + '.bias', (n,), std=0.5)))
+            m.running_var.copy_(t(synth.log_uniform_pow2(seed, name + '.running_var', n).astype(np.float32)))
+            m.running_mean.zero_()
+    trunk.double()
+    last, names, hooks = {}, {m: n for n, m in trunk.named_modules()}, []
+
+    def conv_hook(mod, inp, out):
+        last['conv'] = mod
+
+    def bn_pre(mod, inp):
+        y, conv = inp[0], last['conv']
+        assert conv.out_channels == mod.num_features, (names[mod], names[conv])
+        yc = y.transpose(0, 1).reshape(mod.num_features, -1)
+        mean, std = yc.mean(dim=1).numpy(), yc.std(dim=1, unbiased=False).numpy()
+        sigma = np.sqrt(mod.running_var.numpy())
+        live = std > 0
+        mm, e = np.frexp(np.where(live, sigma / np.where(live, std, 1.0), 1.0))
+        q = np.where(live, np.ldexp(1.0, np.where(mm >= 0.7071067811865476, e, e - 1)), 1.0)
+        xi = synth.normal(seed, names[mod] + '.running_mean', (mod.num_features,)).astype(np.float64)
+        rm = np.where(live, np.round((mean * q / sigma + 0.3 * xi) * 32.0) / 32.0, xi) * sigma
+        conv.weight.mul_(t(q).view(-1, 1, 1, 1))
+        mod.running_mean.copy_(t(rm.astype(np.float32).astype(np.float64)))
+        return (y * t(q).view(1, -1, 1, 1),)
+
+    for m in trunk.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            hooks.append(m.register_forward_hook(conv_hook))
+        elif isinstance(m, torch.nn.BatchNorm2d):
+            hooks.append(m.register_forward_pre_hook(bn_pre))
+    with cpu_threads():
+        trunk(images.double())
+    for h_ in hooks:
+        h_.remove()
+    trunk.float()
+    return {k: v.detach().numpy().copy() for k, v in trunk.state_dict().items() if not k.endswith('num_batches_tracked')}
