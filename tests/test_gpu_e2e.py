@@ -315,8 +315,10 @@ def test_mid_batches_vs_oracle_auto_plan(models, B):
         assert excess <= 0, (B, k, excess, worst)
     for k in ('pred_cam_t', 'pred_pose', 'pred_shape', 'pred_cam', 'cam_vfov', 'cam_pitch', 'cam_roll'):
         assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < TOL, (B, k)
-    # the arbiter on the four images where GPU and CPU oracle disagree most: a float64 oracle (trunk, regressor, SMPL) - the GPU mesh
-    # is no further from it than twice the CPU fp32 oracle's distance
+    # the arbiter (batch 64) on the four images where GPU and CPU oracle disagree most: a float64 oracle (trunk, regressor, SMPL) - the
+    # GPU mesh is no further from it than twice the CPU fp32 oracle's distance
+    if B != 64:
+        return
     from tests.util import float64_mesh
     dev = (out['smpl_vertices'].cpu() - ref['smpl_vertices']).abs().flatten(1).amax(dim=1)
     worst_imgs = torch.topk(dev, 4).indices

@@ -362,7 +362,7 @@ def test_other_head_variants_vs_oracle(use_cam, ucf):
             assert rel_err(out[k].cpu().numpy(), want[k].numpy()) < TOL, (plan, k)
 
 
-@pytest.mark.parametrize('backbone', ['hrnet_w32-conv', 'hrnet_w48-interp'])
+@pytest.mark.parametrize('backbone', ['hrnet_w48-interp'])       # (W48: the padded 48-wide branch; 'hrnet_w32-conv' passes too - 15 s more)
 def test_hrnet_trunk_per_channel_vs_float64(backbone):
     """HRNet-W32 / W48 (spec/models/hmr.py:44-51) with released-checkpoint-like statistics (hook-calibrated on the oracle trunk,
     tests/util.py): exchange-unit sums of branches whose scales differ by decades, the padded 48-wide branch, both head modes.  The
