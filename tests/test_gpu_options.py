@@ -68,3 +68,30 @@ def test_opt_in_by_handle_and_by_environment(no_env, monkeypatch):
     with pytest.raises(_lib.SpecmiError):
         b.set_option('wsplit', 0)
     a.close(); b.close()
+
+
+def test_default_path_needs_no_experimental_option(no_env):
+    """With SPECMI_EXPERIMENTAL unset (tests/conftest.py sets it for the tests that pin variants and flip opt-ins): fresh modules,
+    commit, the whole pipeline under every stable plan, and the reference-composed fixture - the stable surface is all the drop-in
+    path itself ever touches."""
+    import numpy as np
+    from spec_amd import synth
+    from spec_amd.pipeline import SpecPipeline
+    from tests.util import golden, gpu_models, pinned_plan, rel_err, t
+    assert 'SPECMI_EXPERIMENTAL' not in os.environ
+    cc, hm = gpu_models(True, True, 'cuda:0')
+    g = golden('hmr_e2e_camfeats.npz')
+    B = int(g['batch'])
+    x = t(synth.images(int(g['seed_images']), B)).to('cuda:0')
+    args = [t(g[k]).to('cuda:0') for k in ('cam_rotmat', 'cam_intrinsics', 'bbox_scale', 'bbox_center', 'img_w', 'img_h')]
+    for plan in ('auto', 'throughput', 'latency', 'single'):
+        with pinned_plan(plan, cc, hm):
+            out = hm(x, *args)
+            for k in out:
+                assert rel_err(out[k].cpu().numpy(), g[f'out_{k}']) < 1e-4, (plan, k)
+            full = SpecPipeline(cc, hm)(x, args[2], args[3], args[4], args[5])
+            assert torch.isfinite(full['smpl_vertices']).all()
+    for eng in (cc.engine(torch.device('cuda:0')), hm.engine(torch.device('cuda:0'))):
+        eng.set_option('winograd', 0); eng.set_option('fuse_downsample', 0)        # the stable structure switches
+        eng.set_option('winograd', 1); eng.set_option('fuse_downsample', 1)
+        assert eng.get_option('experimental') == 0
