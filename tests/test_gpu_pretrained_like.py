@@ -140,6 +140,15 @@ def test_whole_path_vs_oracle(pl, B):
             assert err < TOL, (plan, k, err)
         d = _wmpjpe_mm(out['smpl_vertices'].cpu().numpy().astype(np.float64), ref['smpl_vertices'].numpy().astype(np.float64))
         assert d < 0.1, f'{plan}: delta W-MPJPE {d} mm'
+    if B == 8:      # the reference's nine-GEMM regressor loop instead of the float64-composed map (option head_collapse = 0)
+        eng = hm.engine(torch.device(DEV))
+        eng.set_option('head_collapse', 0)
+        try:
+            out = SpecPipeline(cc, hm)(x.to(DEV), sc.to(DEV), ce.to(DEV), iw.to(DEV), ih.to(DEV))
+        finally:
+            eng.set_option('head_collapse', 1)
+        for k in ('smpl_vertices', 'smpl_joints3d', 'smpl_joints2d', 'pred_pose', 'pred_shape', 'pred_cam'):
+            assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < TOL, ('loop', k)
 
 
 @pytest.mark.parametrize('plan', PLANS)
@@ -213,15 +222,20 @@ def conv_eng():
     e.close()
 
 
+# the second 3x3 convolution of a BasicBlock (ResNet-18 / 34, camcalib/config.py:81): stride 1 with the block input as residual
+BASIC_RES_SHAPES = [(64, 64, 3, 1, 56), (128, 128, 3, 1, 28), (256, 256, 3, 1, 14), (512, 512, 3, 1, 7)]
+
+
 @pytest.mark.parametrize('path', list(LAYER_PATHS))
-@pytest.mark.parametrize('shape', RESNET_SHAPES, ids=lambda s: 'c%d_%d_k%d_s%d_h%d' % s)
+@pytest.mark.parametrize('shape', RESNET_SHAPES + [s_ + ('res',) for s_ in BASIC_RES_SHAPES], ids=lambda s: 'c%d_%d_k%d_s%d_h%d' % s[:5] + ('_res' if len(s) > 5 else ''))
 def test_conv_layer_per_channel_with_wide_scales(conv_eng, shape, path):
     """A single fused conv + BN (+ residual) launch with released-checkpoint-like folds: scale = gamma / sigma over five decades with
     exact zeros and negatives, shifts that cancel a large pre-BN mean, a few all-zero filters, heavy-tailed filters and post-ReLU-like
     inputs with outliers.  Every OUTPUT CHANNEL against a float64 reference, next to a CPU fp32 evaluation of the same formula: a channel
     whose folded scale is 10^3 below its neighbours' cannot hide behind the tensor's max-norm."""
-    cin, cout, k, stride, H = shape
-    g = torch.Generator().manual_seed(cin * 11 + cout * 3 + k + H)
+    force_res = len(shape) > 5
+    cin, cout, k, stride, H = shape[:5]
+    g = torch.Generator().manual_seed(cin * 11 + cout * 3 + k + H + (7 if force_res else 0))
     B = 2 if H >= 28 else 3
     x = torch.relu(torch.randn(B, H, H, cin, generator=g) * 1.5 + 0.5)
     x = x * torch.where(torch.rand(cin, generator=g) < 0.02, 10.0, 1.0)                      # a few loud input channels
@@ -235,9 +249,9 @@ def test_conv_layer_per_channel_with_wide_scales(conv_eng, shape, path):
     sh = 0.5 * torch.randn(cout, generator=g) - (torch.randn(cout, generator=g) * 2.0) * sc
     pad = 1 if k == 3 else 0
     oh = (H + 2 * pad - k) // stride + 1
-    use_res = (k == 1 and cout >= 2 * cin)
+    use_res = force_res or (k == 1 and cout >= 2 * cin)
     res = torch.relu(torch.randn(B, oh, oh, cout, generator=g) * 2.0) if use_res else None
-    relu = bool((cin + cout + k) % 2)
+    relu = True if force_res else bool((cin + cout + k) % 2)
 
     def ref(dtype):
         y = torch.nn.functional.conv2d(x.to(dtype).permute(0, 3, 1, 2), w.to(dtype), stride=stride, padding=pad)
